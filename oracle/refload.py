@@ -1,0 +1,99 @@
+"""Import the ACTUAL reference package from /root/reference (build container only).
+
+TEST INFRASTRUCTURE ONLY.  /root/reference does not exist on the GPU box, so
+nothing that runs there may call this; it is used by oracle/make_golden.py (to
+produce tests/golden/) and by the ``-m "not gpu"`` tests that re-validate the
+restatements when the reference happens to be mounted.
+
+``plyfile`` and ``taichi`` are not installed here: a two-line
+``plyfile`` stub lets ``gsconverter`` import, and the package then runs on its
+CPU fallbacks (``HAS_TAICHI`` is False).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "gsconverter"))
+
+
+def load():
+    """-> (DataProcessor class, gpu_ops module, data_processor module)."""
+    if not available():
+        raise RuntimeError("reference not mounted at %s" % REFERENCE_ROOT)
+    if "plyfile" not in sys.modules:
+        stub = types.ModuleType("plyfile")
+        stub.PlyData = object
+        stub.PlyElement = object
+        sys.modules["plyfile"] = stub
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from gsconverter.processing import DataProcessor, gpu_ops  # noqa: E402
+    import gsconverter.processing.data_processor as dpmod  # noqa: E402
+    return DataProcessor, gpu_ops, dpmod
+
+
+def xyz_to_struct(xyz, extra_index=True):
+    import numpy as np
+    dt = [("x", "f4"), ("y", "f4"), ("z", "f4")]
+    if extra_index:
+        dt.append(("orig_index", "i8"))
+    arr = np.zeros(len(xyz), dtype=dt)
+    arr["x"], arr["y"], arr["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if extra_index:
+        arr["orig_index"] = np.arange(len(xyz))
+    return arr
+
+
+def reference_sor(xyz, k=25, threshold_factor=10.5, intensity=None):
+    """Run the reference's own ``DataProcessor.remove_flyers`` CPU branch and capture the
+    locals of its frame (the function computes ``mask`` at data_processor.py:180 but returns
+    the unfiltered data)."""
+    import numpy as np
+    DataProcessor, gpu_ops, dpmod = load()
+    assert not gpu_ops.HAS_TAICHI
+    cap = {}
+    saved = dpmod.status_print
+
+    def spy(*a, **kw):
+        f = sys._getframe(1)
+        loc = f.f_locals
+        if "mask" in loc and "all_mean_dists" in loc:
+            cap["mask"] = np.array(loc["mask"], copy=True)
+            cap["mean_dists"] = np.array(loc["all_mean_dists"], copy=True)
+            cap["threshold"] = loc["threshold"]
+            cap["mean"] = loc["global_mean"]
+            cap["std"] = loc["global_std"]
+            cap["k"] = loc["k"]
+            cap["threshold_factor"] = loc["threshold_factor"]
+
+    dpmod.status_print = spy
+    try:
+        with np.errstate(invalid="ignore"):
+            DataProcessor(xyz_to_struct(xyz, False)).remove_flyers(k, threshold_factor, intensity=intensity)
+    finally:
+        dpmod.status_print = saved
+    return cap
+
+
+def reference_density(xyz, voxel_size=1.0, threshold_percentage=0.32, sensitivity=None, keep_multicluster=False):
+    """Run the reference's own ``apply_density_filter``; the survivor mask is recovered from an
+    extra ``orig_index`` field carried through the structured array."""
+    import numpy as np
+    DataProcessor, _, dpmod = load()
+    msgs = []
+    saved = dpmod.status_print
+    dpmod.status_print = lambda *a, **kw: msgs.append(" ".join(map(str, a)))
+    try:
+        out = DataProcessor(xyz_to_struct(xyz, True)).apply_density_filter(
+            voxel_size, threshold_percentage, sensitivity=sensitivity, keep_multicluster=keep_multicluster)
+    finally:
+        dpmod.status_print = saved
+    mask = np.zeros(len(xyz), dtype=bool)
+    mask[out["orig_index"]] = True
+    return {"mask": mask, "messages": msgs}
