@@ -1,0 +1,298 @@
+"""ctypes binding of libgsx_hip.so (C ABI declared in include/gsx_hip.h).
+
+numpy + ctypes only -- no torch, no Taichi.  The library is built in-tree by
+``3dgsconverter_amd/build.py`` (hipcc, gfx950).  There is deliberately NO CPU
+fallback anywhere in this package: if the library or a GPU is missing the calls
+raise ``GsxError`` (a RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsx_hip.so")
+
+KNN_AUTO, KNN_BRUTE, KNN_GRID = 0, 1, 2
+T_SOR_KNN, T_SOR_BIN, T_SOR_FALLBACK, T_SOR_STATS, T_DENSITY, T_KMEANS_ASSIGN, T_KMEANS_UPDATE, T_QUANTIZE = range(8)
+
+
+class GsxError(RuntimeError):
+    """Raised for every failure of the HIP path (missing library, no GPU, HIP error)."""
+
+
+class SorInfo(C.Structure):
+    _fields_ = [("algo", C.c_int32), ("grid_dim", C.c_int32 * 3), ("cell_size", C.c_float),
+                ("n_cells", C.c_int64), ("n_bricks", C.c_int64), ("n_fallback", C.c_int64),
+                ("n_exhaustive", C.c_int64)]
+
+    def as_dict(self):
+        return {"algo": int(self.algo), "grid_dim": tuple(int(v) for v in self.grid_dim),
+                "cell_size": float(self.cell_size), "n_cells": int(self.n_cells), "n_bricks": int(self.n_bricks),
+                "n_fallback": int(self.n_fallback), "n_exhaustive": int(self.n_exhaustive)}
+
+
+# name -> (restype, argtypes); every symbol include/gsx_hip.h declares
+_P, _I64, _I, _D = C.c_void_p, C.c_int64, C.c_int, C.c_double
+SIGNATURES = {
+    "gsx_version": (C.c_char_p, []),
+    "gsx_last_error": (C.c_char_p, []),
+    "gsx_device_count": (_I, []),
+    "gsx_ctx_create": (_I, [_I, C.POINTER(_P)]),
+    "gsx_ctx_destroy": (None, [_P]),
+    "gsx_ctx_set_stream": (_I, [_P, _P]),
+    "gsx_ctx_synchronize": (_I, [_P]),
+    "gsx_ctx_set_timing": (_I, [_P, _I]),
+    "gsx_ctx_reset_timing": (_I, [_P]),
+    "gsx_ctx_get_timing": (_I, [_P, _I, C.POINTER(C.c_uint64), C.POINTER(_D)]),
+    "gsx_ctx_set_param": (_I, [_P, C.c_char_p, _D]),
+    "gsx_dev_malloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gsx_dev_free": (_I, [_P, _P]),
+    "gsx_dev_upload": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_dev_download": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
+    "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
+    "gsx_sor_mask_dev": (_I, [_P, _P, _I64, _P, _P]),
+    "gsx_sor_filter": (_I, [_P, _P, _P, _I64, _I64, _I, _D, _I, _P, _P, _P, C.POINTER(SorInfo)]),
+    "gsx_density_voxels": (_I, [_P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
+    "gsx_density_mask": (_I, [_P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
+    "gsx_kmeans_lloyd": (_I, [_P, _I64, _I, _I, _I, _P, _P, _P]),
+    "gsx_quantize_sorted_codebook": (_I, [_P, _I64, _P, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol (raises GsxError if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsxError("libgsx_hip.so is not built: run `python 3dgsconverter_amd/build.py` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise GsxError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GsxError("libgsx_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().gsx_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise GsxError("%s failed: %s" % (what, last_error()))
+
+
+def device_count() -> int:
+    try:
+        return int(load().gsx_device_count())
+    except GsxError:
+        return 0
+
+
+def has_hip() -> bool:
+    return device_count() > 0
+
+
+def require_hip():
+    lib = load()
+    if lib.gsx_device_count() <= 0:
+        raise GsxError("no MI355X (gfx950) device visible to HIP; the HIP path has no CPU fallback")
+    return lib
+
+
+def _xyz_pointers(xyz_or_cols):
+    """Accept an (N,3) float32 C-contiguous array (the reference's `coords`, data_processor.py:139)
+    or a tuple of three contiguous float32 columns. -> (keepalive, px, py, pz, stride, n)"""
+    if isinstance(xyz_or_cols, (tuple, list)):
+        cols = [np.ascontiguousarray(c, dtype=np.float32) for c in xyz_or_cols]
+        if len(cols) != 3 or len({len(c) for c in cols}) != 1:
+            raise ValueError("expected three equally long columns")
+        return cols, cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, 1, len(cols[0])
+    a = np.ascontiguousarray(xyz_or_cols, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("Requires 3D data")  # same message as gpu_ops.py:198
+    base = a.ctypes.data
+    return a, base, base + 4, base + 8, 3, a.shape[0]
+
+
+def sor_filter(xyz, k: int, threshold_factor: float, algo: int = KNN_AUTO, want_mean: bool = True,
+               want_info: bool = False):
+    """Whole SOR on one GPU from host buffers (C ABI gsx_sor_filter).
+    -> dict(mask bool[N], mean_dists f32[N] | None, mean, std, threshold (np.float32), info | None)"""
+    lib = require_hip()
+    keep, px, py, pz, stride, n = _xyz_pointers(xyz)
+    mask = np.empty(n, dtype=np.uint8)
+    mean = np.empty(n, dtype=np.float32) if want_mean else None
+    stats = np.empty(3, dtype=np.float32)
+    info = SorInfo() if want_info else None
+    rc = lib.gsx_sor_filter(px, py, pz, stride, n, int(k), float(threshold_factor), int(algo),
+                            mask.ctypes.data, mean.ctypes.data if want_mean else None, stats.ctypes.data,
+                            C.byref(info) if want_info else None)
+    check(rc, "gsx_sor_filter")
+    del keep
+    return {"mask": mask.view(np.bool_), "mean_dists": mean, "mean": stats[0], "std": stats[1],
+            "threshold": stats[2], "info": info.as_dict() if want_info else None}
+
+
+def density_voxels(xyz, voxel_size: float, min_points: int, dense_cap: int | None = None):
+    """Voxel occupancy on the GPU (C ABI gsx_density_voxels).
+    -> dict(n_unique, dense_keys int64[M,3] in np.unique(axis=0) order, dense_counts int64[M])"""
+    lib = require_hip()
+    keep, px, py, pz, stride, n = _xyz_pointers(xyz)
+    if dense_cap is None:
+        # count >= min_points  =>  at most n / max(min_points,1) dense voxels
+        dense_cap = int(min(n, n // max(int(min_points), 1) + 1))
+    keys = np.empty((max(dense_cap, 1), 3), dtype=np.int64)
+    counts = np.empty(max(dense_cap, 1), dtype=np.int64)
+    n_unique = C.c_int64()
+    n_dense = C.c_int64()
+    rc = lib.gsx_density_voxels(px, py, pz, stride, n, float(voxel_size), int(min_points), int(dense_cap),
+                                C.byref(n_unique), C.byref(n_dense), keys.ctypes.data, counts.ctypes.data)
+    check(rc, "gsx_density_voxels")
+    del keep
+    m = int(n_dense.value)
+    return {"n_unique": int(n_unique.value), "dense_keys": keys[:m].copy(), "dense_counts": counts[:m].copy()}
+
+
+def density_mask(xyz, voxel_size: float, kept_keys: np.ndarray) -> np.ndarray:
+    """mask[i] = voxel(i) in kept_keys (C ABI gsx_density_mask)."""
+    lib = require_hip()
+    keep, px, py, pz, stride, n = _xyz_pointers(xyz)
+    kk = np.ascontiguousarray(kept_keys, dtype=np.int64).reshape(-1, 3)
+    mask = np.empty(n, dtype=np.uint8)
+    check(lib.gsx_density_mask(px, py, pz, stride, n, float(voxel_size), kk.ctypes.data, len(kk), mask.ctypes.data),
+          "gsx_density_mask")
+    del keep
+    return mask.view(np.bool_)
+
+
+def kmeans_lloyd(data: np.ndarray, init_centroids: np.ndarray, max_iter: int):
+    """max_iter x (assign, update) on the GPU (C ABI gsx_kmeans_lloyd) -> (centroids f32[K,D], labels i32[N])."""
+    lib = require_hip()
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    init = np.ascontiguousarray(init_centroids, dtype=np.float32)
+    n, d = data.shape
+    k = init.shape[0]
+    if init.shape[1] != d:
+        raise ValueError("init_centroids has the wrong dimensionality")
+    cent = np.empty((k, d), dtype=np.float32)
+    labels = np.empty(n, dtype=np.int32)
+    check(lib.gsx_kmeans_lloyd(data.ctypes.data, n, d, k, int(max_iter), init.ctypes.data, cent.ctypes.data,
+                               labels.ctypes.data), "gsx_kmeans_lloyd")
+    return cent, labels
+
+
+def quantize_sorted_codebook(vals: np.ndarray, codebook: np.ndarray) -> np.ndarray:
+    lib = require_hip()
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    cb = np.ascontiguousarray(codebook, dtype=np.float32)
+    if len(cb) > 256:
+        raise ValueError("codebook indices are uint8: at most 256 entries")
+    out = np.empty(vals.shape, dtype=np.uint8)
+    check(lib.gsx_quantize_sorted_codebook(vals.ctypes.data, vals.size, cb.ctypes.data, len(cb), out.ctypes.data),
+          "gsx_quantize_sorted_codebook")
+    return out
+
+
+class DeviceArray:
+    """A raw HBM allocation owned by a Context (only used where no other allocator is around)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.gsx_dev_malloc(ctx.handle, self.nbytes, C.byref(p)), "gsx_dev_malloc")
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        check(self.ctx.lib.gsx_dev_upload(self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload")
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.ctx.lib.gsx_dev_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "gsx_dev_download")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.gsx_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """gsx_ctx wrapper: device-resident entry points (pointers are plain ints)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = require_hip()
+        h = C.c_void_p()
+        check(self.lib.gsx_ctx_create(int(device), C.byref(h)), "gsx_ctx_create")
+        self.handle = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self.handle:
+            self.lib.gsx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream: int):
+        check(self.lib.gsx_ctx_set_stream(self.handle, C.c_void_p(int(stream))), "gsx_ctx_set_stream")
+
+    def synchronize(self):
+        check(self.lib.gsx_ctx_synchronize(self.handle), "gsx_ctx_synchronize")
+
+    def set_param(self, name: str, value: float):
+        check(self.lib.gsx_ctx_set_param(self.handle, name.encode(), float(value)), "gsx_ctx_set_param")
+
+    def set_timing(self, on: bool):
+        check(self.lib.gsx_ctx_set_timing(self.handle, 1 if on else 0), "gsx_ctx_set_timing")
+
+    def reset_timing(self):
+        check(self.lib.gsx_ctx_reset_timing(self.handle), "gsx_ctx_reset_timing")
+
+    def timing(self, slot: int):
+        n = C.c_uint64()
+        ms = C.c_double()
+        check(self.lib.gsx_ctx_get_timing(self.handle, int(slot), C.byref(n), C.byref(ms)), "gsx_ctx_get_timing")
+        return int(n.value), float(ms.value)
+
+    def alloc(self, nbytes: int) -> DeviceArray:
+        return DeviceArray(self, nbytes)
+
+    def sor_knn(self, x: int, y: int, z: int, stride: int, n_ref: int, q_begin: int, q_count: int, k: int,
+                mean_out: int, algo: int = KNN_AUTO, want_info: bool = False):
+        info = SorInfo() if want_info else None
+        check(self.lib.gsx_sor_knn_dev(self.handle, x, y, z, stride, n_ref, q_begin, q_count, int(k), int(algo),
+                                       mean_out, C.byref(info) if want_info else None), "gsx_sor_knn_dev")
+        return info.as_dict() if want_info else None
+
+    def sor_stats(self, mean_dists: int, n: int, threshold_factor: float, stats_out: int):
+        check(self.lib.gsx_sor_stats_dev(self.handle, mean_dists, n, float(threshold_factor), stats_out),
+              "gsx_sor_stats_dev")
+
+    def sor_mask(self, mean_dists: int, n: int, threshold_ptr: int, mask_out: int):
+        check(self.lib.gsx_sor_mask_dev(self.handle, mean_dists, n, threshold_ptr, mask_out), "gsx_sor_mask_dev")

@@ -1,0 +1,363 @@
+// api.hip -- C-ABI entry points of libgsx_hip.so (see include/gsx_hip.h).
+#include <algorithm>
+#include <mutex>
+
+#include "gsx_common.h"
+#include "sor_grid_params.h"
+
+namespace gsx {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return 0;
+    if (p) {
+        GSX_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;  // a little headroom: fewer re-allocations when N drifts
+    GSX_HIP(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int timing_begin(gsx_ctx *ctx, int slot)
+{
+    if (!ctx->timing) return 0;
+    TimingSlot &s = ctx->slots[slot];
+    if (s.used + 2 > s.ev.size()) {
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            GSX_HIP(hipEventCreate(&e));
+            s.ev.push_back(e);
+        }
+    }
+    GSX_HIP(hipEventRecord(s.ev[s.used], ctx->stream));
+    return 0;
+}
+
+int timing_end(gsx_ctx *ctx, int slot)
+{
+    if (!ctx->timing) return 0;
+    TimingSlot &s = ctx->slots[slot];
+    GSX_HIP(hipEventRecord(s.ev[s.used + 1], ctx->stream));
+    s.used += 2;
+    return 0;
+}
+
+static int timing_resolve(gsx_ctx *ctx, int slot)
+{
+    TimingSlot &s = ctx->slots[slot];
+    for (size_t i = 0; i + 1 < s.used; i += 2) {
+        float ms = 0.f;
+        GSX_HIP(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+        s.total_ms += ms;
+        s.launches += 1;
+    }
+    s.used = 0;
+    return 0;
+}
+
+// kernels implemented in the other translation units
+int launch_pack_points(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, float4 *);
+int launch_knn_brute(gsx_ctx *, const float4 *, int64_t, int64_t, int64_t, const unsigned *, const unsigned *,
+                     int64_t, int, float *);
+int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int,
+                    float *, gsx_sor_info *);
+int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
+int launch_sor_mask(gsx_ctx *, const float *, int64_t, const float *, uint8_t *);
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" {
+
+const char *gsx_version(void) { return "gsx-hip 0.1 (gfx950)"; }
+const char *gsx_last_error(void) { return g_err.c_str(); }
+
+int gsx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int gsx_ctx_create(int device, gsx_ctx **out)
+{
+    if (!out) GSX_FAIL("gsx_ctx_create: null out");
+    int n = gsx_device_count();
+    if (n <= 0) GSX_FAIL("gsx_ctx_create: no HIP device visible");
+    if (device < 0 || device >= n) GSX_FAIL("gsx_ctx_create: device %d out of range (%d visible)", device, n);
+    GSX_HIP(hipSetDevice(device));
+    gsx_ctx *c = new gsx_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    GSX_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete c;
+        GSX_FAIL("gsx_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                 prop.gcnArchName);
+    }
+    *out = c;
+    return 0;
+}
+
+void gsx_ctx_destroy(gsx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->slots)
+        for (auto e : s.ev) (void)hipEventDestroy(e);
+    gsx::DevBuf *bufs[] = {&c->packed, &c->qsorted, &c->rank, &c->cellcnt, &c->cellstart, &c->qcellcnt,
+                           &c->qcellstart, &c->qrank, &c->scanpart, &c->gridparams, &c->bboxpart, &c->faillist,
+                           &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
+    for (auto b : bufs) b->release();
+    delete c;
+}
+
+int gsx_ctx_set_stream(gsx_ctx *c, void *s)
+{
+    if (!c) GSX_FAIL("null ctx");
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return 0;
+}
+
+int gsx_ctx_synchronize(gsx_ctx *c)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_ctx_set_timing(gsx_ctx *c, int enable)
+{
+    if (!c) GSX_FAIL("null ctx");
+    c->timing = enable != 0;
+    return 0;
+}
+
+int gsx_ctx_reset_timing(gsx_ctx *c)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    for (auto &s : c->slots) {
+        s.used = 0;
+        s.launches = 0;
+        s.total_ms = 0.0;
+    }
+    return 0;
+}
+
+int gsx_ctx_get_timing(gsx_ctx *c, int slot, uint64_t *launches, double *total_ms)
+{
+    if (!c || slot < 0 || slot >= GSX_T_SLOTS) GSX_FAIL("gsx_ctx_get_timing: bad arguments");
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    GSX_CHECK(timing_resolve(c, slot));
+    if (launches) *launches = c->slots[slot].launches;
+    if (total_ms) *total_ms = c->slots[slot].total_ms;
+    return 0;
+}
+
+int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
+{
+    if (!c || !name) GSX_FAIL("gsx_ctx_set_param: bad arguments");
+    if (!strcmp(name, "grid_points_per_cell")) {
+        if (!(value >= 1.0 && value <= 512.0)) GSX_FAIL("grid_points_per_cell must be in [1,512]");
+        c->grid_points_per_cell = value;
+    } else if (!strcmp(name, "brute_below")) {
+        c->brute_below = (int64_t)value;
+    } else {
+        GSX_FAIL("gsx_ctx_set_param: unknown parameter '%s'", name);
+    }
+    return 0;
+}
+
+int gsx_dev_malloc(gsx_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) GSX_FAIL("gsx_dev_malloc: bad arguments");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+
+int gsx_dev_free(gsx_ctx *c, void *dptr)
+{
+    if (!c) GSX_FAIL("null ctx");
+    if (dptr) GSX_HIP(hipFree(dptr));
+    return 0;
+}
+
+int gsx_dev_upload(gsx_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_dev_download(gsx_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ SOR
+int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
+                    int64_t q_begin, int64_t q_count, int k, int algo, float *mean_out, gsx_sor_info *info)
+{
+    if (!c || !x || !y || !z || !mean_out) GSX_FAIL("gsx_sor_knn_dev: null argument");
+    if (n_ref <= 0 || n_ref >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_knn_dev: n_ref=%lld out of range", (long long)n_ref);
+    if (q_begin < 0 || q_count < 0 || q_begin + q_count > n_ref) GSX_FAIL("gsx_sor_knn_dev: query range out of bounds");
+    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_knn_dev: k=%d not supported (1 <= k <= 64)", k);
+    if (stride < 1) GSX_FAIL("gsx_sor_knn_dev: bad stride");
+    GSX_HIP(hipSetDevice(c->device));
+    if (q_count == 0) return 0;
+    if (algo == GSX_KNN_AUTO) algo = n_ref < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID;
+    if (algo == GSX_KNN_BRUTE) {
+        GSX_CHECK(c->packed.reserve(sizeof(float4) * (size_t)n_ref));
+        GSX_CHECK(timing_begin(c, GSX_T_SOR_BIN));
+        GSX_CHECK(launch_pack_points(c, x, y, z, stride, n_ref, c->packed.as<float4>()));
+        GSX_CHECK(timing_end(c, GSX_T_SOR_BIN));
+        GSX_CHECK(timing_begin(c, GSX_T_SOR_KNN));
+        GSX_CHECK(launch_knn_brute(c, c->packed.as<float4>(), n_ref, q_begin, q_count, nullptr, nullptr, 0, k, mean_out));
+        GSX_CHECK(timing_end(c, GSX_T_SOR_KNN));
+        if (info) {
+            memset(info, 0, sizeof(*info));
+            info->algo = GSX_KNN_BRUTE;
+            GSX_HIP(hipStreamSynchronize(c->stream));
+        }
+        return 0;
+    }
+    if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, info);
+    GSX_FAIL("gsx_sor_knn_dev: unknown algo %d", algo);
+}
+
+int gsx_sor_stats_dev(gsx_ctx *c, const float *md, int64_t n, double factor, float *stats_dev)
+{
+    if (!c || !md || !stats_dev) GSX_FAIL("gsx_sor_stats_dev: null argument");
+    if (reinterpret_cast<uintptr_t>(md) & 15) GSX_FAIL("gsx_sor_stats_dev: mean_dists must be 16-byte aligned");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_CHECK(timing_begin(c, GSX_T_SOR_STATS));
+    GSX_CHECK(launch_sor_stats(c, md, n, factor, stats_dev));
+    GSX_CHECK(timing_end(c, GSX_T_SOR_STATS));
+    return 0;
+}
+
+int gsx_sor_mask_dev(gsx_ctx *c, const float *md, int64_t n, const float *thr_dev, uint8_t *mask)
+{
+    if (!c || !md || !thr_dev || !mask) GSX_FAIL("gsx_sor_mask_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_CHECK(timing_begin(c, GSX_T_SOR_STATS));
+    GSX_CHECK(launch_sor_mask(c, md, n, thr_dev, mask));
+    GSX_CHECK(timing_end(c, GSX_T_SOR_STATS));
+    return 0;
+}
+
+// one cached context per process for the host-buffer entry points (callers are single-threaded,
+// SURVEY.md 8(b)); guarded anyway
+static std::mutex g_host_mu;
+static gsx_ctx *g_host_ctx = nullptr;
+
+static int host_ctx(gsx_ctx **out)
+{
+    if (!g_host_ctx) GSX_CHECK(gsx_ctx_create(0, &g_host_ctx));
+    GSX_HIP(hipSetDevice(g_host_ctx->device));
+    *out = g_host_ctx;
+    return 0;
+}
+
+// stage strided host xyz as three device columns (SoA in HBM)
+static int upload_xyz(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                      float **dx, float **dy, float **dz, int64_t *dstride)
+{
+    if (stride == 1) {
+        GSX_CHECK(c->scratch.reserve(sizeof(float) * 3 * (size_t)n));
+        float *base = c->scratch.as<float>();
+        GSX_HIP(hipMemcpyAsync(base, x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(hipMemcpyAsync(base + n, y, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(hipMemcpyAsync(base + 2 * n, z, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        *dx = base; *dy = base + n; *dz = base + 2 * n; *dstride = 1;
+        return 0;
+    }
+    if (stride == 3 && y == x + 1 && z == x + 2) {  // the reference's (N,3) coords: one contiguous copy
+        GSX_CHECK(c->scratch.reserve(sizeof(float) * 3 * (size_t)n));
+        float *base = c->scratch.as<float>();
+        GSX_HIP(hipMemcpyAsync(base, x, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        *dx = base; *dy = base + 1; *dz = base + 2; *dstride = 3;
+        return 0;
+    }
+    GSX_FAIL("xyz layout not supported by the host entry points (use three contiguous columns or (N,3) rows)");
+}
+
+int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t stride, int64_t n, int k, double factor,
+                   int algo, uint8_t *mask_out, float *mean_out, float *stats_out, gsx_sor_info *info)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!x || !y || !z || !mask_out) GSX_FAIL("gsx_sor_filter: null argument");
+    if (n <= 0) GSX_FAIL("gsx_sor_filter: empty cloud");
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    float *dx, *dy, *dz;
+    int64_t ds;
+    GSX_CHECK(upload_xyz(c, x, y, z, stride, n, &dx, &dy, &dz, &ds));
+    GSX_CHECK(c->scratch2.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch3.reserve(sizeof(float) * 4));
+    GSX_CHECK(c->scratch4.reserve((size_t)n + 4));
+    float *dmd = c->scratch2.as<float>();
+    float *dstats = c->scratch3.as<float>();
+    uint8_t *dmask = c->scratch4.as<uint8_t>();
+    GSX_CHECK(gsx_sor_knn_dev(c, dx, dy, dz, ds, n, 0, n, k, algo, dmd, nullptr));
+    GSX_CHECK(gsx_sor_stats_dev(c, dmd, n, factor, dstats));
+    GSX_CHECK(gsx_sor_mask_dev(c, dmd, n, dstats + 2, dmask));
+    GSX_HIP(hipMemcpyAsync(mask_out, dmask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (mean_out) GSX_HIP(hipMemcpyAsync(mean_out, dmd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    if (info) {
+        // re-query diagnostics without recomputing: only the grid path has device-side counters
+        memset(info, 0, sizeof(*info));
+        int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
+        info->algo = used;
+        if (used == GSX_KNN_GRID) {
+            GridParams hgp;
+            GSX_HIP(hipMemcpy(&hgp, c->gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
+            info->grid_dim[0] = hgp.nx; info->grid_dim[1] = hgp.ny; info->grid_dim[2] = hgp.nz;
+            info->cell_size = hgp.h;
+            info->n_cells = hgp.ncells;
+            info->n_bricks = hgp.nbricks;
+            info->n_fallback = hgp.fail_count;
+            info->n_exhaustive = hgp.exhaustive_count;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

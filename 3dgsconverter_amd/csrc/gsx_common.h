@@ -1,0 +1,101 @@
+// gsx_common.h -- context, error plumbing, workspace arena and timing for libgsx_hip.so.
+// gfx950 only: wave64 is hard-coded throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gsx_hip.h"
+
+namespace gsx {
+
+constexpr int WAVE = 64;
+
+void set_error(const char *fmt, ...);
+
+#define GSX_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            gsx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                           __LINE__);                                                         \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define GSX_CHECK(expr)            \
+    do {                           \
+        int r__ = (expr);          \
+        if (r__ != 0) return r__;  \
+    } while (0)
+
+#define GSX_FAIL(...)                \
+    do {                             \
+        gsx::set_error(__VA_ARGS__); \
+        return 1;                    \
+    } while (0)
+
+// A grow-only device buffer owned by the context (no hipMalloc inside a timed step once warm).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimingSlot {
+    std::vector<hipEvent_t> ev;  // pairs: start, stop
+    size_t used = 0;
+    uint64_t launches = 0;       // resolved so far
+    double total_ms = 0.0;
+};
+
+}  // namespace gsx
+
+struct gsx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    gsx::TimingSlot slots[GSX_T_SLOTS];
+    int num_cu = 256;
+
+    // tunables
+    double grid_points_per_cell = 7.0;
+    int64_t brute_below = 2048;
+
+    // SOR workspace
+    gsx::DevBuf packed;      // float4[n_ref]  (brute: original order; grid: cell-sorted refs)
+    gsx::DevBuf qsorted;     // float4[q_count] cell-sorted queries when q != all refs
+    gsx::DevBuf rank;        // u32[n_ref] rank of a point inside its cell
+    gsx::DevBuf cellcnt;     // u32[cap+1]
+    gsx::DevBuf cellstart;   // u32[cap+1]
+    gsx::DevBuf qcellcnt, qcellstart, qrank;
+    gsx::DevBuf scanpart;    // u32 block partials
+    gsx::DevBuf gridparams;  // GridParams + work counters
+    gsx::DevBuf bboxpart;    // float[6 * blocks]
+    gsx::DevBuf faillist;    // u32[q_count]
+    gsx::DevBuf statspart;   // float chunk sums
+    gsx::DevBuf scratch;     // host-API staging
+    gsx::DevBuf scratch2;
+    gsx::DevBuf scratch3;
+    gsx::DevBuf scratch4;
+    gsx::DevBuf scratch5;
+};
+
+namespace gsx {
+
+// RAII-less timing helper: call begin/end around a group of launches on ctx->stream.
+int timing_begin(gsx_ctx *ctx, int slot);
+int timing_end(gsx_ctx *ctx, int slot);
+
+inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gsx

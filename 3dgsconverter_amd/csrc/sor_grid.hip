@@ -1,0 +1,646 @@
+// sor_grid.hip -- grid-binned EXACT k-nearest-neighbour mean distance.
+//
+// Replaces the hot loop of data_processor.py:160-173 (cKDTree build + query(k+1) + row
+// mean) and supersedes the reference's approximate Taichi kernel gpu_ops.py:98-176 and
+// its numpy hash-grid prep gpu_ops.py:203-237 (27 cells, K<=50, hash collisions; SURVEY
+// F4/F5).  Results are bit-identical to the cKDTree path.
+//
+// Pipeline (all on one stream, no host round trip):
+//   bbox_partial -> grid_params            per-axis min/max, cell edge h for ~m pts/cell
+//   cell_count                             cell id per point, atomic histogram, rank in cell
+//   scan_partials / scan_top / scan_apply  exclusive scan -> cell_start
+//   cell_scatter                           counting sort into float4 {x,y,z,orig} (x-fastest cells)
+//   knn_brick                              one WAVE per 2x2x2-cell brick (~56 queries)
+//   knn_ring                               expanding-ring exact fallback for the few queries
+//                                          whose (k+1)-th neighbour is farther than one cell
+//
+// knn_brick: the 64 lanes of a wave are 64 queries of one brick.  The brick's 4x4x4-cell
+// neighbourhood is 16 x-rows, each a CONTIGUOUS range of the sorted array; the wave walks
+// those ranges in lock step with wave-uniform (scalar-cache) loads -- no LDS staging, no
+// per-lane addressing.  Phase 1 only FILTERS: 6 f32 ops for the squared distance, one
+// compare against r_safe^2 and one shift-or build a per-lane bit mask (32 candidates per
+// word, words parked in LDS).  Phase 2 walks each lane's set bits (~4.19*m of ~512) with a
+// private cursor, recomputes those distances in float64 exactly as cKDTree does and keeps
+// the k+1 smallest in a register-resident sorted list.  A query is exact iff its (k+1)-th
+// distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is farther.
+#include "gsx_common.h"
+#include "knn_common.h"
+#include "sor_grid_params.h"
+
+namespace gsx {
+
+
+constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index rounding bound, see r_safe)
+constexpr int SCAN_BLOCK = 2048;    // elements per scan block (256 threads x 8)
+constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
+constexpr int WCAP = 32;            // mask words parked in LDS per wave between drains
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------- bbox + grid params
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ z, int64_t stride, int n,
+                                                           float *__restrict__ part)
+{
+    __shared__ float red[6][4];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v[3] = {x[(int64_t)i * stride], y[(int64_t)i * stride], z[(int64_t)i * stride]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], v[a]);
+            mx[a] = fmaxf(mx[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            red[a][w] = mn[a];
+            red[3 + a][w] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[threadIdx.x][0];
+        for (int i = 1; i < 4; ++i) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][i]) : fmaxf(v, red[threadIdx.x][i]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
+                                                         double pts_per_cell, int cell_cap,
+                                                         GridParams *__restrict__ gp)
+{
+    const int lane = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float acc = a < 3 ? __builtin_inff() : -__builtin_inff();
+        for (int i = lane; i < nparts; i += 64) acc = a < 3 ? fminf(acc, part[i * 6 + a]) : fmaxf(acc, part[i * 6 + a]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float o = __shfl_xor(acc, off);
+            acc = a < 3 ? fminf(acc, o) : fmaxf(acc, o);
+        }
+        v[a] = acc;
+    }
+    if (lane != 0) return;
+    double e[3] = {(double)v[3] - (double)v[0], (double)v[4] - (double)v[1], (double)v[5] - (double)v[2]};
+    double vol = 1.0, emax = 0.0;
+    int nd = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (e[a] > 0.0) { vol *= e[a]; ++nd; }
+        emax = e[a] > emax ? e[a] : emax;
+    }
+    double h;
+    if (nd == 0 || !(emax < 1e300)) {
+        h = 1.0;
+    } else {
+        double per = vol * pts_per_cell / (double)(n > 0 ? n : 1);
+        h = nd == 3 ? cbrt(per) : (nd == 2 ? sqrt(per) : per);
+        double hmin = emax / (double)(MAX_DIM - 1);
+        if (!(h > hmin)) h = hmin;
+    }
+    int nx, ny, nz;
+    float inv_h;
+    for (int it = 0; it < 256; ++it) {
+        inv_h = (float)(1.0 / h);
+        // dims from the SAME f32 arithmetic the kernels use, so no point ever indexes past the grid
+        nx = (int)((v[3] - v[0]) * inv_h) + 1;
+        ny = (int)((v[4] - v[1]) * inv_h) + 1;
+        nz = (int)((v[5] - v[2]) * inv_h) + 1;
+        bool ok = nx <= MAX_DIM && ny <= MAX_DIM && nz <= MAX_DIM && nx > 0 && ny > 0 && nz > 0 &&
+                  (long long)nx * ny * nz <= (long long)cell_cap;
+        if (ok) break;
+        h *= 1.1;
+    }
+    if (!(nx > 0 && ny > 0 && nz > 0) || (long long)nx * ny * nz > (long long)cell_cap) {  // NaN / inf input
+        nx = ny = nz = 1;
+        inv_h = 0.0f;
+    }
+    gp->ox = v[0]; gp->oy = v[1]; gp->oz = v[2];
+    gp->inv_h = inv_h;
+    gp->h = (float)h;
+    gp->nx = nx; gp->ny = ny; gp->nz = nz;
+    gp->ncells = nx * ny * nz;
+    gp->nbx = (nx + 1) / 2; gp->nby = (ny + 1) / 2; gp->nbz = (nz + 1) / 2;
+    gp->nbricks = gp->nbx * gp->nby * gp->nbz;
+    // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
+    // f32 cell index floor(fl(fl(x-o)*inv_h)) is monotone and off by < dim*2^-22 <= 2.5e-4 cells.
+    double hp = inv_h > 0.0f ? 1.0 / (double)inv_h : 0.0;
+    double r1 = hp * (1.0 - 1e-3);
+    gp->hprime = hp;
+    gp->r1sq = r1 * r1;
+    gp->tau1 = bound_from(r1 * r1);
+    gp->brick_next = 0;
+    gp->fail_count = 0;
+    gp->ring_next = 0;
+    gp->exhaustive_count = 0;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim)
+{
+    int c = (int)((v - o) * inv_h);
+    return min(max(c, 0), dim - 1);
+}
+
+__device__ __forceinline__ int cell_of(const GridParams &g, float x, float y, float z)
+{
+    int cx = cell_coord(x, g.ox, g.inv_h, g.nx);
+    int cy = cell_coord(y, g.oy, g.inv_h, g.ny);
+    int cz = cell_coord(z, g.oz, g.inv_h, g.nz);
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+
+// ---------------------------------------------------------------- counting sort by cell
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned *__restrict__ p, const GridParams *__restrict__ gp)
+{
+    const int n = gp->ncells + 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ z, int64_t stride, int first, int n,
+                                                         const GridParams *__restrict__ gp, unsigned *__restrict__ cnt,
+                                                         unsigned *__restrict__ rank)
+{
+    const GridParams g = *gp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int64_t s = (int64_t)(first + i) * stride;
+        int c = cell_of(g, x[s], y[s], z[s]);
+        rank[i] = atomicAdd(&cnt[c], 1u);
+    }
+}
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned *total, unsigned *wsum /*[4]*/)
+{
+    // inclusive scan inside the wave
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned o = __shfl_up(inc, off);
+        if ((int)(threadIdx.x & 63) >= off) inc += o;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned s = wsum[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_partials_kernel(const unsigned *__restrict__ cnt,
+                                                            const GridParams *__restrict__ gp,
+                                                            unsigned *__restrict__ part)
+{
+    __shared__ unsigned wsum[4];
+    const int n = gp->ncells;
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 8;
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (base + j < n) ? cnt[base + j] : 0u;
+    unsigned tot;
+    (void)block_exclusive_scan_256(s, &tot, wsum);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void scan_top_kernel(unsigned *__restrict__ part, int nparts)
+{
+    __shared__ unsigned wsum[4];
+    unsigned carry = 0;
+    for (int b = 0; b < nparts; b += 256) {
+        int i = b + threadIdx.x;
+        unsigned v = i < nparts ? part[i] : 0u;
+        unsigned tot;
+        unsigned ex = block_exclusive_scan_256(v, &tot, wsum);
+        if (i < nparts) part[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned *__restrict__ cnt,
+                                                         const GridParams *__restrict__ gp,
+                                                         const unsigned *__restrict__ part,
+                                                         unsigned *__restrict__ start)
+{
+    __shared__ unsigned wsum[4];
+    const int n = gp->ncells;
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 8;
+    if (blockIdx.x * SCAN_BLOCK > n) return;  // uniform per block
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = (base + j < n) ? cnt[base + j] : 0u;
+        s += v[j];
+    }
+    unsigned tot;
+    unsigned ex = block_exclusive_scan_256(s, &tot, wsum) + part[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (base + j <= n) start[base + j] = ex;  // start[n] = total
+        ex += v[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ z, int64_t stride, int first, int n,
+                                                           const GridParams *__restrict__ gp,
+                                                           const unsigned *__restrict__ start,
+                                                           const unsigned *__restrict__ rank, float4 *__restrict__ out)
+{
+    const GridParams g = *gp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int64_t s = (int64_t)(first + i) * stride;
+        float px = x[s], py = y[s], pz = z[s];
+        int c = cell_of(g, px, py, pz);
+        unsigned dst = start[c] + rank[i];
+        out[dst] = make_float4(px, py, pz, __uint_as_float((unsigned)(first + i)));
+    }
+}
+
+// ---------------------------------------------------------------- knn_brick
+// One wave per brick.  refs/rstart: cell-sorted reference points and cell starts;
+// qpts/qstart: cell-sorted QUERY points (same arrays when every reference is a query).
+template <int KCAP>
+__global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
+    GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
+    const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
+    float *__restrict__ mean_out, unsigned *__restrict__ faillist)
+{
+    __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
+    __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
+
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    unsigned(*mask)[64] = s_mask[wv];
+    unsigned *wbase = s_wbase[wv];
+
+    const int nx = gp->nx, ny = gp->ny, nz = gp->nz;
+    const int nbx = gp->nbx, nby = gp->nby;
+    const int nbricks = gp->nbricks;
+    const double r1sq = gp->r1sq;
+    const float tau1 = gp->tau1;
+    const int kk = k + 1;
+
+    for (;;) {
+        int b = 0;
+        if (lane == 0) b = (int)atomicAdd(&gp->brick_next, 1u);
+        b = uniform(b);
+        if (b >= nbricks) break;
+        const int bz = b / (nbx * nby);
+        const int brem = b - bz * nbx * nby;
+        const int by = brem / nbx;
+        const int bx = brem - by * nbx;
+
+        // lane r < 16: candidate row r (4 cells along x); lanes 16..19: query rows (2 cells)
+        int v_start = 0, v_len = 0;
+        {
+            const bool isq = lane >= 16;
+            const int r = isq ? lane - 16 : lane;
+            const int yy = isq ? 2 * by + (r & 1) : 2 * by - 1 + (r & 3);
+            const int zz = isq ? 2 * bz + (r >> 1) : 2 * bz - 1 + (r >> 2);
+            const int xa = isq ? 2 * bx : max(2 * bx - 1, 0);
+            const int xb = isq ? min(2 * bx + 1, nx - 1) : min(2 * bx + 2, nx - 1);
+            const bool valid = lane < 20 && yy >= 0 && yy < ny && zz >= 0 && zz < nz;
+            if (valid) {
+                const unsigned *st = isq ? qstart : rstart;
+                const int row = (zz * ny + yy) * nx;
+                unsigned s = st[row + xa], e = st[row + xb + 1];
+                v_start = (int)s;
+                v_len = (int)(e - s);
+            }
+        }
+        int qoff[5];
+        qoff[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qoff[r + 1] = qoff[r] + __builtin_amdgcn_readlane(v_len, 16 + r);
+        const int nq = qoff[4];
+
+        for (int qb = 0; qb < nq; qb += 64) {
+            // ---- this lane's query
+            const int f = qb + lane;
+            const bool live = f < nq;
+            int qidx = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int s = __builtin_amdgcn_readlane(v_start, 16 + r);
+                if (f >= qoff[r] && f < qoff[r + 1]) qidx = s + (f - qoff[r]);
+            }
+            const float4 qp = qpts[live ? qidx : 0];
+            const float qx = qp.x, qy = qp.y, qz = qp.z;
+            const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
+            float tau = live ? tau1 : -1.0f;
+            TopList<KCAP> lst;
+            lst.init(kk);
+
+            int widx = 0;
+            unsigned nzw = 0;
+
+            // ---- phase 2: walk this lane's set bits, exact f64 distance, sorted insert
+            auto drain = [&]() {
+                wave_sync();  // wbase[] written by lane 0 is visible to every lane
+                unsigned m = 0;
+                int base = 0;
+                for (;;) {
+                    if (m == 0 && nzw != 0) {
+                        const int w = __builtin_ctz(nzw);
+                        nzw &= nzw - 1;
+                        m = mask[w][lane];
+                        base = (int)wbase[w];
+                    }
+                    const bool act = m != 0;
+                    if (!__any(act)) break;
+                    if (act) {
+                        const int i = __builtin_clz(m);
+                        m &= ~(0x80000000u >> i);
+                        const float4 p = refs[base + i];
+                        lst.insert(dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z));
+                    }
+                }
+                tau = fminf(tau, bound_from(lst.kth()));
+                widx = 0;
+                nzw = 0;
+                wave_sync();  // all reads of mask/wbase done before they are overwritten
+            };
+
+            // ---- phase 1: lock-step filter over the 16 candidate rows
+            for (int r = 0; r < 16; ++r) {
+                const int gs = __builtin_amdgcn_readlane(v_start, r);
+                const int len = __builtin_amdgcn_readlane(v_len, r);
+                for (int w0 = 0; w0 < len; w0 += 32) {
+                    if (widx == WCAP) drain();
+                    const int c = min(32, len - w0);
+                    const float4 *__restrict__ p = refs + gs + w0;
+                    unsigned m = 0;
+                    int i = 0;
+                    for (; i + 8 <= c; i += 8) {
+                        float4 P[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) P[u] = p[i + u];  // wave-uniform address: scalar loads
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            float d2 = dist2_f32(qx, qy, qz, P[u].x, P[u].y, P[u].z);
+                            m = (m << 1) | (d2 <= tau ? 1u : 0u);
+                        }
+                    }
+                    for (; i < c; ++i) {
+                        float4 P = p[i];
+                        float d2 = dist2_f32(qx, qy, qz, P.x, P.y, P.z);
+                        m = (m << 1) | (d2 <= tau ? 1u : 0u);
+                    }
+                    m <<= (32 - c);  // candidate i of this word <-> bit 31-i
+                    mask[widx][lane] = m;
+                    if (lane == 0) wbase[widx] = (unsigned)(gs + w0);
+                    nzw |= (m != 0 ? 1u : 0u) << widx;
+                    ++widx;
+                }
+            }
+            drain();
+
+            // ---- exact iff the (k+1)-th distance lies inside the searched cells
+            if (live) {
+                if (lst.kth() <= r1sq) {
+                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
+                } else {
+                    unsigned slot = atomicAdd(&gp->fail_count, 1u);
+                    faillist[slot] = (unsigned)qidx;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- knn_ring (fallback)
+// One wave per failed query: search the (2H+1)^3 cells around the query's cell, H = 2,4,8..;
+// lanes split every row, keep private sorted lists, then the wave merges the 64 lists by
+// repeated min-extraction.  Exact once the (k+1)-th distance <= H*r_safe or the ring covers
+// the whole grid.
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int KCAP>
+__global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
+    GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
+    const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, int k, int q_begin,
+    float *__restrict__ mean_out)
+{
+    __shared__ double s_out[BRICK_THREADS / 64][KCAP];
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    double *out = s_out[wv];
+    const GridParams g = *gp;
+    const int nfail = (int)g.fail_count;
+    const int kk = k + 1;
+
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(&gp->ring_next, 1u);
+        t = uniform(t);
+        if (t >= nfail) break;
+        const float4 qp = qpts[faillist[t]];
+        const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
+        const int cx = cell_coord(qp.x, g.ox, g.inv_h, g.nx);
+        const int cy = cell_coord(qp.y, g.oy, g.inv_h, g.ny);
+        const int cz = cell_coord(qp.z, g.oz, g.inv_h, g.nz);
+
+        for (int H = 2;; H *= 2) {
+            double a[KCAP];  // ascending, +inf padded: a[0] is this lane's smallest
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i) a[i] = __builtin_inf();
+            const int x0 = max(cx - H, 0), x1 = min(cx + H, g.nx - 1);
+            const int y0 = max(cy - H, 0), y1 = min(cy + H, g.ny - 1);
+            const int z0 = max(cz - H, 0), z1 = min(cz + H, g.nz - 1);
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const int row = (zz * g.ny + yy) * g.nx;
+                    const int s = (int)rstart[row + x0], e = (int)rstart[row + x1 + 1];
+                    for (int j = s + lane; j < e; j += 64) {
+                        const float4 p = refs[j];
+                        double d = dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z);
+                        if (d < a[KCAP - 1]) {
+#pragma unroll
+                            for (int i = 0; i < KCAP; ++i) {
+                                double lo, hi;
+                                asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a[i]), "v"(d));
+                                asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a[i]), "v"(d));
+                                a[i] = lo;
+                                d = hi;
+                            }
+                        }
+                    }
+                }
+            // merge: kk rounds of wave-min over the list heads
+            for (int r = 0; r < kk; ++r) {
+                const double mn = wave_min_f64(a[0]);
+                const unsigned long long eq = __ballot(a[0] == mn);
+                const int win = (int)__builtin_ctzll(eq);
+                if (lane == 0) out[r] = mn;
+                if (lane == win) {
+#pragma unroll
+                    for (int i = 0; i + 1 < KCAP; ++i) a[i] = a[i + 1];
+                    a[KCAP - 1] = __builtin_inf();
+                }
+            }
+            wave_sync();
+            const bool covers = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
+            const double rH = (double)H * g.hprime * (1.0 - 1e-3);
+            const double kth = out[kk - 1];
+            if (covers || kth <= rH * rH) {
+                if (lane == 0) {
+                    if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
+                    double sum = pairwise_sum_le128([&](int i) { return __dsqrt_rn(out[1 + i]); }, k);
+                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                }
+                wave_sync();
+                break;
+            }
+            wave_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static int grid_blocks(const gsx_ctx *ctx, int64_t n, int per_thread = 1)
+{
+    int64_t want = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    int64_t cap = (int64_t)ctx->num_cu * 16;
+    return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+template <int KCAP>
+static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, const unsigned *rstart,
+                             const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
+                             float *mean_out, unsigned *faillist)
+{
+    const int wgs = ctx->num_cu * 4;  // persistent: 16 waves per CU pull bricks from a counter
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+                       qpts, qstart, k, (int)q_begin, mean_out, faillist);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
+    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+                       qpts, faillist, k, (int)q_begin, mean_out);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
+    return 0;
+}
+
+int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
+
+// Bin (x,y,z)[first, first+n) with the grid in gp: cnt/start/rank/sorted are outputs.
+static int bin_points(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
+                      int64_t n, GridParams *gp, int64_t cell_cap, unsigned *cnt, unsigned *start, unsigned *rank,
+                      unsigned *part, float4 *sorted)
+{
+    const int nparts = div_up(cell_cap + 1, SCAN_BLOCK);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(grid_blocks(ctx, cell_cap)), dim3(256), 0, ctx->stream, cnt, gp);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(grid_blocks(ctx, n)), dim3(256), 0, ctx->stream, x, y, z, stride,
+                       (int)first, (int)n, gp, cnt, rank);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(nparts), dim3(256), 0, ctx->stream, cnt, gp, part);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, ctx->stream, part, nparts);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nparts), dim3(256), 0, ctx->stream, cnt, gp, part, start);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid_blocks(ctx, n)), dim3(256), 0, ctx->stream, x, y, z, stride,
+                       (int)first, (int)n, gp, start, rank, sorted);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
+                    int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info)
+{
+    const int kk = k + 1;
+    if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
+    const int64_t cap = grid_cell_cap(n_ref);
+    const int nparts = div_up(cap + 1, SCAN_BLOCK);
+    const bool all = (q_begin == 0 && q_count == n_ref);
+    const int bbox_blocks = grid_blocks(ctx, n_ref, 4);
+
+    GSX_CHECK(ctx->packed.reserve(sizeof(float4) * (size_t)n_ref));
+    GSX_CHECK(ctx->rank.reserve(sizeof(unsigned) * (size_t)n_ref));
+    GSX_CHECK(ctx->cellcnt.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+    GSX_CHECK(ctx->cellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+    GSX_CHECK(ctx->scanpart.reserve(sizeof(unsigned) * (size_t)nparts));
+    GSX_CHECK(ctx->gridparams.reserve(sizeof(GridParams)));
+    GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 6 * (size_t)bbox_blocks));
+    GSX_CHECK(ctx->faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
+    if (!all) {
+        GSX_CHECK(ctx->qsorted.reserve(sizeof(float4) * (size_t)q_count));
+        GSX_CHECK(ctx->qrank.reserve(sizeof(unsigned) * (size_t)q_count));
+        GSX_CHECK(ctx->qcellcnt.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+        GSX_CHECK(ctx->qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+    }
+    GridParams *gp = ctx->gridparams.as<GridParams>();
+    float4 *refs = ctx->packed.as<float4>();
+    unsigned *rstart = ctx->cellstart.as<unsigned>();
+
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
+                       ctx->bboxpart.as<float>());
+    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
+                       (int)n_ref, ctx->grid_points_per_cell, (int)cap, gp);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, cap, ctx->cellcnt.as<unsigned>(), rstart,
+                         ctx->rank.as<unsigned>(), ctx->scanpart.as<unsigned>(), refs));
+    const float4 *qpts = refs;
+    const unsigned *qstart = rstart;
+    if (!all) {
+        GSX_CHECK(bin_points(ctx, x, y, z, stride, q_begin, q_count, gp, cap, ctx->qcellcnt.as<unsigned>(),
+                             ctx->qcellstart.as<unsigned>(), ctx->qrank.as<unsigned>(),
+                             ctx->scanpart.as<unsigned>(), ctx->qsorted.as<float4>()));
+        qpts = ctx->qsorted.as<float4>();
+        qstart = ctx->qcellstart.as<unsigned>();
+    }
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
+
+    unsigned *fl = ctx->faillist.as<unsigned>();
+    int rc;
+    if (kk <= 9) rc = launch_brick_ring<9>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
+    else if (kk <= 17) rc = launch_brick_ring<17>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
+    else if (kk <= 33) rc = launch_brick_ring<33>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
+    else rc = launch_brick_ring<65>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
+    GSX_CHECK(rc);
+
+    if (info) {
+        GridParams hgp;
+        GSX_HIP(hipMemcpyAsync(&hgp, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        info->algo = GSX_KNN_GRID;
+        info->grid_dim[0] = hgp.nx; info->grid_dim[1] = hgp.ny; info->grid_dim[2] = hgp.nz;
+        info->cell_size = hgp.h;
+        info->n_cells = hgp.ncells;
+        info->n_bricks = hgp.nbricks;
+        info->n_fallback = hgp.fail_count;
+        info->n_exhaustive = hgp.exhaustive_count;
+    }
+    return 0;
+}
+
+}  // namespace gsx

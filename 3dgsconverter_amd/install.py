@@ -1,0 +1,50 @@
+"""Make the reference package use this implementation without editing it.
+
+``install()`` rebinds the three names the reference's orchestrator and SOG writer resolve
+at call time:
+    gsconverter.converter.DataProcessor            (converter.py:10 -> used at :150)
+    gsconverter.processing.DataProcessor / gsconverter.processing.data_processor.DataProcessor
+    gsconverter.formats.sog.gpu_ops                (sog.py:11 -> used at :402,443,524,544)
+    gsconverter.processing.gpu_ops                 (data_processor.py:142 imports it lazily)
+so ``gsconverter``'s CLI (main.py) and every flag in SURVEY.md 8(b) keep working.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+
+_saved = {}
+
+
+def install():
+    from . import processing
+    from .processing import gpu_ops, DataProcessor
+    import gsconverter.processing as rp  # type: ignore  (raises ImportError if the reference is absent)
+    import gsconverter.processing.data_processor as rdp  # type: ignore
+    targets = [(rp, "DataProcessor", DataProcessor), (rdp, "DataProcessor", DataProcessor),
+               (rp, "gpu_ops", gpu_ops)]
+    for modname, attr, val in (("gsconverter.converter", "DataProcessor", DataProcessor),
+                               ("gsconverter.formats.sog", "gpu_ops", gpu_ops)):
+        try:
+            targets.append((importlib.import_module(modname), attr, val))
+        except Exception:
+            pass  # e.g. plyfile / pillow missing: that codec is not importable anyway
+    for mod, attr, val in targets:
+        _saved.setdefault((mod.__name__, attr), getattr(mod, attr, None))
+        setattr(mod, attr, val)
+    _saved.setdefault(("sys.modules", "gsconverter.processing.gpu_ops"),
+                      sys.modules.get("gsconverter.processing.gpu_ops"))
+    sys.modules["gsconverter.processing.gpu_ops"] = gpu_ops
+    return processing
+
+
+def uninstall():
+    for (modname, attr), val in list(_saved.items()):
+        if modname == "sys.modules":
+            if val is None:
+                sys.modules.pop(attr, None)
+            else:
+                sys.modules[attr] = val
+        elif val is not None:
+            setattr(importlib.import_module(modname), attr, val)
+    _saved.clear()

@@ -1,0 +1,153 @@
+/*
+ * gsx_hip.h -- C ABI of libgsx_hip.so, the MI355X (gfx950) implementation of the
+ * 3dgsconverter point-cloud filtering hot path.
+ *
+ * The reference (francescofugazzi/3dgsconverter v0.8) is pure Python and has no
+ * FFI; its "operator API" for this path is a handful of Python callables.  Each
+ * entry point below names the reference interface it replaces (file:line into
+ * the reference tree) -- the ctypes stub a maintainer would add is shown in
+ * INTEGRATION.md and implemented in 3dgsconverter_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types;
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from gsx_last_error() (thread-local);
+ *   - "host" entry points borrow caller-owned HOST buffers for one call and keep
+ *     nothing; "_dev" entry points take DEVICE pointers that are already resident
+ *     in HBM and enqueue work on the context's stream (asynchronous unless noted);
+ *   - xyz is described by three base pointers and an element stride, so both the
+ *     SoA columns and the reference's (N,3) row-major coords
+ *     (data_processor.py:139, column_stack) can be passed without a copy
+ *     (SoA: stride 1; (N,3): y = x + 1, z = x + 2, stride 3).
+ */
+#ifndef GSX_HIP_H
+#define GSX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsx_ctx gsx_ctx;
+
+/* KNN algorithm selector for the SOR entry points */
+enum {
+    GSX_KNN_AUTO = 0,  /* grid-binned exact KNN, brute force for tiny inputs   */
+    GSX_KNN_BRUTE = 1, /* LDS-tiled brute force (BASELINE.json configs[1])     */
+    GSX_KNN_GRID = 2   /* grid-binned exact KNN + exact fallback ring/brute    */
+};
+
+/* timing slots (HIP-event pairs recorded on the context stream when enabled) */
+enum {
+    GSX_T_SOR_KNN = 0,    /* dominant kernel: knn_brick / knn_brute             */
+    GSX_T_SOR_BIN = 1,    /* bbox + cell histogram + scan + scatter             */
+    GSX_T_SOR_FALLBACK = 2,
+    GSX_T_SOR_STATS = 3,  /* numpy-exact mean/std/threshold + mask              */
+    GSX_T_DENSITY = 4,
+    GSX_T_KMEANS_ASSIGN = 5,
+    GSX_T_KMEANS_UPDATE = 6,
+    GSX_T_QUANTIZE = 7,
+    GSX_T_SLOTS = 8
+};
+
+/* diagnostics of one SOR KNN call (all counts are exact) */
+typedef struct gsx_sor_info {
+    int32_t algo;            /* algorithm actually used                          */
+    int32_t grid_dim[3];     /* cells per axis (0 for brute force)               */
+    float   cell_size;       /* cell edge h                                      */
+    int64_t n_cells;
+    int64_t n_bricks;
+    int64_t n_fallback;      /* queries re-done by the expanding-ring kernel     */
+    int64_t n_exhaustive;    /* of those, queries that needed the whole cloud    */
+} gsx_sor_info;
+
+/* ---- library / device -------------------------------------------------- */
+const char *gsx_version(void);
+const char *gsx_last_error(void);
+/* replaces the capability probe gpu_ops.py:8-23 (HAS_TAICHI) */
+int gsx_device_count(void);
+
+/* ---- context ------------------------------------------------------------ */
+int  gsx_ctx_create(int device, gsx_ctx **out);
+void gsx_ctx_destroy(gsx_ctx *ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = legacy default stream */
+int  gsx_ctx_set_stream(gsx_ctx *ctx, void *hip_stream);
+int  gsx_ctx_synchronize(gsx_ctx *ctx);
+int  gsx_ctx_set_timing(gsx_ctx *ctx, int enable);
+int  gsx_ctx_reset_timing(gsx_ctx *ctx);
+/* synchronises, then returns the number of recorded launches and their summed duration */
+int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *total_ms);
+/* tuning knobs (0 keeps the default): target points per cell of the KNN grid */
+int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
+
+/* raw device memory for hosts that have no other allocator (bench without torch) */
+int gsx_dev_malloc(gsx_ctx *ctx, size_t bytes, void **dptr);
+int gsx_dev_free(gsx_ctx *ctx, void *dptr);
+int gsx_dev_upload(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- Statistical Outlier Removal --------------------------------------- */
+/*
+ * KNN mean distance -- replaces data_processor.py:156-173 (cKDTree build + chunked
+ * query(k+1) + row mean) and the Taichi kernel gpu_ops.py:98-176 / its host prep
+ * :193-256.  For the queries [q_begin, q_begin+q_count) of the n_ref reference
+ * points writes mean_out[i - q_begin] = (float) mean of the k nearest neighbour
+ * distances (self excluded), bit-identical to the reference's cKDTree path.
+ */
+int gsx_sor_knn_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
+                    int64_t n_ref, int64_t q_begin, int64_t q_count, int k, int algo,
+                    float *mean_out_dev, gsx_sor_info *info /* nullable; forces a sync if given */);
+/*
+ * np.mean / np.std / threshold -- replaces data_processor.py:176-178 and
+ * gpu_ops.py:259-261 with numpy's exact float32 arithmetic (8192-element buffered
+ * pairwise sums, float64 division).  stats_dev[0..2] = mean, std, threshold.
+ */
+int gsx_sor_stats_dev(gsx_ctx *ctx, const float *mean_dists_dev, int64_t n, double threshold_factor,
+                      float *stats_dev);
+/* mask = mean_dists < threshold (strict) -- data_processor.py:180, gpu_ops.py:263 */
+int gsx_sor_mask_dev(gsx_ctx *ctx, const float *mean_dists_dev, int64_t n, const float *threshold_dev,
+                     uint8_t *mask_out_dev);
+
+/* host buffers, one GPU: the whole of filter_sor_gpu (gpu_ops.py:193-263).
+ * mean_out (n floats) and stats_out (3 floats) may be NULL. */
+int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                   int k, double threshold_factor, int algo, uint8_t *mask_out, float *mean_out,
+                   float *stats_out, gsx_sor_info *info);
+
+/* ---- voxel-density filter ---------------------------------------------- */
+/*
+ * Voxel occupancy -- replaces data_processor.py:38-52 (floor(xyz / voxel) keys,
+ * np.unique(axis=0) counts, dense = count >= min_points).  Returns the number of
+ * occupied voxels and the dense voxels (lexicographically sorted like np.unique)
+ * in dense_keys_out (3 x int64 each) / dense_counts_out, at most dense_cap.
+ */
+int gsx_density_voxels(const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                       double voxel_size, int64_t min_points, int64_t dense_cap,
+                       int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
+                       int64_t *dense_counts_out);
+/*
+ * Per-point membership -- replaces data_processor.py:111-114: mask[i] = voxel(i) in kept set.
+ * kept_keys: n_kept x 3 int64.
+ */
+int gsx_density_mask(const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                     double voxel_size, const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_out);
+
+/* ---- K-Means codebook (SOG writer) ------------------------------------- */
+/*
+ * Lloyd iterations with an injected initialisation -- replaces _kmeans_taichi
+ * (gpu_ops.py:178-191) and its kernels k_means_assign (:57-73) / k_means_update
+ * (:75-96): exactly max_iter x (assign, update), empty cluster -> 0, returned
+ * labels are one step older than the returned centroids.  data: n x d row-major.
+ */
+int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter,
+                     const float *init_centroids, float *centroids_out, int32_t *labels_out);
+/* nearest entry of a sorted codebook -- replaces quantize_to_codebook, formats/sog.py:408-419 */
+int gsx_quantize_sorted_codebook(const float *vals, int64_t n, const float *codebook, int kcb,
+                                 uint8_t *idx_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_HIP_H */

@@ -1,0 +1,168 @@
+"""-m gpu: the HIP SOR path (through the C ABI) against the oracle / golden vectors.
+Bar: mean_dists bit-identical (f32), statistics bit-identical, survivor mask bit-identical."""
+import numpy as np
+import pytest
+
+from conftest import f32_from_hex, sha16
+from oracle import datasets, sor as osor
+
+pytestmark = pytest.mark.gpu
+
+BRUTE, GRID = 1, 2
+
+SMALL = ["sor_u100k_k8_s1", "sor_u100k_k8_s10p5", "sor_u20k_k16_s1", "sor_u50k_k32_s1",
+         "sor_clustered30k_k16_s2", "sor_dups8k_k8_s1", "sor_lattice17_k6_s1", "sor_lattice17_k26_s0p5",
+         "sor_tiny10_k16", "sor_tiny17_k16", "sor_u20k_int1", "sor_u20k_int5", "sor_u20k_int10",
+         "sor_centered40k_k16_s1"]
+
+
+@pytest.fixture(scope="module")
+def lib(gsx):
+    gsx._lib.require_hip()
+    return gsx._lib
+
+
+def _explain(md_gpu, md_ref):
+    bad = np.nonzero(md_gpu.view(np.uint32) != md_ref.view(np.uint32))[0]
+    if len(bad) == 0:
+        return "ok"
+    with np.errstate(all="ignore"):
+        rel = np.abs(md_gpu[bad].astype(np.float64) - md_ref[bad]) / np.abs(md_ref[bad])
+    return "%d / %d mean_dists differ; first %s gpu=%s ref=%s max rel %.3g" % (
+        len(bad), len(md_ref), bad[:8], md_gpu[bad[:8]], md_ref[bad[:8]], np.nanmax(rel))
+
+
+def _check_against_case(lib, name, case, arrays, algo):
+    xyz = datasets.make(case["dataset"])
+    assert sha16(xyz.tobytes()) == case["xyz_sha"]
+    res = lib.sor_filter(xyz, case["k_used"], case["sigma_used"], algo=algo, want_info=True)
+    md = res["mean_dists"]
+    if sha16(md.tobytes()) != case["mean_dists_sha"]:
+        ref = osor.mean_dists_ckdtree(xyz, case["k_used"])
+        pytest.fail("%s algo=%d: %s (info %s)" % (name, algo, _explain(md, ref), res["info"]))
+    for got, key in ((res["mean"], "mean_hex"), (res["std"], "std_hex"), (res["threshold"], "threshold_hex")):
+        want = f32_from_hex(case[key])
+        assert np.float32(got).tobytes() == want.tobytes() or (np.isnan(got) and np.isnan(want)), (name, key, got, want)
+    np.testing.assert_array_equal(np.packbits(res["mask"]), arrays[name + "__mask"])
+    assert int(res["mask"].sum()) == case["survivors"]
+    return res
+
+
+@pytest.mark.parametrize("algo", [BRUTE, GRID])
+@pytest.mark.parametrize("name", SMALL)
+def test_sor_golden_small(lib, golden_cases, golden_arrays, name, algo):
+    _check_against_case(lib, name, golden_cases["sor"][name], golden_arrays, algo)
+
+
+@pytest.mark.parametrize("name", ["sor_u1m_k16_s1", "sor_u1m_k16_s2"])
+def test_sor_1m_kat_grid(lib, golden_cases, golden_arrays, name):
+    """BASELINE.json configs[1]: 1M splats, k=16 -- 848 169 survivors at sigma 1."""
+    res = _check_against_case(lib, name, golden_cases["sor"][name], golden_arrays, GRID)
+    assert res["info"]["n_fallback"] < 0.1 * 1_000_000
+
+
+def test_sor_1m_kat_brute(lib, golden_cases, golden_arrays):
+    _check_against_case(lib, "sor_u1m_k16_s1", golden_cases["sor"]["sor_u1m_k16_s1"], golden_arrays, BRUTE)
+
+
+def test_soa_and_rows_agree(lib):
+    xyz = datasets.uniform(30000, 10.0, 21)
+    a = lib.sor_filter(xyz, 16, 1.0, algo=GRID)
+    b = lib.sor_filter((xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy()), 16, 1.0, algo=GRID)
+    np.testing.assert_array_equal(a["mean_dists"].view(np.uint32), b["mean_dists"].view(np.uint32))
+    np.testing.assert_array_equal(a["mask"], b["mask"])
+
+
+@pytest.mark.parametrize("algo", [BRUTE, GRID])
+@pytest.mark.parametrize("k", [1, 3, 8, 9, 17, 25, 33, 50, 64])
+def test_k_buckets(lib, algo, k):
+    """every list-capacity bucket (9/17/33/65) and the k<8 sequential mean"""
+    xyz = datasets.clustered(6000, seed=k)
+    ref = osor.mean_dists_ckdtree(xyz, k)
+    res = lib.sor_filter(xyz, k, 1.5, algo=algo)
+    assert _explain(res["mean_dists"], ref) == "ok"
+    m, s, t = osor.threshold_numpy(ref, 1.5)
+    assert np.float32(t).tobytes() == np.float32(res["threshold"]).tobytes()
+    np.testing.assert_array_equal(res["mask"], ref < t)
+
+
+@pytest.mark.parametrize("algo", [BRUTE, GRID])
+def test_query_subrange_device_api(gsx, lib, algo):
+    """sharded queries (what each rank of a multi-GPU run does): any index range of the cloud"""
+    xyz = datasets.uniform(50000, 10.0, 33)
+    ref = osor.mean_dists_ckdtree(xyz, 16)
+    ctx = lib.Context(0)
+    n = len(xyz)
+    cols = [np.ascontiguousarray(xyz[:, a]) for a in range(3)]
+    d = [ctx.alloc(4 * n).upload(c) for c in cols]
+    for q0, qc in ((0, n), (12345, 20000), (n - 777, 777), (5, 1)):
+        out = ctx.alloc(4 * qc)
+        info = ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, q0, qc, 16, out.ptr, algo=algo, want_info=True)
+        got = out.download(np.float32, qc)
+        assert _explain(got, ref[q0:q0 + qc]) == "ok", (q0, qc, info)
+        out.free()
+    for a in d:
+        a.free()
+    ctx.close()
+
+
+def test_stats_kernel_matches_numpy(lib):
+    """gsx_sor_stats_dev == np.mean / np.std / threshold, bit for bit, at ragged sizes"""
+    rng = np.random.default_rng(9)
+    ctx = lib.Context(0)
+    for n in (1, 5, 8, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 70001, 1000003):
+        a = (rng.random(n, dtype=np.float32) * 0.3 + 0.01).astype(np.float32)
+        if n > 100:
+            a[rng.integers(0, n, 5)] *= 40
+        d = ctx.alloc(4 * n).upload(a)
+        st = ctx.alloc(16)
+        mk = ctx.alloc(n + 4)
+        for tf in (1.0, 10.5, 12.444444444444445):
+            ctx.sor_stats(d.ptr, n, tf, st.ptr)
+            ctx.sor_mask(d.ptr, n, st.ptr + 8, mk.ptr)
+            got = st.download(np.float32, 3)
+            want = osor.threshold_numpy(a, tf)
+            assert all(np.float32(g).tobytes() == np.float32(w).tobytes() for g, w in zip(got, want)), (n, tf, got, want)
+            mask = mk.download(np.uint8, n).view(np.bool_)
+            np.testing.assert_array_equal(mask, a < want[2])
+        for x in (d, st, mk):
+            x.free()
+    ctx.close()
+
+
+def test_sor_10m_subset_and_properties(lib):
+    """BASELINE.json configs[2] size: 10M splats k=16.  Full-size checks that do not need a full CPU run:
+    a random 4000-query subset against the scalar C restatement, plus sanity properties."""
+    n = 10_000_000
+    xyz = datasets.uniform(n, 5.0, 0)
+    res = lib.sor_filter(xyz, 16, 1.0, algo=GRID, want_info=True)
+    md = res["mean_dists"]
+    assert np.isfinite(md).all() and (md > 0).all()
+    rng = np.random.default_rng(1)
+    q = np.sort(rng.choice(n, 600, replace=False))
+    ref = osor.mean_dists_brute_subset_c(xyz, 16, q)
+    assert _explain(md[q], ref) == "ok", res["info"]
+    m, s, t = osor.threshold_numpy(md, 1.0)
+    assert np.float32(t).tobytes() == np.float32(res["threshold"]).tobytes()
+    np.testing.assert_array_equal(res["mask"], md < t)
+    assert res["info"]["n_fallback"] < 0.05 * n
+
+
+def test_drop_in_dataprocessor(gsx, golden_cases, golden_arrays):
+    """the reference-shaped API: DataProcessor(data).remove_flyers(k, sigma) returns the filtered array"""
+    case = golden_cases["sor"]["sor_u100k_k8_s1"]
+    xyz = datasets.make(case["dataset"])
+    arr = np.zeros(len(xyz), dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("opacity", "f4")])
+    arr["x"], arr["y"], arr["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    arr["opacity"] = np.arange(len(xyz))
+    proc = gsx.DataProcessor(arr)
+    out = proc.remove_flyers(8, 1.0)
+    assert out is proc.data and len(out) == case["survivors"] == 84668
+    mask = np.unpackbits(golden_arrays["sor_u100k_k8_s1__mask"])[:len(xyz)].astype(bool)
+    np.testing.assert_array_equal(out["opacity"], arr["opacity"][mask])
+    with pytest.raises(TypeError):
+        gsx.DataProcessor([1, 2, 3]).remove_flyers()
+    mask2 = gsx.gpu_ops.filter_sor_gpu(xyz, 8, 1.0)
+    np.testing.assert_array_equal(mask2, mask)
+    with pytest.raises(ValueError):
+        gsx.gpu_ops.filter_sor_gpu(np.zeros((10, 2), np.float32))

@@ -1,0 +1,68 @@
+"""Exploratory timing on the GPU box (not a test, not the bench): per-slot kernel times of the
+SOR pipeline for a sweep of cloud sizes / k / grid density.  Usage: python tools/gpu_probe.py [quick]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gsx = importlib.import_module("3dgsconverter_amd")
+L = gsx._lib
+
+
+def uniform(n, extent, seed=0):
+    return np.random.default_rng(seed).random((n, 3), dtype=np.float32) * np.float32(extent)
+
+
+def run(ctx, xyz, k, algo, m=None, reps=3, label=""):
+    n = len(xyz)
+    if m is not None:
+        ctx.set_param("grid_points_per_cell", m)
+    cols = [np.ascontiguousarray(xyz[:, a]) for a in range(3)]
+    d = [ctx.alloc(4 * n).upload(c) for c in cols]
+    out = ctx.alloc(4 * n)
+    st = ctx.alloc(16)
+    mk = ctx.alloc(n + 4)
+    info = ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, 0, n, k, out.ptr, algo=algo, want_info=True)  # warm
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, 0, n, k, out.ptr, algo=algo)
+        ctx.sor_stats(out.ptr, n, 1.0, st.ptr)
+        ctx.sor_mask(out.ptr, n, st.ptr + 8, mk.ptr)
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    slots = {name: ctx.timing(i) for i, name in enumerate(["knn", "bin", "fallback", "stats"])}
+    ctx.set_timing(False)
+    msg = " ".join("%s=%.3fms" % (k_, v[1] / max(v[0], 1) * (v[0] / reps)) for k_, v in slots.items())
+    print("%-28s n=%9d k=%2d algo=%d m=%s wall=%.3f ms  %.1f Msplat/s | %s | dims=%s cells=%d bricks=%d fallback=%d exh=%d"
+          % (label, n, k, algo, m, wall, n / wall / 1e3, msg, info["grid_dim"], info["n_cells"], info["n_bricks"],
+             info["n_fallback"], info["n_exhaustive"]), flush=True)
+    for a in d + [out, st, mk]:
+        a.free()
+
+
+def main():
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    ctx = L.Context(0)
+    x1 = uniform(1_000_000, 10.0)
+    for m in (5.0, 6.0, 7.0, 8.0, 10.0):
+        run(ctx, x1, 16, 2, m, label="grid 1M")
+    run(ctx, x1, 32, 2, 14.0, label="grid 1M k32")
+    run(ctx, x1, 32, 2, 10.0, label="grid 1M k32")
+    run(ctx, x1, 8, 2, 4.0, label="grid 1M k8")
+    run(ctx, uniform(100_000, 10.0), 16, 1, None, label="brute 100k")
+    if not quick:
+        run(ctx, x1, 16, 1, None, reps=1, label="brute 1M")
+        x10 = uniform(10_000_000, 5.0)
+        for m in (6.0, 7.0, 8.0):
+            run(ctx, x10, 16, 2, m, label="grid 10M")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
