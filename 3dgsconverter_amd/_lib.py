@@ -60,6 +60,10 @@ SIGNATURES = {
     "gsx_density_mask": (_I, [_P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_kmeans_lloyd": (_I, [_P, _I64, _I, _I, _I, _P, _P, _P]),
     "gsx_quantize_sorted_codebook": (_I, [_P, _I64, _P, _I, _P]),
+    "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
+    "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
+    "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
+    "gsx_quantize_sorted_codebook_dev": (_I, [_P, _P, _I64, _P, _I, _P]),
 }
 
 _lib = None

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgsx_hip.so")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc",
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -85,6 +85,12 @@ int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int6
                     float *, gsx_sor_info *);
 int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
 int launch_sor_mask(gsx_ctx *, const float *, int64_t, const float *, uint8_t *);
+int density_voxels_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int64_t,
+                       int64_t *, int64_t *, int64_t *, int64_t *);
+int density_mask_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, const int64_t *,
+                     int64_t, uint8_t *);
+int kmeans_lloyd_dev(gsx_ctx *, const float *, int64_t, int, int, int, float *, int32_t *);
+int quantize_dev(gsx_ctx *, const float *, int64_t, const float *, int, uint8_t *);
 
 }  // namespace gsx
 
@@ -357,6 +363,123 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
             info->n_exhaustive = hgp.exhaustive_count;
         }
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------ density
+int gsx_density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                           double voxel_size, int64_t min_points, int64_t dense_cap, int64_t *n_unique_out,
+                           int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    if (!c || !x || !y || !z || !n_unique_out || !n_dense_out || !dense_keys_out || !dense_counts_out)
+        GSX_FAIL("gsx_density_voxels_dev: null argument");
+    if (n <= 0) GSX_FAIL("gsx_density_voxels_dev: empty cloud");
+    GSX_HIP(hipSetDevice(c->device));
+    return density_voxels_dev(c, x, y, z, stride, n, voxel_size, min_points, dense_cap, n_unique_out, n_dense_out,
+                              dense_keys_out, dense_counts_out);
+}
+
+int gsx_density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                         double voxel_size, const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_out_dev)
+{
+    if (!c || !x || !y || !z || !mask_out_dev || (n_kept > 0 && !kept_keys)) GSX_FAIL("gsx_density_mask_dev: null argument");
+    if (n <= 0) return 0;
+    GSX_HIP(hipSetDevice(c->device));
+    return density_mask_dev(c, x, y, z, stride, n, voxel_size, kept_keys, n_kept, mask_out_dev);
+}
+
+int gsx_density_voxels(const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                       int64_t min_points, int64_t dense_cap, int64_t *n_unique_out, int64_t *n_dense_out,
+                       int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!x || !y || !z) GSX_FAIL("gsx_density_voxels: null argument");
+    if (n <= 0) GSX_FAIL("gsx_density_voxels: empty cloud");
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    float *dx, *dy, *dz;
+    int64_t ds;
+    GSX_CHECK(upload_xyz(c, x, y, z, stride, n, &dx, &dy, &dz, &ds));
+    return gsx_density_voxels_dev(c, dx, dy, dz, ds, n, voxel_size, min_points, dense_cap, n_unique_out, n_dense_out,
+                                  dense_keys_out, dense_counts_out);
+}
+
+int gsx_density_mask(const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                     const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!x || !y || !z || !mask_out) GSX_FAIL("gsx_density_mask: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    float *dx, *dy, *dz;
+    int64_t ds;
+    GSX_CHECK(upload_xyz(c, x, y, z, stride, n, &dx, &dy, &dz, &ds));
+    GSX_CHECK(c->scratch4.reserve((size_t)n + 4));
+    GSX_CHECK(gsx_density_mask_dev(c, dx, dy, dz, ds, n, voxel_size, kept_keys, n_kept, c->scratch4.as<uint8_t>()));
+    GSX_HIP(hipMemcpyAsync(mask_out, c->scratch4.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ K-Means
+int gsx_kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k, int max_iter,
+                         float *centroids_dev, int32_t *labels_dev)
+{
+    if (!c || !data_dev || !centroids_dev || !labels_dev) GSX_FAIL("gsx_kmeans_lloyd_dev: null argument");
+    if (max_iter < 0) GSX_FAIL("gsx_kmeans_lloyd_dev: negative max_iter");
+    GSX_HIP(hipSetDevice(c->device));
+    return kmeans_lloyd_dev(c, data_dev, n, d, k, max_iter, centroids_dev, labels_dev);
+}
+
+int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter, const float *init_centroids,
+                     float *centroids_out, int32_t *labels_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!data || !init_centroids || !centroids_out || !labels_out) GSX_FAIL("gsx_kmeans_lloyd: null argument");
+    if (n <= 0 || d <= 0 || k <= 0) GSX_FAIL("gsx_kmeans_lloyd: bad shape");
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    const size_t nd = (size_t)n * d, kd = (size_t)k * d;
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * nd));
+    GSX_CHECK(c->scratch2.reserve(sizeof(float) * kd));
+    GSX_CHECK(c->scratch4.reserve(sizeof(int32_t) * (size_t)n));
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, data, sizeof(float) * nd, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(hipMemcpyAsync(c->scratch2.p, init_centroids, sizeof(float) * kd, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(hipMemsetAsync(c->scratch4.p, 0, sizeof(int32_t) * (size_t)n, c->stream));  // max_iter == 0: labels stay 0 (gpu_ops.py:183)
+    GSX_CHECK(gsx_kmeans_lloyd_dev(c, c->scratch.as<float>(), n, d, k, max_iter, c->scratch2.as<float>(),
+                                   c->scratch4.as<int32_t>()));
+    GSX_HIP(hipMemcpyAsync(centroids_out, c->scratch2.p, sizeof(float) * kd, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipMemcpyAsync(labels_out, c->scratch4.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_quantize_sorted_codebook_dev(gsx_ctx *c, const float *vals_dev, int64_t n, const float *codebook_dev, int kcb,
+                                     uint8_t *idx_out_dev)
+{
+    if (!c || !vals_dev || !codebook_dev || !idx_out_dev) GSX_FAIL("gsx_quantize_sorted_codebook_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    return quantize_dev(c, vals_dev, n, codebook_dev, kcb, idx_out_dev);
+}
+
+int gsx_quantize_sorted_codebook(const float *vals, int64_t n, const float *codebook, int kcb, uint8_t *idx_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!vals || !codebook || !idx_out) GSX_FAIL("gsx_quantize_sorted_codebook: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch2.reserve(sizeof(float) * 256));
+    GSX_CHECK(c->scratch4.reserve((size_t)n + 4));
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, vals, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(hipMemcpyAsync(c->scratch2.p, codebook, sizeof(float) * (size_t)(kcb > 0 && kcb <= 256 ? kcb : 0),
+                           hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_quantize_sorted_codebook_dev(c, c->scratch.as<float>(), n, c->scratch2.as<float>(), kcb,
+                                               c->scratch4.as<uint8_t>()));
+    GSX_HIP(hipMemcpyAsync(idx_out, c->scratch4.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -1,0 +1,369 @@
+// density.hip -- voxel occupancy + per-point membership of the voxel-density filter.
+//
+// Replaces the O(N) parts of DataProcessor.apply_density_filter:
+//   data_processor.py:38-39   keys = floor(f32 xyz / voxel_size)            -> voxel_key()
+//   data_processor.py:43      np.unique(keys, axis=0, return_counts=True)   -> voxel_count_kernel
+//   data_processor.py:48-52   dense = counts >= min_points                  -> voxel_collect_kernel
+//   data_processor.py:111-114 mask = voxel(point) in kept clusters          -> voxel_mask_kernel
+// The 6-connected BFS over the (<= ~1000) dense voxels stays on the host
+// (3dgsconverter_amd/processing/clusters.py), as SURVEY.md 7.6 plans.
+//
+// Only counts per voxel and membership reach the mask, never np.unique's order, so the
+// lexicographic sort (the reference's O(N log N) hot spot) is replaced by an open-addressing
+// hash table in HBM keyed by a 63-bit packed voxel key (3 x 21 bits relative to the minimum
+// key).  Points arrive in arbitrary order; when few voxels hold most points the global
+// atomics would pile onto a handful of addresses, so every workgroup first aggregates its
+// 4096-point tile in a 1024-slot LDS table and flushes one global atomic per (tile, voxel).
+// HBM-bound: 12 B read per point per pass (bbox, count, mask) + 1 B written.
+#include <algorithm>
+#include <vector>
+
+#include "gsx_common.h"
+
+namespace gsx {
+
+struct VoxelFrame {
+    int kmin[3];
+    int dim[3];   // kmax - kmin + 1
+    int ok;       // 0: key range does not fit 3 x 21 bits (or non-finite coordinates)
+    int pad;
+};
+
+__device__ __forceinline__ int voxel_key(float v, float voxel)
+{
+    // np.floor(coords / voxel_size): IEEE f32 divide (hipcc keeps f32 divide correctly rounded), floor in f32
+    return (int)floorf(v / voxel);
+}
+
+__global__ __launch_bounds__(256) void bbox_partial_kernel2(const float *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ z, int64_t stride, int64_t n,
+                                                            float *__restrict__ part)
+{
+    __shared__ float red[6][4];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[3] = {x[i * stride], y[i * stride], z[i * stride]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], v[a]);
+            mx[a] = fmaxf(mx[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            red[a][w] = mn[a];
+            red[3 + a][w] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[threadIdx.x][0];
+        for (int i = 1; i < 4; ++i) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][i]) : fmaxf(v, red[threadIdx.x][i]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void voxel_frame_kernel(const float *__restrict__ part, int nparts, float voxel,
+                                                         VoxelFrame *__restrict__ vf)
+{
+    const int lane = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float acc = a < 3 ? __builtin_inff() : -__builtin_inff();
+        for (int i = lane; i < nparts; i += 64) acc = a < 3 ? fminf(acc, part[i * 6 + a]) : fmaxf(acc, part[i * 6 + a]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float o = __shfl_xor(acc, off);
+            acc = a < 3 ? fminf(acc, o) : fmaxf(acc, o);
+        }
+        v[a] = acc;
+    }
+    if (lane != 0) return;
+    int ok = 1;
+    for (int a = 0; a < 3; ++a) {
+        // x -> floor(x / voxel) is monotone, so the key range is the image of the coordinate range
+        float lo = floorf(v[a] / voxel), hi = floorf(v[3 + a] / voxel);
+        if (!(fabsf(lo) < 1.0e9f) || !(fabsf(hi) < 1.0e9f)) { ok = 0; lo = hi = 0.f; }
+        int klo = (int)lo, khi = (int)hi;
+        long long d = (long long)khi - klo + 1;
+        if (d > (1 << 21) - 1) { ok = 0; d = 1; }
+        vf->kmin[a] = klo;
+        vf->dim[a] = (int)d;
+    }
+    vf->ok = ok;
+    vf->pad = 0;
+}
+
+__device__ __forceinline__ unsigned long long pack_key(const VoxelFrame &f, int kx, int ky, int kz)
+{
+    // +1 so that 0 can mean "empty slot"
+    return (((unsigned long long)(unsigned)(kx - f.kmin[0]) << 42) | ((unsigned long long)(unsigned)(ky - f.kmin[1]) << 21) |
+            (unsigned long long)(unsigned)(kz - f.kmin[2])) + 1ull;
+}
+
+__device__ __forceinline__ unsigned hash_key(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (unsigned)k;
+}
+
+__device__ __forceinline__ void table_add(unsigned long long *__restrict__ tkeys, unsigned *__restrict__ tcnt,
+                                          unsigned mask, unsigned long long key, unsigned c)
+{
+    unsigned h = hash_key(key) & mask;
+    for (;;) {
+        unsigned long long old = tkeys[h];
+        if (old == 0ull) old = atomicCAS(&tkeys[h], 0ull, key);
+        if (old == 0ull || old == key) {
+            atomicAdd(&tcnt[h], c);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+constexpr int VOX_TILE = 4096;   // points per workgroup tile
+constexpr int VOX_LDS = 1024;    // LDS aggregation slots
+
+__global__ __launch_bounds__(256) void voxel_count_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, int64_t stride, int64_t n,
+                                                          float voxel, const VoxelFrame *__restrict__ vfp,
+                                                          unsigned long long *__restrict__ tkeys,
+                                                          unsigned *__restrict__ tcnt, unsigned tmask)
+{
+    __shared__ unsigned long long lkeys[VOX_LDS];
+    __shared__ unsigned lcnt[VOX_LDS];
+    const VoxelFrame f = *vfp;
+    if (!f.ok) return;
+    const int64_t ntiles = (n + VOX_TILE - 1) / VOX_TILE;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        for (int i = threadIdx.x; i < VOX_LDS; i += 256) { lkeys[i] = 0ull; lcnt[i] = 0u; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < VOX_TILE; j += 256) {
+            int64_t i = t * VOX_TILE + j;
+            if (i >= n) break;
+            unsigned long long key = pack_key(f, voxel_key(x[i * stride], voxel), voxel_key(y[i * stride], voxel),
+                                              voxel_key(z[i * stride], voxel));
+            unsigned h = hash_key(key) & (VOX_LDS - 1);
+            bool done = false;
+            for (int probe = 0; probe < 8 && !done; ++probe) {
+                unsigned long long old = lkeys[h];
+                if (old == 0ull) old = atomicCAS(&lkeys[h], 0ull, key);
+                if (old == 0ull || old == key) {
+                    atomicAdd(&lcnt[h], 1u);
+                    done = true;
+                } else {
+                    h = (h + 1) & (VOX_LDS - 1);
+                }
+            }
+            if (!done) table_add(tkeys, tcnt, tmask, key, 1u);  // LDS table crowded: straight to HBM
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < VOX_LDS; i += 256) {
+            unsigned c = lcnt[i];
+            if (c) table_add(tkeys, tcnt, tmask, lkeys[i], c);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void voxel_collect_kernel(const unsigned long long *__restrict__ tkeys,
+                                                            const unsigned *__restrict__ tcnt, unsigned tsize,
+                                                            unsigned min_points, unsigned dense_cap,
+                                                            unsigned long long *__restrict__ out_keys,
+                                                            unsigned *__restrict__ out_cnt,
+                                                            unsigned *__restrict__ counters /* [0]=unique [1]=dense */)
+{
+    unsigned uniq = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) {
+        unsigned long long k = tkeys[i];
+        if (k == 0ull) continue;
+        ++uniq;
+        unsigned c = tcnt[i];
+        if (c >= min_points) {
+            unsigned slot = atomicAdd(&counters[1], 1u);
+            if (slot < dense_cap) {
+                out_keys[slot] = k;
+                out_cnt[slot] = c;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) uniq += __shfl_xor(uniq, off);
+    if ((threadIdx.x & 63) == 0 && uniq) atomicAdd(&counters[0], uniq);
+}
+
+constexpr int KEPT_LDS = 4096;
+
+__global__ __launch_bounds__(256) void voxel_mask_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ z, int64_t stride, int64_t n,
+                                                         float voxel, const VoxelFrame *__restrict__ vfp,
+                                                         const unsigned long long *__restrict__ kept, int n_kept,
+                                                         uint8_t *__restrict__ mask)
+{
+    __shared__ unsigned long long lk[KEPT_LDS];
+    const VoxelFrame f = *vfp;
+    const bool in_lds = n_kept <= KEPT_LDS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n_kept; i += 256) lk[i] = kept[i];
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int kx = voxel_key(x[i * stride], voxel), ky = voxel_key(y[i * stride], voxel), kz = voxel_key(z[i * stride], voxel);
+        unsigned long long key = pack_key(f, kx, ky, kz);
+        int lo = 0, hi = n_kept;  // first index with kept[idx] >= key
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            unsigned long long v = in_lds ? lk[mid] : kept[mid];
+            if (v < key) lo = mid + 1; else hi = mid;
+        }
+        bool hit = lo < n_kept && (in_lds ? lk[lo] : kept[lo]) == key;
+        mask[i] = hit ? 1 : 0;
+    }
+}
+
+static int blocks_for(const gsx_ctx *ctx, int64_t n, int per_block)
+{
+    int64_t want = (n + per_block - 1) / per_block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * 8));
+}
+
+// frame (key range) of a device-resident cloud -> host copy
+static int compute_frame(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                         float voxel, VoxelFrame *dev_vf, VoxelFrame *host_vf)
+{
+    const int blocks = blocks_for(c, n, 1024);
+    GSX_CHECK(c->bboxpart.reserve(sizeof(float) * 6 * (size_t)blocks));
+    hipLaunchKernelGGL(bbox_partial_kernel2, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n,
+                       c->bboxpart.as<float>());
+    hipLaunchKernelGGL(voxel_frame_kernel, dim3(1), dim3(64), 0, c->stream, c->bboxpart.as<float>(), blocks, voxel, dev_vf);
+    GSX_HIP(hipGetLastError());
+    GSX_HIP(hipMemcpyAsync(host_vf, dev_vf, sizeof(VoxelFrame), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    if (!host_vf->ok)
+        GSX_FAIL("density: voxel key range does not fit 3 x 21 bits (extent / voxel_size too large) or coordinates are not finite");
+    return 0;
+}
+
+int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                       double voxel_size, int64_t min_points, int64_t dense_cap, int64_t *n_unique_out,
+                       int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    const float voxel = (float)voxel_size;  // python float is a weak scalar next to the f32 array
+    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
+    if (dense_cap < 0) GSX_FAIL("density: bad dense_cap");
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + 64));
+    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
+    VoxelFrame hvf;
+    GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+
+    // table size: power of two >= 2 x min(n, number of voxels in the frame)
+    double space = (double)hvf.dim[0] * hvf.dim[1] * hvf.dim[2];
+    uint64_t need = (uint64_t)std::min<double>((double)n, space);
+    uint64_t tsize = 1024;
+    while (tsize < 2 * need) tsize <<= 1;
+    if (tsize > (1ull << 31)) GSX_FAIL("density: too many points for the voxel table");
+    const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
+    // layout in one buffer: keys[tsize] | cnt[tsize] | out_keys[cap] | out_cnt[cap] | counters[2]
+    size_t off_cnt = sizeof(unsigned long long) * tsize;
+    size_t off_ok = off_cnt + sizeof(unsigned) * tsize;
+    off_ok = (off_ok + 15) & ~(size_t)15;
+    size_t off_oc = off_ok + sizeof(unsigned long long) * cap;
+    size_t off_ctr = (off_oc + sizeof(unsigned) * cap + 15) & ~(size_t)15;
+    GSX_CHECK(c->scratch2.reserve(off_ctr + 16));
+    char *base = c->scratch2.as<char>();
+    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(base);
+    unsigned *tcnt = reinterpret_cast<unsigned *>(base + off_cnt);
+    unsigned long long *okeys = reinterpret_cast<unsigned long long *>(base + off_ok);
+    unsigned *ocnt = reinterpret_cast<unsigned *>(base + off_oc);
+    unsigned *ctr = reinterpret_cast<unsigned *>(base + off_ctr);
+    GSX_HIP(hipMemsetAsync(base, 0, off_ok, c->stream));
+    GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
+    hipLaunchKernelGGL(voxel_count_kernel, dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
+                       voxel, dvf, tkeys, tcnt, (unsigned)(tsize - 1));
+    unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
+    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)tsize, 1024)), dim3(256), 0, c->stream, tkeys,
+                       tcnt, (unsigned)tsize, mp, (unsigned)cap, okeys, ocnt, ctr);
+    GSX_HIP(hipGetLastError());
+    unsigned hctr[2];
+    GSX_HIP(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    if ((int64_t)hctr[1] > dense_cap)
+        GSX_FAIL("density: %u dense voxels exceed dense_cap=%lld", hctr[1], (long long)dense_cap);
+    const size_t m = hctr[1];
+    std::vector<unsigned long long> hk(m);
+    std::vector<unsigned> hc(m);
+    if (m) {
+        GSX_HIP(hipMemcpy(hk.data(), okeys, sizeof(unsigned long long) * m, hipMemcpyDeviceToHost));
+        GSX_HIP(hipMemcpy(hc.data(), ocnt, sizeof(unsigned) * m, hipMemcpyDeviceToHost));
+    }
+    // packed keys order like (x, y, z) tuples because kmin is subtracted per axis: sort = np.unique's row order
+    std::vector<size_t> order(m);
+    for (size_t i = 0; i < m; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
+    for (size_t i = 0; i < m; ++i) {
+        unsigned long long k = hk[order[i]] - 1ull;
+        dense_keys_out[3 * i + 0] = (int64_t)(k >> 42) + hvf.kmin[0];
+        dense_keys_out[3 * i + 1] = (int64_t)((k >> 21) & 0x1fffff) + hvf.kmin[1];
+        dense_keys_out[3 * i + 2] = (int64_t)(k & 0x1fffff) + hvf.kmin[2];
+        dense_counts_out[i] = hc[order[i]];
+    }
+    *n_unique_out = hctr[0];
+    *n_dense_out = (int64_t)m;
+    return 0;
+}
+
+int density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                     double voxel_size, const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_dev)
+{
+    const float voxel = (float)voxel_size;
+    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + 64));
+    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
+    VoxelFrame hvf;
+    GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+    std::vector<unsigned long long> packed;
+    packed.reserve((size_t)n_kept);
+    for (int64_t i = 0; i < n_kept; ++i) {
+        int64_t r[3];
+        bool inside = true;
+        for (int a = 0; a < 3; ++a) {
+            r[a] = kept_keys[3 * i + a] - hvf.kmin[a];
+            inside &= r[a] >= 0 && r[a] < hvf.dim[a];
+        }
+        if (!inside) continue;  // a kept voxel outside the cloud's key range can match no point
+        packed.push_back((((unsigned long long)r[0] << 42) | ((unsigned long long)r[1] << 21) | (unsigned long long)r[2]) + 1ull);
+    }
+    std::sort(packed.begin(), packed.end());
+    packed.erase(std::unique(packed.begin(), packed.end()), packed.end());
+    const int nk = (int)packed.size();
+    GSX_CHECK(c->scratch2.reserve(sizeof(unsigned long long) * (size_t)std::max(nk, 1)));
+    if (nk)
+        GSX_HIP(hipMemcpyAsync(c->scratch2.p, packed.data(), sizeof(unsigned long long) * nk, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(voxel_mask_kernel, dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
+                       dvf, c->scratch2.as<unsigned long long>(), nk, mask_dev);
+    GSX_HIP(hipGetLastError());
+    GSX_HIP(hipStreamSynchronize(c->stream));  // `packed` (pageable host memory) must outlive the async copy
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    return 0;
+}
+
+}  // namespace gsx

@@ -21,6 +21,9 @@ def install():
     from .processing import gpu_ops, DataProcessor
     import gsconverter.processing as rp  # type: ignore  (raises ImportError if the reference is absent)
     import gsconverter.processing.data_processor as rdp  # type: ignore
+    from .processing import data_processor as mine
+    if rdp.DataProcessor is not DataProcessor:
+        mine._REFERENCE_CLASS = rdp.DataProcessor  # non-hot-path methods are forwarded to it
     targets = [(rp, "DataProcessor", DataProcessor), (rdp, "DataProcessor", DataProcessor),
                (rp, "gpu_ops", gpu_ops)]
     for modname, attr, val in (("gsconverter.converter", "DataProcessor", DataProcessor),

@@ -38,6 +38,20 @@ def density_params_from_sensitivity(sensitivity):
     return voxel_size, threshold_percentage
 
 
+_REFERENCE_CLASS = None  # set by install() before it rebinds gsconverter's name to this class
+
+
+def _reference_class():
+    global _REFERENCE_CLASS
+    if _REFERENCE_CLASS is None:
+        from gsconverter.processing.data_processor import DataProcessor as ref  # type: ignore
+        if ref.__module__.startswith("gsconverter"):
+            _REFERENCE_CLASS = ref
+        else:
+            raise ImportError("gsconverter.processing.DataProcessor is already the HIP drop-in")
+    return _REFERENCE_CLASS
+
+
 def _xyz_columns(vertices):
     return (np.ascontiguousarray(vertices["x"], dtype=np.float32),
             np.ascontiguousarray(vertices["y"], dtype=np.float32),
@@ -111,7 +125,7 @@ class DataProcessor:
         if name.startswith("__"):
             raise AttributeError(name)
         try:
-            from gsconverter.processing.data_processor import DataProcessor as _Ref  # type: ignore
+            _Ref = _reference_class()
         except Exception as e:  # pragma: no cover - depends on the environment
             raise AttributeError(
                 f"DataProcessor.{name} is outside the accelerated hot path and needs the reference package "

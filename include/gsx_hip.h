@@ -134,6 +134,15 @@ int gsx_density_voxels(const float *x, const float *y, const float *z, int64_t s
 int gsx_density_mask(const float *x, const float *y, const float *z, int64_t stride, int64_t n,
                      double voxel_size, const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_out);
 
+/* device-resident variants (dense_* outputs are HOST arrays; the kept set is a HOST array) */
+int gsx_density_voxels_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
+                           int64_t n, double voxel_size, int64_t min_points, int64_t dense_cap,
+                           int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
+                           int64_t *dense_counts_out);
+int gsx_density_mask_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
+                         int64_t n, double voxel_size, const int64_t *kept_keys, int64_t n_kept,
+                         uint8_t *mask_out_dev);
+
 /* ---- K-Means codebook (SOG writer) ------------------------------------- */
 /*
  * Lloyd iterations with an injected initialisation -- replaces _kmeans_taichi
@@ -146,6 +155,12 @@ int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter,
 /* nearest entry of a sorted codebook -- replaces quantize_to_codebook, formats/sog.py:408-419 */
 int gsx_quantize_sorted_codebook(const float *vals, int64_t n, const float *codebook, int kcb,
                                  uint8_t *idx_out);
+
+/* device-resident variants: centroids_dev holds the init on entry and the result on exit */
+int gsx_kmeans_lloyd_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, int k, int max_iter,
+                         float *centroids_dev, int32_t *labels_dev);
+int gsx_quantize_sorted_codebook_dev(gsx_ctx *ctx, const float *vals_dev, int64_t n,
+                                     const float *codebook_dev, int kcb, uint8_t *idx_out_dev);
 
 #ifdef __cplusplus
 }
