@@ -194,7 +194,7 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
 {
     if (!c || !name) GSX_FAIL("gsx_ctx_set_param: bad arguments");
     if (!strcmp(name, "grid_points_per_cell")) {
-        if (!(value >= 1.0 && value <= 512.0)) GSX_FAIL("grid_points_per_cell must be in [1,512]");
+        if (value != 0.0 && !(value >= 1.0 && value <= 512.0)) GSX_FAIL("grid_points_per_cell must be 0 (auto) or in [1,512]");
         c->grid_points_per_cell = value;
     } else if (!strcmp(name, "brute_below")) {
         c->brute_below = (int64_t)value;

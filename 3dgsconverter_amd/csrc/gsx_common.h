@@ -68,7 +68,7 @@ struct gsx_ctx {
     int num_cu = 256;
 
     // tunables
-    double grid_points_per_cell = 7.0;
+    double grid_points_per_cell = 0.0;  // 0 = auto: 0.47 * (k + 1), see launch_knn_grid
     int64_t brute_below = 2048;
 
     // SOR workspace

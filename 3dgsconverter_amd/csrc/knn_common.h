@@ -45,19 +45,32 @@ __device__ __forceinline__ float bound_from(double T)
     return __double2float_ru(T) * F32_SLACK + F32_TINY;
 }
 
-// Ascending list of the kk = k+1 smallest exact squared distances, kept in KCAP >= kk
-// registers.  The KCAP-kk lowest slots hold -inf sentinels, so the kk-th smallest real
-// value is always a[KCAP-1] (a STATIC register index) whatever k is.
+// Ascending list of the KCAP smallest exact squared distances seen so far (+inf padded), all in
+// registers and only ever indexed with compile-time constants.  KCAP >= kk = k+1; entries
+// beyond kk are simply further neighbours that are never read.
 template <int KCAP>
 struct TopList {
     double a[KCAP];
 
-    __device__ __forceinline__ void init(int kk)
+    __device__ __forceinline__ void init()
     {
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) a[i] = (i < KCAP - kk) ? -__builtin_inf() : __builtin_inf();
+        for (int i = 0; i < KCAP; ++i) a[i] = __builtin_inf();
     }
-    __device__ __forceinline__ double kth() const { return a[KCAP - 1]; }
+
+    // the kk-th smallest (kk is wave-uniform: the selects are driven by scalar compares)
+    __device__ __forceinline__ double kth(int kk) const
+    {
+        double r = a[KCAP - 1];
+#pragma unroll
+        for (int i = 0; i < KCAP - 1; ++i) {
+            r = (kk - 1 == i) ? a[i] : r;
+            // opaque to the optimiser: without it LLVM folds the select chain into a[kk-1], a
+            // DYNAMIC index that drags the whole list out of VGPRs into scratch memory
+            asm("" : "+v"(r));
+        }
+        return r;
+    }
 
     // branch-free sorted insert that drops the largest: 2 f64 VALU ops per slot.
     // Raw v_min_f64 / v_max_f64: fmin()/fmax() make LLVM add a canonicalising
@@ -76,7 +89,8 @@ struct TopList {
     }
 };
 
-// numpy pairwise sum of n <= 128 doubles read through a functor (loops_utils.h.src)
+// numpy pairwise sum of n <= 128 doubles read through a functor (loops_utils.h.src);
+// used where the values sit in LDS (dynamic indexing is free there)
 template <class F>
 __device__ __forceinline__ double pairwise_sum_le128(F at, int n)
 {
@@ -103,18 +117,36 @@ __device__ __forceinline__ double pairwise_sum_le128(F at, int n)
     return res;
 }
 
-// Epilogue: list -> (float) mean of sqrt of entries 1..k.  The list is copied to a
-// separate local array that is indexed dynamically (it lives in scratch); `lst.a`
-// itself is only ever indexed statically so it stays in VGPRs.
+// Epilogue: list -> (float) mean of sqrt(entries 1..k) in numpy's pairwise order (entry 0 is the
+// query itself).  Everything is unrolled with compile-time register indices; k is wave-uniform,
+// so the `j < ...` predicates are scalar branches.  No scratch memory.
 template <int KCAP>
 __device__ __forceinline__ float mean_from_list(const TopList<KCAP> &lst, int k)
 {
-    double b[KCAP];
+    double b[KCAP - 1];
 #pragma unroll
-    for (int i = 0; i < KCAP; ++i) b[i] = __dsqrt_rn(lst.a[i]);  // sqrt(-inf sentinel) = NaN, never read
-    const int first = KCAP - k;  // entry KCAP-k-1 is the query itself (dropped)
-    double sum = pairwise_sum_le128([&](int i) { return b[first + i]; }, k);
-    return __double2float_rn(__ddiv_rn(sum, (double)k));
+    for (int j = 0; j < KCAP - 1; ++j) b[j] = __dsqrt_rn(lst.a[1 + j]);
+    double res;
+    if (k < 8) {
+        res = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7 && j < KCAP - 1; ++j)
+            if (j < k) res = __dadd_rn(res, b[j]);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r[t] = b[t < KCAP - 1 ? t : 0];
+        const int nfull = k - (k % 8);
+#pragma unroll
+        for (int j = 8; j < KCAP - 1; ++j)
+            if (j < nfull) r[j & 7] = __dadd_rn(r[j & 7], b[j]);
+        res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                        __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+#pragma unroll
+        for (int j = 8; j < KCAP - 1; ++j)
+            if (j >= nfull && j < k) res = __dadd_rn(res, b[j]);
+    }
+    return __double2float_rn(__ddiv_rn(res, (double)k));
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

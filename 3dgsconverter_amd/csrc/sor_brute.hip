@@ -65,7 +65,7 @@ __global__ __launch_bounds__(BRUTE_THREADS) void knn_brute_kernel(
         float4 p = pts[live ? orig : 0];
         qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
         qxd[q] = (double)p.x; qyd[q] = (double)p.y; qzd[q] = (double)p.z;
-        lst[q].init(kk);
+        lst[q].init();
         bound[q] = live ? __builtin_inff() : -1.0f;  // dead lanes never pass the filter
     }
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BRUTE_THREADS) void knn_brute_kernel(
                         if (d2[u][q] <= bound[q]) {
                             double s = dist2_f64(qxd[q], qyd[q], qzd[q], px[u], py[u], pz[u]);
                             lst[q].insert(s);
-                            bound[q] = bound_from(lst[q].kth());
+                            bound[q] = bound_from(lst[q].kth(kk));
                         }
                     }
             }

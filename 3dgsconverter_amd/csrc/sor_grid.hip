@@ -33,7 +33,21 @@ namespace gsx {
 constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index rounding bound, see r_safe)
 constexpr int SCAN_BLOCK = 2048;    // elements per scan block (256 threads x 8)
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
-constexpr int WCAP = 32;            // mask words parked in LDS per wave between drains
+constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
+
+// Phase-1 filter step: shift the predicate "squared distance < tau" into the lane's bit mask.
+// d2 - tau is evaluated as one fma chain and its SIGN BIT is the predicate, so the shift-in is a
+// single v_alignbit_b32: ({m, t} >> 31) = (m << 1) | sign(t).  (v_cmp + v_addc cost 2 x 4.4
+// cycles on gfx950 -- tools/ubench/valu_rates.hip -- i.e. 38 % of the whole filter step.)
+// Rounding: the three fma roundings perturb t by <= 3 * 2^-24 * max(tau, d2), far inside the
+// 2e-6 relative slack already built into tau (knn_common.h F32_SLACK).
+__device__ __forceinline__ unsigned shift_in_lt(unsigned m, float qx, float qy, float qz, float px, float py,
+                                                float pz, float neg_tau)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, neg_tau)));
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -145,10 +159,12 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->hprime = hp;
     gp->r1sq = r1 * r1;
     gp->tau1 = bound_from(r1 * r1);
-    gp->brick_next = 0;
     gp->fail_count = 0;
-    gp->ring_next = 0;
     gp->exhaustive_count = 0;
+    for (int i = 0; i < 8; ++i) {
+        gp->brick_ctr[i * 32] = 0;
+        gp->ring_ctr[i * 32] = 0;
+    }
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim)
@@ -302,11 +318,11 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
     const float tau1 = gp->tau1;
     const int kk = k + 1;
 
+    WorkQueue wq;
+    wq_init(wq, gp->brick_ctr, nbricks, BRICK_THREADS / 64);
     for (;;) {
-        int b = 0;
-        if (lane == 0) b = (int)atomicAdd(&gp->brick_next, 1u);
-        b = uniform(b);
-        if (b >= nbricks) break;
+        const int b = uniform(wq_next(wq));
+        if (b < 0) break;
         const int bz = b / (nbx * nby);
         const int brem = b - bz * nbx * nby;
         const int by = brem / nbx;
@@ -351,16 +367,20 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
             const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
             float tau = live ? tau1 : -1.0f;
             TopList<KCAP> lst;
-            lst.init(kk);
+            lst.init();
 
             int widx = 0;
             unsigned nzw = 0;
 
             // ---- phase 2: walk this lane's set bits, exact f64 distance, sorted insert
-            auto drain = [&]() {
+            auto drain = [&]() __attribute__((always_inline)) {
                 wave_sync();  // wbase[] written by lane 0 is visible to every lane
                 unsigned m = 0;
                 int base = 0;
+                // software pipeline: the gather of candidate n+1 is in flight while candidate n goes
+                // through the float64 distance + the 2*KCAP-op sorted insert
+                bool have_cur = false;
+                float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (;;) {
                     if (m == 0 && nzw != 0) {
                         const int w = __builtin_ctz(nzw);
@@ -368,16 +388,19 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
                         m = mask[w][lane];
                         base = (int)wbase[w];
                     }
-                    const bool act = m != 0;
-                    if (!__any(act)) break;
-                    if (act) {
+                    const bool have_next = m != 0;
+                    float4 pn = pc;
+                    if (have_next) {
                         const int i = __builtin_clz(m);
                         m &= ~(0x80000000u >> i);
-                        const float4 p = refs[base + i];
-                        lst.insert(dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z));
+                        pn = refs[base + i];
                     }
+                    if (have_cur) lst.insert(dist2_f64(qxd, qyd, qzd, pc.x, pc.y, pc.z));
+                    if (!__any(have_next)) break;
+                    pc = pn;
+                    have_cur = have_next;
                 }
-                tau = fminf(tau, bound_from(lst.kth()));
+                tau = fminf(tau, bound_from(lst.kth(kk)));
                 widx = 0;
                 nzw = 0;
                 wave_sync();  // all reads of mask/wbase done before they are overwritten
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
                     if (widx == WCAP) drain();
                     const int c = min(32, len - w0);
                     const float4 *__restrict__ p = refs + gs + w0;
+                    const float neg_tau = -tau;  // dead lanes: tau = -1 => t > 0 => bit 0
                     unsigned m = 0;
                     int i = 0;
                     for (; i + 8 <= c; i += 8) {
@@ -399,14 +423,12 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
                         for (int u = 0; u < 8; ++u) P[u] = p[i + u];  // wave-uniform address: scalar loads
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            float d2 = dist2_f32(qx, qy, qz, P[u].x, P[u].y, P[u].z);
-                            m = (m << 1) | (d2 <= tau ? 1u : 0u);
+                            m = shift_in_lt(m, qx, qy, qz, P[u].x, P[u].y, P[u].z, neg_tau);
                         }
                     }
                     for (; i < c; ++i) {
                         float4 P = p[i];
-                        float d2 = dist2_f32(qx, qy, qz, P.x, P.y, P.z);
-                        m = (m << 1) | (d2 <= tau ? 1u : 0u);
+                        m = shift_in_lt(m, qx, qy, qz, P.x, P.y, P.z, neg_tau);
                     }
                     m <<= (32 - c);  // candidate i of this word <-> bit 31-i
                     mask[widx][lane] = m;
@@ -419,7 +441,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
 
             // ---- exact iff the (k+1)-th distance lies inside the searched cells
             if (live) {
-                if (lst.kth() <= r1sq) {
+                if (lst.kth(kk) <= r1sq) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);
@@ -445,6 +467,8 @@ __device__ __forceinline__ double wave_min_f64(double v)
     return v;
 }
 
+constexpr int RING_ROWS = 320;  // rows whose bounds are prefetched in parallel (covers H <= 8: 17x17)
+
 template <int KCAP>
 __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
@@ -452,18 +476,21 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     float *__restrict__ mean_out)
 {
     __shared__ double s_out[BRICK_THREADS / 64][KCAP];
+    __shared__ int s_rs[BRICK_THREADS / 64][RING_ROWS];       // first point of each row
+    __shared__ int s_ro[BRICK_THREADS / 64][RING_ROWS + 1];   // flat offset of each row
     const int lane = lane_id();
     const int wv = uniform((int)(threadIdx.x >> 6));
     double *out = s_out[wv];
+    int *rs = s_rs[wv], *ro = s_ro[wv];
     const GridParams g = *gp;
     const int nfail = (int)g.fail_count;
     const int kk = k + 1;
 
+    WorkQueue wq;
+    wq_init(wq, gp->ring_ctr, nfail, BRICK_THREADS / 64);
     for (;;) {
-        int t = 0;
-        if (lane == 0) t = (int)atomicAdd(&gp->ring_next, 1u);
-        t = uniform(t);
-        if (t >= nfail) break;
+        const int t = uniform(wq_next(wq));
+        if (t < 0) break;
         const float4 qp = qpts[faillist[t]];
         const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
         const int cx = cell_coord(qp.x, g.ox, g.inv_h, g.nx);
@@ -474,28 +501,77 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
             double a[KCAP];  // ascending, +inf padded: a[0] is this lane's smallest
 #pragma unroll
             for (int i = 0; i < KCAP; ++i) a[i] = __builtin_inf();
+            auto consider = [&](const float4 p) __attribute__((always_inline)) {
+                double d = dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z);
+                if (d < a[KCAP - 1]) {
+#pragma unroll
+                    for (int i = 0; i < KCAP; ++i) {
+                        double lo, hi;
+                        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a[i]), "v"(d));
+                        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a[i]), "v"(d));
+                        a[i] = lo;
+                        d = hi;
+                    }
+                }
+            };
             const int x0 = max(cx - H, 0), x1 = min(cx + H, g.nx - 1);
             const int y0 = max(cy - H, 0), y1 = min(cy + H, g.ny - 1);
             const int z0 = max(cz - H, 0), z1 = min(cz + H, g.nz - 1);
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const int row = (zz * g.ny + yy) * g.nx;
-                    const int s = (int)rstart[row + x0], e = (int)rstart[row + x1 + 1];
-                    for (int j = s + lane; j < e; j += 64) {
-                        const float4 p = refs[j];
-                        double d = dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z);
-                        if (d < a[KCAP - 1]) {
+            const int nyr = y1 - y0 + 1;
+            const int nrows = nyr * (z1 - z0 + 1);
+            if (nrows <= RING_ROWS) {
+                // all row bounds in parallel (one lane per row), wave scan -> flat offsets in LDS
+                int carry = 0;
+                for (int r0 = 0; r0 < nrows; r0 += 64) {
+                    const int r = r0 + lane;
+                    int s = 0, len = 0;
+                    if (r < nrows) {
+                        const int zz = z0 + r / nyr, yy = y0 + r % nyr;
+                        const int row = (zz * g.ny + yy) * g.nx;
+                        s = (int)rstart[row + x0];
+                        len = (int)rstart[row + x1 + 1] - s;
+                    }
+                    int inc = len;
 #pragma unroll
-                            for (int i = 0; i < KCAP; ++i) {
-                                double lo, hi;
-                                asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a[i]), "v"(d));
-                                asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a[i]), "v"(d));
-                                a[i] = lo;
-                                d = hi;
-                            }
+                    for (int off = 1; off < 64; off <<= 1) {
+                        int o = __shfl_up(inc, off);
+                        if (lane >= off) inc += o;
+                    }
+                    if (r < nrows) {
+                        rs[r] = s;
+                        ro[r] = carry + inc - len;
+                    }
+                    carry += __shfl(inc, 63);
+                }
+                const int total = carry;
+                if (lane == 0) ro[nrows] = total;
+                wave_sync();
+                // every lane walks the flat candidate range with stride 64, 4 independent loads in flight
+                int row = 0;
+                for (int f0 = lane; f0 < total; f0 += 256) {
+                    float4 p[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int f = f0 + 64 * u;
+                        ok[u] = f < total;
+                        if (ok[u]) {
+                            while (f >= ro[row + 1]) ++row;
+                            p[u] = refs[rs[row] + (f - ro[row])];
                         }
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ok[u]) consider(p[u]);
                 }
+            } else {
+                for (int zz = z0; zz <= z1; ++zz)
+                    for (int yy = y0; yy <= y1; ++yy) {
+                        const int row = (zz * g.ny + yy) * g.nx;
+                        const int s = (int)rstart[row + x0], e = (int)rstart[row + x1 + 1];
+                        for (int j = s + lane; j < e; j += 64) consider(refs[j]);
+                    }
+            }
             // merge: kk rounds of wave-min over the list heads
             for (int r = 0; r < kk; ++r) {
                 const double mn = wave_min_f64(a[0]);
@@ -539,14 +615,14 @@ static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, c
                              const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
                              float *mean_out, unsigned *faillist)
 {
-    const int wgs = ctx->num_cu * 4;  // persistent: 16 waves per CU pull bricks from a counter
+    const int wgs = ctx->num_cu * 5;  // persistent: 20 waves per CU (5 per SIMD) pull bricks from the per-XCD queues
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
     hipLaunchKernelGGL((knn_brick_kernel<KCAP>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
                        qpts, qstart, k, (int)q_begin, mean_out, faillist);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
-    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * 5), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
                        qpts, faillist, k, (int)q_begin, mean_out);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
@@ -582,6 +658,11 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     const int nparts = div_up(cap + 1, SCAN_BLOCK);
     const bool all = (q_begin == 0 && q_count == n_ref);
     const int bbox_blocks = grid_blocks(ctx, n_ref, 4);
+    // cell edge h is also the guaranteed search radius: the expected number of points within h is
+    // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts
+    // ~2 (k+1) points inside h (measured optimum at k = 8, 16, 32: profiles/r01_probe_*.log).
+    const double pts_per_cell = ctx->grid_points_per_cell > 0.0 ? ctx->grid_points_per_cell
+                                                                 : std::max(2.0, 0.47 * (double)(k + 1));
 
     GSX_CHECK(ctx->packed.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(ctx->rank.reserve(sizeof(unsigned) * (size_t)n_ref));
@@ -605,7 +686,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        ctx->bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, ctx->grid_points_per_cell, (int)cap, gp);
+                       (int)n_ref, pts_per_cell, (int)cap, gp);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, cap, ctx->cellcnt.as<unsigned>(), rstart,
                          ctx->rank.as<unsigned>(), ctx->scanpart.as<unsigned>(), refs));

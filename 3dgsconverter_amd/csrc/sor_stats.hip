@@ -11,8 +11,9 @@
 //     accumulators, recursive split at n/2 rounded down to a multiple of 8;
 //   * mean = (float)((double)sum / n); var likewise from sum((x-mean)^2); std = sqrtf;
 //   * threshold = mean + (float)factor * std in f32.
-// One wave sums one 8192-element piece: lane l owns leaf l (128 contiguous floats), the 64
-// leaf sums combine in the balanced tree the recursion produces for 8192.  The ragged last
+// One 128-lane workgroup sums one 8192-element piece: two lanes own each 128-element leaf (4 of
+// numpy's 8 accumulators each, 16-byte loads), the 64 leaf sums combine in the balanced tree the
+// recursion produces for 8192.  The ragged last
 // piece is split into its (irregular) leaves by lane 0 and combined by the same recursion.
 // HBM-bound and tiny: 4 B/splat per pass, 3 passes.
 #include "gsx_common.h"
@@ -53,50 +54,52 @@ __device__ float leaf_sum(const float *__restrict__ a, int n, float mean)
     return res;
 }
 
+constexpr int CHUNK_THREADS = 128;  // one workgroup (2 waves) per 8192-element piece
+
 template <bool SQ>
-__global__ __launch_bounds__(256) void chunk_sums_kernel(const float *__restrict__ a, int64_t n,
-                                                         const float *__restrict__ stats,
-                                                         float *__restrict__ chunk_sum)
+__global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *__restrict__ a, int64_t n,
+                                                                   const float *__restrict__ stats,
+                                                                   float *__restrict__ chunk_sum)
 {
-    __shared__ int s_leaf_start[4][160];
-    __shared__ int s_leaf_len[4][160];
-    __shared__ float s_leaf_val[4][160];
+    __shared__ int s_leaf_start[160];
+    __shared__ int s_leaf_len[160];
+    __shared__ float s_leaf_val[160];
+    __shared__ float s_half[2];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
-    const int64_t c = (int64_t)blockIdx.x * 4 + wv;
-    if (c >= nchunks) return;  // no block-wide barrier below
+    const int64_t c = blockIdx.x;
     const float mean = SQ ? stats[0] : 0.0f;
     const float *p = a + c * NP_BUF;
     const int len = (int)((n - c * NP_BUF) < NP_BUF ? (n - c * NP_BUF) : NP_BUF);
 
-    if (len == NP_BUF) {
-        // 64 leaves of 128; leaf l = elements [128 l, 128 l + 128): 8 accumulators over 16 rows
-        const float4 *q = reinterpret_cast<const float4 *>(p + lane * 128);
-        float r[8];
-        {
-            float4 v0 = q[0], v1 = q[1];
-            r[0] = elem<SQ>(v0.x, mean); r[1] = elem<SQ>(v0.y, mean); r[2] = elem<SQ>(v0.z, mean); r[3] = elem<SQ>(v0.w, mean);
-            r[4] = elem<SQ>(v1.x, mean); r[5] = elem<SQ>(v1.y, mean); r[6] = elem<SQ>(v1.z, mean); r[7] = elem<SQ>(v1.w, mean);
-        }
+    if (len == NP_BUF) {  // block-uniform
+        // 64 leaves of 128 elements; two lanes per leaf: lane (leaf, hh) owns accumulators 4hh..4hh+3
+        // (numpy's r[0..7]) and walks the leaf's 16 rows with one 16-byte load per row.
+        const int leaf = threadIdx.x >> 1, hh = threadIdx.x & 1;
+        const float4 *q = reinterpret_cast<const float4 *>(p + leaf * 128 + hh * 4);
+        float4 v = q[0];
+        float r0 = elem<SQ>(v.x, mean), r1 = elem<SQ>(v.y, mean), r2 = elem<SQ>(v.z, mean), r3 = elem<SQ>(v.w, mean);
 #pragma unroll
         for (int i = 1; i < 16; ++i) {
-            float4 v0 = q[2 * i], v1 = q[2 * i + 1];
-            r[0] += elem<SQ>(v0.x, mean); r[1] += elem<SQ>(v0.y, mean); r[2] += elem<SQ>(v0.z, mean); r[3] += elem<SQ>(v0.w, mean);
-            r[4] += elem<SQ>(v1.x, mean); r[5] += elem<SQ>(v1.y, mean); r[6] += elem<SQ>(v1.z, mean); r[7] += elem<SQ>(v1.w, mean);
+            v = q[2 * i];  // +8 floats per row
+            r0 += elem<SQ>(v.x, mean); r1 += elem<SQ>(v.y, mean); r2 += elem<SQ>(v.z, mean); r3 += elem<SQ>(v.w, mean);
         }
-        float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        // balanced tree over adjacent leaves (8192 -> 4096+4096 -> ... -> 128)
+        float s = (r0 + r1) + (r2 + r3);      // (r0+r1)+(r2+r3)  |  (r4+r5)+(r6+r7)
+        s = s + __shfl_xor(s, 1);             // leaf sum (both lanes of the pair hold it)
+        // balanced tree over adjacent leaves: 128 -> 256 -> ... -> 4096 inside the wave
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) s = s + __shfl_down(s, off);
-        if (lane == 0) chunk_sum[c] = s;
+        for (int off = 2; off < 64; off <<= 1) s = s + __shfl_xor(s, off);
+        if (lane == 0) s_half[wv] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_sum[c] = s_half[0] + s_half[1];  // 4096 + 4096
         return;
     }
 
-    // ragged last piece: enumerate the recursion's leaves in order (lane 0), sum leaves in
-    // parallel, then replay the recursion over the leaf sums (lane 0).
-    int *ls = s_leaf_start[wv], *ll = s_leaf_len[wv];
-    float *lv = s_leaf_val[wv];
+    // ragged last piece (wave 0 only): enumerate the recursion's leaves in order (lane 0), sum the
+    // leaves in parallel, then replay the recursion over the leaf sums (lane 0).
+    if (wv != 0) return;
+    int *ls = s_leaf_start, *ll = s_leaf_len;
+    float *lv = s_leaf_val;
     int nleaf = 0;
     if (lane == 0) {
         int st_n[20], st_o[20], sp = 0;
@@ -197,11 +200,11 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
     const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
     GSX_CHECK(ctx->statspart.reserve(sizeof(float) * (size_t)nchunks));
     float *cs = ctx->statspart.as<float>();
-    const int blocks = div_up(nchunks, 4);
+    const int blocks = (int)nchunks;
     const float tf = (float)factor;  // python float is a weak scalar: rounded to f32 first
-    hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, md, n, stats_dev, cs);
+    hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, cs, n, 0, tf, stats_dev);
-    hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, md, n, stats_dev, cs);
+    hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, cs, n, 1, tf, stats_dev);
     GSX_HIP(hipGetLastError());
     return 0;
