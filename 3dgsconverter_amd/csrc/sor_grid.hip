@@ -14,8 +14,8 @@
 //   knn_ring                               expanding-ring exact fallback for the few queries
 //                                          whose (k+1)-th neighbour is farther than one cell
 //
-// knn_brick: the 64 lanes of a wave are 64 queries of one brick.  The brick's 4x4x4-cell
-// neighbourhood is 16 x-rows, each a CONTIGUOUS range of the sorted array; the wave walks
+// knn_brick: the 64 lanes of a wave are 64 queries of one brick (2x2x2 cells for k <= 16, fewer
+// cells for larger k).  The brick's neighbourhood (brick + 1 cell each way, 4x4x4 cells) is 16 x-rows, each a CONTIGUOUS range of the sorted array; the wave walks
 // those ranges in lock step with wave-uniform (scalar-cache) loads -- no LDS staging, no
 // per-lane addressing.  Phase 1 only FILTERS: 6 f32 ops for the squared distance, one
 // compare against r_safe^2 and one shift-or build a per-lane bit mask (32 candidates per
@@ -150,7 +150,15 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->h = (float)h;
     gp->nx = nx; gp->ny = ny; gp->nz = nz;
     gp->ncells = nx * ny * nz;
-    gp->nbx = (nx + 1) / 2; gp->nby = (ny + 1) / 2; gp->nbz = (nz + 1) / 2;
+    // brick = the cells one wave owns.  Its ~pts_per_cell * cells queries should fill 64 lanes in ONE
+    // batch (a second batch repeats the whole neighbourhood scan): 2x2x2 cells up to ~8 pts/cell
+    // (k <= 16), then 2x2x1, 2x1x1, 1x1x1 as k -- hence the cell population -- grows.
+    int bdx = 2, bdy = 2, bdz = 2;
+    if (pts_per_cell * 8.0 > 66.0) bdz = 1;
+    if (pts_per_cell * 4.0 > 66.0) bdy = 1;
+    if (pts_per_cell * 2.0 > 66.0) bdx = 1;
+    gp->bdx = bdx; gp->bdy = bdy; gp->bdz = bdz;
+    gp->nbx = (nx + bdx - 1) / bdx; gp->nby = (ny + bdy - 1) / bdy; gp->nbz = (nz + bdz - 1) / bdz;
     gp->nbricks = gp->nbx * gp->nby * gp->nbz;
     // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
     // f32 cell index floor(fl(fl(x-o)*inv_h)) is monotone and off by < dim*2^-22 <= 2.5e-4 cells.
@@ -313,6 +321,10 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
 
     const int nx = gp->nx, ny = gp->ny, nz = gp->nz;
     const int nbx = gp->nbx, nby = gp->nby;
+    const int bdx = gp->bdx, bdy = gp->bdy, bdz = gp->bdz;
+    const int cry = bdy + 2;                  // candidate rows per z-slab
+    const int ncrows = cry * (bdz + 2);       // <= 16 candidate x-rows
+    const int nqrows = bdy * bdz;             // <= 4 query x-rows
     const int nbricks = gp->nbricks;
     const double r1sq = gp->r1sq;
     const float tau1 = gp->tau1;
@@ -328,16 +340,16 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
         const int by = brem / nbx;
         const int bx = brem - by * nbx;
 
-        // lane r < 16: candidate row r (4 cells along x); lanes 16..19: query rows (2 cells)
+        // lane r < 16: candidate row r (bdx+2 cells along x); lanes 16..19: query rows (bdx cells)
         int v_start = 0, v_len = 0;
         {
             const bool isq = lane >= 16;
             const int r = isq ? lane - 16 : lane;
-            const int yy = isq ? 2 * by + (r & 1) : 2 * by - 1 + (r & 3);
-            const int zz = isq ? 2 * bz + (r >> 1) : 2 * bz - 1 + (r >> 2);
-            const int xa = isq ? 2 * bx : max(2 * bx - 1, 0);
-            const int xb = isq ? min(2 * bx + 1, nx - 1) : min(2 * bx + 2, nx - 1);
-            const bool valid = lane < 20 && yy >= 0 && yy < ny && zz >= 0 && zz < nz;
+            const int yy = isq ? by * bdy + (r % bdy) : by * bdy - 1 + (r % cry);
+            const int zz = isq ? bz * bdz + (r / bdy) : bz * bdz - 1 + (r / cry);
+            const int xa = isq ? bx * bdx : max(bx * bdx - 1, 0);
+            const int xb = isq ? min(bx * bdx + bdx - 1, nx - 1) : min(bx * bdx + bdx, nx - 1);
+            const bool valid = (isq ? (lane < 20 && r < nqrows) : r < ncrows) && yy >= 0 && yy < ny && zz >= 0 && zz < nz;
             if (valid) {
                 const unsigned *st = isq ? qstart : rstart;
                 const int row = (zz * ny + yy) * nx;
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
             };
 
             // ---- phase 1: lock-step filter over the 16 candidate rows
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < ncrows; ++r) {
                 const int gs = __builtin_amdgcn_readlane(v_start, r);
                 const int len = __builtin_amdgcn_readlane(v_len, r);
                 for (int w0 = 0; w0 < len; w0 += 32) {
@@ -589,9 +601,12 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
             const double rH = (double)H * g.hprime * (1.0 - 1e-3);
             const double kth = out[kk - 1];
             if (covers || kth <= rH * rH) {
+                // sqrt of the k+1 winners in parallel (one lane each), then lane 0 sums in numpy order
+                for (int i = lane; i < kk; i += 64) out[i] = __dsqrt_rn(out[i]);
+                wave_sync();
                 if (lane == 0) {
                     if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
-                    double sum = pairwise_sum_le128([&](int i) { return __dsqrt_rn(out[1 + i]); }, k);
+                    double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
                 }
                 wave_sync();
@@ -657,7 +672,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     const int64_t cap = grid_cell_cap(n_ref);
     const int nparts = div_up(cap + 1, SCAN_BLOCK);
     const bool all = (q_begin == 0 && q_count == n_ref);
-    const int bbox_blocks = grid_blocks(ctx, n_ref, 4);
+    const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
     // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts
     // ~2 (k+1) points inside h (measured optimum at k = 8, 16, 32: profiles/r01_probe_*.log).

@@ -10,6 +10,7 @@ struct GridParams {
     int ncells;
     int nbx, nby, nbz;
     int nbricks;
+    int bdx, bdy, bdz;  // brick size in cells: (2,2,2), (2,2,1), (2,1,1) or (1,1,1)
     float tau1;      // f32 filter bound for r1sq
     double r1sq;     // (h' * (1 - 1e-3))^2, h' = 1/inv_h
     double hprime;   // 1/inv_h

@@ -32,29 +32,47 @@ __device__ __forceinline__ float elem(float v, float mean)
     return v;
 }
 
-// numpy leaf: n <= 128 elements
-template <bool SQ>
-__device__ float leaf_sum(const float *__restrict__ a, int n, float mean)
+constexpr int CHUNK_THREADS = 128;  // one workgroup (2 waves) per 8192-element piece
+
+// numpy's split: left half = n/2 rounded down to a multiple of 8
+__device__ __forceinline__ int np_split(int n)
 {
-    if (n < 8) {
-        float res = 0.0f;
-        for (int i = 0; i < n; ++i) res += elem<SQ>(a[i], mean);
-        return res;
-    }
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = elem<SQ>(a[j], mean);
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] += elem<SQ>(a[i + j], mean);
-    }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += elem<SQ>(a[i], mean);
-    return res;
+    int n2 = n / 2;
+    return n2 - (n2 % 8);
 }
 
-constexpr int CHUNK_THREADS = 128;  // one workgroup (2 waves) per 8192-element piece
+// leaf (lo, n) of the recursion over [0, len) that contains element `pos` -- registers only
+__device__ __forceinline__ void leaf_of(int len, int pos, int &lo, int &n)
+{
+    lo = 0;
+    n = len;
+#pragma unroll 1
+    while (n > 128) {
+        const int n2 = np_split(n);
+        if (pos < lo + n2) {
+            n = n2;
+        } else {
+            lo += n2;
+            n -= n2;
+        }
+    }
+}
+
+// S(n) = S(n2) + S(n - n2) replayed over the leaf sums (consumed in DFS order).  The recursion is at
+// most 7 deep for n <= 8192, so it is expanded at compile time: no stack arrays, no scratch memory.
+template <int DEPTH>
+__device__ __forceinline__ float replay_tree(int n, const float *lv, int &li)
+{
+    if constexpr (DEPTH == 0) {
+        return lv[li++];
+    } else {
+        if (n <= 128) return lv[li++];
+        const int n2 = np_split(n);
+        const float a = replay_tree<DEPTH - 1>(n2, lv, li);
+        const float b = replay_tree<DEPTH - 1>(n - n2, lv, li);
+        return a + b;
+    }
+}
 
 template <bool SQ>
 __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *__restrict__ a, int64_t n,
@@ -95,77 +113,96 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
         return;
     }
 
-    // ragged last piece (wave 0 only): enumerate the recursion's leaves in order (lane 0), sum the
-    // leaves in parallel, then replay the recursion over the leaf sums (lane 0).
-    if (wv != 0) return;
+    // ragged last piece.  Every leaf of numpy's recursion is >= 57 elements, so it contains a multiple
+    // of 32: each thread descends the recursion for two such positions (registers only) and the
+    // thread whose position is the FIRST multiple of 32 inside a leaf owns it.  Owners are ranked in
+    // position order (= the recursion's DFS order), 8 lanes per leaf sum the leaves, thread 0 replays
+    // the tree over the leaf sums with a compile-time-expanded recursion.
     int *ls = s_leaf_start, *ll = s_leaf_len;
     float *lv = s_leaf_val;
-    int nleaf = 0;
-    if (lane == 0) {
-        int st_n[20], st_o[20], sp = 0;
-        st_n[0] = len; st_o[0] = 0; sp = 1;
-        while (sp > 0) {
-            int nn = st_n[sp - 1], oo = st_o[sp - 1];
-            --sp;
-            if (nn <= 128) {
-                ls[nleaf] = oo; ll[nleaf] = nn; ++nleaf;
-            } else {
-                int n2 = nn / 2;
-                n2 -= n2 % 8;
-                // push right first so the left half is expanded first (in-order leaves)
-                st_n[sp] = nn - n2; st_o[sp] = oo + n2; ++sp;
-                st_n[sp] = n2; st_o[sp] = oo; ++sp;
-            }
+    __shared__ int s_cnt[4];
+    int my_lo[2], my_n[2];
+    bool own[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pos = 32 * ((int)threadIdx.x * 2 + u);   // positions in increasing thread order
+        own[u] = false;
+        my_lo[u] = 0; my_n[u] = 0;
+        if (pos < len || (pos == 0 && len > 0)) {
+            leaf_of(len, pos, my_lo[u], my_n[u]);
+            own[u] = pos - my_lo[u] < 32 && (pos == 0 || pos - 32 < my_lo[u]);
         }
     }
-    nleaf = __shfl(nleaf, 0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int l = lane; l < nleaf; l += 64) lv[l] = leaf_sum<SQ>(p + ls[l], ll[l], mean);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        // replay: post-order evaluation of S(n) = S(n2) + S(n - n2)
-        float vals[24];
-        int st_n[24];
-        signed char st_s[24];
-        int sp = 1, vp = 0, li = 0;
-        st_n[0] = len; st_s[0] = 0;
-        while (sp > 0) {
-            int nn = st_n[sp - 1];
-            int s = st_s[sp - 1];
-            if (nn <= 128) {
-                vals[vp++] = lv[li++];
-                --sp;
-            } else {
-                int n2 = nn / 2;
-                n2 -= n2 % 8;
-                if (s == 0) { st_s[sp - 1] = 1; st_n[sp] = n2; st_s[sp] = 0; ++sp; }
-                else if (s == 1) { st_s[sp - 1] = 2; st_n[sp] = nn - n2; st_s[sp] = 0; ++sp; }
-                else { float rr = vals[vp - 2] + vals[vp - 1]; vp -= 2; vals[vp++] = rr; --sp; }
-            }
+    const int mine = (int)own[0] + (int)own[1];
+    // exclusive prefix of `mine` over the 128 threads (wave scan + one cross-wave add)
+    int inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_cnt[wv] = inc;
+    __syncthreads();
+    int rank = inc - mine + (wv == 1 ? s_cnt[0] : 0);
+    const int nleaf = s_cnt[0] + s_cnt[1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (own[u]) {
+            ls[rank] = my_lo[u];
+            ll[rank] = my_n[u];
+            ++rank;
         }
-        chunk_sum[c] = vals[0];
+    __syncthreads();
+    const int j = threadIdx.x & 7;
+    for (int l0 = 0; l0 < nleaf; l0 += CHUNK_THREADS / 8) {  // uniform trip count
+        const int l = l0 + (int)(threadIdx.x >> 3);
+        const bool live = l < nleaf;
+        const int L = live ? ll[l] : 0;
+        const float *q = p + (live ? ls[l] : 0);
+        float res;
+        if (L < 8) {
+            res = 0.0f;
+            for (int i = 0; i < L; ++i) res += elem<SQ>(q[i], mean);  // every lane of the group, same value
+        } else {
+            const int rows = L >> 3;
+            float r = elem<SQ>(q[j], mean);
+            for (int i = 1; i < rows; ++i) r += elem<SQ>(q[8 * i + j], mean);
+            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- shuffles stay inside the 8-lane group
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            r = r + __shfl_xor(r, 4);
+            res = r;
+            for (int i = rows * 8; i < L; ++i) res += elem<SQ>(q[i], mean);
+        }
+        if (live && j == 0) lv[l] = res;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int li = 0;
+        chunk_sum[c] = replay_tree<7>(len, lv, li);
     }
 }
 
 // mode 0: stats[0] = mean.  mode 1: stats[1] = std, stats[2] = threshold.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n,
-                                                             int mode, float factor, float *__restrict__ stats)
+// One wave: numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial; the
+// wave loads 64 piece sums per step (coalesced) and folds them in order through v_readlane.
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n,
+                                                            int mode, float factor, float *__restrict__ stats)
 {
-    __shared__ float buf[8192];
+    const int lane = threadIdx.x;
     const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
     float acc = 0.0f;
-    for (int64_t base = 0; base < nchunks; base += 8192) {
-        const int m = (int)((nchunks - base) < 8192 ? (nchunks - base) : 8192);
-        for (int i = threadIdx.x; i < m; i += blockDim.x) buf[i] = chunk_sum[base + i];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 0; i < m; ++i) acc += buf[i];  // numpy: sequential over buffer pieces
+    for (int64_t base = 0; base < nchunks; base += 64) {
+        const int m = (int)((nchunks - base) < 64 ? (nchunks - base) : 64);
+        const float v = lane < m ? chunk_sum[base + lane] : 0.0f;
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+        } else {
+            for (int j = 0; j < m; ++j) acc += __shfl(v, j);
         }
-        __syncthreads();
     }
-    if (threadIdx.x != 0) return;
+    if (lane != 0) return;
     const float q = (float)((double)acc / (double)n);  // f32 sum / np.intp count: float64 divide, cast back
     if (mode == 0) {
         stats[0] = q;
@@ -203,9 +240,9 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
     const int blocks = (int)nchunks;
     const float tf = (float)factor;  // python float is a weak scalar: rounded to f32 first
     hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, cs, n, 0, tf, stats_dev);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, 0, tf, stats_dev);
     hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, cs, n, 1, tf, stats_dev);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, 1, tf, stats_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

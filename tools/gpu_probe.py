@@ -46,21 +46,36 @@ def run(ctx, xyz, k, algo, m=None, reps=3, label=""):
         a.free()
 
 
+def host_level(xyz, k, label):
+    """PCIe-inclusive: numpy (N,3) in host memory -> bool mask in host memory (gsx_sor_filter)."""
+    L.sor_filter(xyz, k, 1.0, want_mean=False)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        L.sor_filter(xyz, k, 1.0, want_mean=False)
+    dt = (time.perf_counter() - t0) / reps
+    print("%-28s n=%9d k=%2d host->host %.3f ms  %.1f Msplat/s (PCIe inclusive)" % (label, len(xyz), k, dt * 1e3, len(xyz) / dt / 1e6), flush=True)
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     ctx = L.Context(0)
     x1 = uniform(1_000_000, 10.0)
-    for m in (5.0, 6.0, 7.0, 8.0, 10.0):
+    for m in (7.0, 8.0, 9.0, 0.0):
         run(ctx, x1, 16, 2, m, label="grid 1M")
-    run(ctx, x1, 32, 2, 14.0, label="grid 1M k32")
-    run(ctx, x1, 32, 2, 10.0, label="grid 1M k32")
-    run(ctx, x1, 8, 2, 4.0, label="grid 1M k8")
+    for k in (8, 25, 32, 50):
+        run(ctx, x1, k, 2, 0.0, label="grid 1M auto-m")
+    run(ctx, x1, 25, 2, 8.0, label="grid 1M k25 m8")
+    run(ctx, x1, 32, 2, 10.0, label="grid 1M k32 m10")
     run(ctx, uniform(100_000, 10.0), 16, 1, None, label="brute 100k")
+    host_level(x1, 16, "host 1M")
     if not quick:
         run(ctx, x1, 16, 1, None, reps=1, label="brute 1M")
         x10 = uniform(10_000_000, 5.0)
-        for m in (6.0, 7.0, 8.0):
+        for m in (7.0, 8.0, 9.0):
             run(ctx, x10, 16, 2, m, label="grid 10M")
+        run(ctx, x10, 25, 2, 0.0, label="grid 10M k25")
+        host_level(x10, 16, "host 10M")
     ctx.close()
 
 
