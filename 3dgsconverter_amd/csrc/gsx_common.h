@@ -82,6 +82,7 @@ struct gsx_ctx {
     gsx::DevBuf gridparams;  // GridParams + work counters
     gsx::DevBuf bboxpart;    // float[6 * blocks]
     gsx::DevBuf faillist;    // u32[q_count]
+    gsx::DevBuf extraitems;  // uint2[q_count/64 + 64]: (brick, first query) of every batch beyond a brick's first
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging
     gsx::DevBuf scratch2;

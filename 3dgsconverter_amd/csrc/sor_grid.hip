@@ -169,8 +169,10 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->tau1 = bound_from(r1 * r1);
     gp->fail_count = 0;
     gp->exhaustive_count = 0;
+    gp->extra_count = 0;
     for (int i = 0; i < 8; ++i) {
         gp->brick_ctr[i * 32] = 0;
+        gp->extra_ctr[i * 32] = 0;
         gp->ring_ctr[i * 32] = 0;
     }
 }
@@ -305,11 +307,15 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restri
 // ---------------------------------------------------------------- knn_brick
 // One wave per brick.  refs/rstart: cell-sorted reference points and cell starts;
 // qpts/qstart: cell-sorted QUERY points (same arrays when every reference is a query).
-template <int KCAP>
+// Work item = (brick, batch of 64 queries).  EXTRA == false: one item per brick, its first batch; any
+// further batch (a brick holding more than 64 queries: ~15-45 % of bricks on uniform data, thousands
+// of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
+// by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
+template <int KCAP, bool EXTRA>
 __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
-    float *__restrict__ mean_out, unsigned *__restrict__ faillist)
+    float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra)
 {
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
     __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
@@ -331,10 +337,16 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
     const int kk = k + 1;
 
     WorkQueue wq;
-    wq_init(wq, gp->brick_ctr, nbricks, BRICK_THREADS / 64);
+    wq_init(wq, EXTRA ? gp->extra_ctr : gp->brick_ctr, EXTRA ? (int)gp->extra_count : nbricks, BRICK_THREADS / 64);
     for (;;) {
-        const int b = uniform(wq_next(wq));
-        if (b < 0) break;
+        const int item = uniform(wq_next(wq));
+        if (item < 0) break;
+        int b = item, qb = 0;
+        if (EXTRA) {
+            const uint2 it = extra[item];
+            b = uniform((int)it.x);
+            qb = uniform((int)it.y);
+        }
         const int bz = b / (nbx * nby);
         const int brem = b - bz * nbx * nby;
         const int by = brem / nbx;
@@ -363,8 +375,22 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) qoff[r + 1] = qoff[r] + __builtin_amdgcn_readlane(v_len, 16 + r);
         const int nq = qoff[4];
+        // A wave loops over up to LOCAL_BATCHES batches of its brick itself (the neighbourhood is hot in
+        // the scalar cache / L2 then); the batches beyond that -- a brick inside a dense cluster can
+        // hold thousands -- become items of the second launch.
+        constexpr int LOCAL_MAX = 3;
+        const int LOCAL_BATCHES = nq > 64 * LOCAL_MAX ? 1 : LOCAL_MAX;  // heavy brick: keep one, spread the rest
+        if (!EXTRA && nq > 64 * LOCAL_BATCHES) {
+            const int nextra = (nq - 1) / 64 + 1 - LOCAL_BATCHES;
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(&gp->extra_count, (unsigned)nextra);
+            slot = (unsigned)uniform((int)slot);
+            for (int e = lane; e < nextra; e += 64)
+                extra[slot + e] = make_uint2((unsigned)b, (unsigned)(64 * (e + LOCAL_BATCHES)));
+        }
+        const int qb_end = EXTRA ? min(nq, qb + 64) : min(nq, 64 * LOCAL_BATCHES);
 
-        for (int qb = 0; qb < nq; qb += 64) {
+        for (; qb < qb_end; qb += 64) {
             // ---- this lane's query
             const int f = qb + lane;
             const bool live = f < nq;
@@ -628,12 +654,14 @@ static int grid_blocks(const gsx_ctx *ctx, int64_t n, int per_thread = 1)
 template <int KCAP>
 static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, const unsigned *rstart,
                              const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
-                             float *mean_out, unsigned *faillist)
+                             float *mean_out, unsigned *faillist, uint2 *extra)
 {
     const int wgs = ctx->num_cu * 5;  // persistent: 20 waves per CU (5 per SIMD) pull bricks from the per-XCD queues
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
-                       qpts, qstart, k, (int)q_begin, mean_out, faillist);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+                       qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+                       qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
@@ -687,6 +715,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_CHECK(ctx->gridparams.reserve(sizeof(GridParams)));
     GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 6 * (size_t)bbox_blocks));
     GSX_CHECK(ctx->faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
+    GSX_CHECK(ctx->extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
     if (!all) {
         GSX_CHECK(ctx->qsorted.reserve(sizeof(float4) * (size_t)q_count));
         GSX_CHECK(ctx->qrank.reserve(sizeof(unsigned) * (size_t)q_count));
@@ -717,11 +746,15 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
     unsigned *fl = ctx->faillist.as<unsigned>();
+    uint2 *ex = ctx->extraitems.as<uint2>();
     int rc;
-    if (kk <= 9) rc = launch_brick_ring<9>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
-    else if (kk <= 17) rc = launch_brick_ring<17>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
-    else if (kk <= 33) rc = launch_brick_ring<33>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
-    else rc = launch_brick_ring<65>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl);
+    // list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
+    if (kk <= 9) rc = launch_brick_ring<9>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 17) rc = launch_brick_ring<17>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 26) rc = launch_brick_ring<26>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 33) rc = launch_brick_ring<33>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 51) rc = launch_brick_ring<51>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else rc = launch_brick_ring<65>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
     GSX_CHECK(rc);
 
     if (info) {

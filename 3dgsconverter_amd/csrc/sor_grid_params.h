@@ -17,12 +17,14 @@ struct GridParams {
     // zeroed by grid_params_kernel every call
     unsigned fail_count;
     unsigned exhaustive_count;
-    unsigned pad_[2];
+    unsigned extra_count;   // (brick, batch >= 1) work items appended by the first knn_brick pass
+    unsigned pad_;
     // work queues: one counter per XCD, 128 B apart.  A single device-wide counter saturates at
     // ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"), which throttled knn_brick at
     // 10M splats (185k bricks); 8 counters on 8 cache lines/channels scale that 8x and keep a
     // contiguous brick range -- hence its L2 working set -- on one XCD.
     unsigned brick_ctr[8 * 32];
+    unsigned extra_ctr[8 * 32];
     unsigned ring_ctr[8 * 32];
 };
 

@@ -69,6 +69,10 @@ def main():
     run(ctx, x1, 32, 2, 10.0, label="grid 1M k32 m10")
     run(ctx, uniform(100_000, 10.0), 16, 1, None, label="brute 100k")
     host_level(x1, 16, "host 1M")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import datasets
+    run(ctx, datasets.clustered(200_000, 1), 16, 2, 0.0, reps=1, label="clustered 200k")
+    run(ctx, datasets.clustered(1_000_000, 1), 16, 2, 0.0, reps=1, label="clustered 1M")
     if not quick:
         run(ctx, x1, 16, 1, None, reps=1, label="brute 1M")
         x10 = uniform(10_000_000, 5.0)
