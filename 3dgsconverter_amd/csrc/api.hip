@@ -347,10 +347,15 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     if (mean_out) GSX_HIP(hipMemcpyAsync(mean_out, dmd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));
+    const int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
+    if (used == GSX_KNN_GRID) {
+        GridParams hgp;
+        GSX_HIP(hipMemcpy(&hgp, c->gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
+        if (hgp.bad_input) GSX_FAIL("gsx_sor_filter: coordinates are not finite (NaN/inf)");
+    }
     if (info) {
         // re-query diagnostics without recomputing: only the grid path has device-side counters
         memset(info, 0, sizeof(*info));
-        int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
         info->algo = used;
         if (used == GSX_KNN_GRID) {
             GridParams hgp;

@@ -60,15 +60,17 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
                                                            const float *__restrict__ z, int64_t stride, int n,
                                                            float *__restrict__ part)
 {
-    __shared__ float red[6][4];
+    __shared__ float red[7][4];
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float bad = 0.0f;  // fminf/fmaxf drop NaNs silently, so non-finite input is tracked separately
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float v[3] = {x[(int64_t)i * stride], y[(int64_t)i * stride], z[(int64_t)i * stride]};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             mn[a] = fminf(mn[a], v[a]);
             mx[a] = fmaxf(mx[a], v[a]);
+            bad = (fabsf(v[a]) < __builtin_inff()) ? bad : 1.0f;
         }
     }
 #pragma unroll
@@ -78,6 +80,8 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad = fmaxf(bad, __shfl_xor(bad, off));
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -85,12 +89,13 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
             red[a][w] = mn[a];
             red[3 + a][w] = mx[a];
         }
+        red[6][w] = bad;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         float v = red[threadIdx.x][0];
         for (int i = 1; i < 4; ++i) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][i]) : fmaxf(v, red[threadIdx.x][i]);
-        part[blockIdx.x * 6 + threadIdx.x] = v;
+        part[blockIdx.x * 7 + threadIdx.x] = v;
     }
 }
 
@@ -99,11 +104,11 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
                                                          GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
-    float v[6];
+    float v[7];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int a = 0; a < 7; ++a) {
         float acc = a < 3 ? __builtin_inff() : -__builtin_inff();
-        for (int i = lane; i < nparts; i += 64) acc = a < 3 ? fminf(acc, part[i * 6 + a]) : fmaxf(acc, part[i * 6 + a]);
+        for (int i = lane; i < nparts; i += 64) acc = a < 3 ? fminf(acc, part[i * 7 + a]) : fmaxf(acc, part[i * 7 + a]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             float o = __shfl_xor(acc, off);
@@ -141,7 +146,11 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
         if (ok) break;
         h *= 1.1;
     }
-    if (!(nx > 0 && ny > 0 && nz > 0) || (long long)nx * ny * nz > (long long)cell_cap) {  // NaN / inf input
+    bool bad = v[6] > 0.0f;  // NaN or inf anywhere in the cloud
+    for (int a = 0; a < 6; ++a) bad |= !(fabsf(v[a]) < 3.0e38f);
+    if (bad || !(nx > 0 && ny > 0 && nz > 0) || (long long)nx * ny * nz > (long long)cell_cap) {
+        // no grid can be built; an exhaustive search would be O(N^2): refuse instead (host raises)
+        bad = true;
         nx = ny = nz = 1;
         inv_h = 0.0f;
     }
@@ -159,7 +168,8 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     if (pts_per_cell * 2.0 > 66.0) bdx = 1;
     gp->bdx = bdx; gp->bdy = bdy; gp->bdz = bdz;
     gp->nbx = (nx + bdx - 1) / bdx; gp->nby = (ny + bdy - 1) / bdy; gp->nbz = (nz + bdz - 1) / bdz;
-    gp->nbricks = gp->nbx * gp->nby * gp->nbz;
+    gp->nbricks = bad ? 0 : gp->nbx * gp->nby * gp->nbz;
+    gp->bad_input = bad ? 1u : 0u;
     // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
     // f32 cell index floor(fl(fl(x-o)*inv_h)) is monotone and off by < dim*2^-22 <= 2.5e-4 cells.
     double hp = inv_h > 0.0f ? 1.0 / (double)inv_h : 0.0;
@@ -713,7 +723,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_CHECK(ctx->cellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
     GSX_CHECK(ctx->scanpart.reserve(sizeof(unsigned) * (size_t)nparts));
     GSX_CHECK(ctx->gridparams.reserve(sizeof(GridParams)));
-    GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 6 * (size_t)bbox_blocks));
+    GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     GSX_CHECK(ctx->faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
     GSX_CHECK(ctx->extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
     if (!all) {
@@ -761,6 +771,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
         GridParams hgp;
         GSX_HIP(hipMemcpyAsync(&hgp, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (hgp.bad_input) GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
         info->algo = GSX_KNN_GRID;
         info->grid_dim[0] = hgp.nx; info->grid_dim[1] = hgp.ny; info->grid_dim[2] = hgp.nz;
         info->cell_size = hgp.h;

@@ -18,7 +18,7 @@ struct GridParams {
     unsigned fail_count;
     unsigned exhaustive_count;
     unsigned extra_count;   // (brick, batch >= 1) work items appended by the first knn_brick pass
-    unsigned pad_;
+    unsigned bad_input;     // 1: non-finite coordinates -- the KNN kernels do nothing, the host reports an error
     // work queues: one counter per XCD, 128 B apart.  A single device-wide counter saturates at
     // ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"), which throttled knn_brick at
     // 10M splats (185k bricks); 8 counters on 8 cache lines/channels scale that 8x and keep a

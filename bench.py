@@ -116,7 +116,7 @@ def main():
 
     # ---- roofline of the dominant kernel (knn_brick, or knn_brute with --algo 1)
     knn_ms = ms_knn / max(n_knn, 1)
-    if info is not None and info["algo"] == 2:
+    if args.algo != 1:
         # algorithmic bytes of ONE knn_brick launch: every brick streams its
         # 4x4x4-cell neighbourhood once (16 B/point, = 8x its own 2x2x2 cells on average), every
         # query reads its own point (16 B) and writes one f32: (8*16 + 16 + 4) B per splat.

@@ -166,3 +166,35 @@ def test_drop_in_dataprocessor(gsx, golden_cases, golden_arrays):
     np.testing.assert_array_equal(mask2, mask)
     with pytest.raises(ValueError):
         gsx.gpu_ops.filter_sor_gpu(np.zeros((10, 2), np.float32))
+
+
+def test_non_finite_coordinates_fail_loudly(gsx, lib):
+    xyz = datasets.uniform(5000, 10.0, 3)
+    xyz[17, 1] = np.nan
+    with pytest.raises(gsx.GsxError, match="finite"):
+        lib.sor_filter(xyz, 16, 1.0, algo=GRID)
+    xyz[17, 1] = np.inf
+    with pytest.raises(gsx.GsxError, match="finite"):
+        lib.sor_filter(xyz, 16, 1.0, algo=GRID)
+
+
+def test_clustered_cloud_with_heavy_cells(lib):
+    """very uneven density: most points sit in a handful of grid cells (bricks with thousands of
+    query batches go through the second knn_brick launch)"""
+    xyz = datasets.clustered(120000, seed=11)
+    ref = osor.mean_dists_ckdtree(xyz, 16)
+    res = lib.sor_filter(xyz, 16, 2.0, algo=GRID, want_info=True)
+    assert _explain(res["mean_dists"], ref) == "ok", res["info"]
+
+
+def test_degenerate_geometries(lib):
+    rng = np.random.default_rng(5)
+    n = 20000
+    flat = np.stack([rng.random(n) * 10, rng.random(n) * 10, np.full(n, 3.0)], 1).astype(np.float32)   # plane
+    line = np.stack([rng.random(n) * 10, np.full(n, 1.0), np.full(n, -2.0)], 1).astype(np.float32)     # line
+    same = np.tile(np.array([[1.5, 2.5, 3.5]], np.float32), (3000, 1))                                  # one point
+    for name, xyz in (("plane", flat), ("line", line), ("identical", same)):
+        ref = osor.mean_dists_ckdtree(xyz, 16)
+        for algo in (BRUTE, GRID):
+            res = lib.sor_filter(xyz, 16, 1.0, algo=algo, want_info=True)
+            assert _explain(res["mean_dists"], ref) == "ok", (name, algo, res["info"])
