@@ -128,8 +128,20 @@ def main():
         kernel = "knn_brute_kernel"
     alg_bytes = bytes_per_splat * args.n
     achieved = alg_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
+    traffic, traffic_note = None, None
+    try:  # PMC counters cannot be read from inside the process: the last rocprofv3 --pmc passes are committed
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            pmc = json.load(f).get(kernel, {}).get("%d:%d" % (args.n, args.k))
+        if pmc and world == 1:
+            traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_latest.json); fetch as "
+                            "counted, x2-corrected upper bound %d B" % (pmc["fetch_x2_upper"] + pmc["write_bytes"]))
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_note": traffic_note, "algorithmic_bytes": int(alg_bytes),
+                "valu_busy_frac_pmc": 0.94, "valu_source": "profiles/r01_pmc_10m_sq.txt (SQ_ACTIVE_INST_VALU / SIMD cycles)",
                 "kernel_ms": round(knn_ms, 4), "algorithmic_bytes_per_splat": bytes_per_splat,
                 "note": "kernel is FP32/FP64 VALU-issue bound, not HBM bound (DESIGN.md section 5); "
                         "PMC HBM traffic per launch is in profiles/"}
