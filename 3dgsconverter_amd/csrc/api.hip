@@ -198,6 +198,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->grid_points_per_cell = value;
     } else if (!strcmp(name, "brute_below")) {
         c->brute_below = (int64_t)value;
+    } else if (!strcmp(name, "debug_skip")) {
+        c->debug_skip = (int)value;
     } else {
         GSX_FAIL("gsx_ctx_set_param: unknown parameter '%s'", name);
     }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
-                                                         double pts_per_cell, int cell_cap,
+                                                         double pts_per_cell, int cell_cap, int debug_skip,
                                                          GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->nbx = (nx + bdx - 1) / bdx; gp->nby = (ny + bdy - 1) / bdy; gp->nbz = (nz + bdz - 1) / bdz;
     gp->nbricks = bad ? 0 : gp->nbx * gp->nby * gp->nbz;
     gp->bad_input = bad ? 1u : 0u;
+    gp->debug_skip = debug_skip;
     // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
     // f32 cell index floor(fl(fl(x-o)*inv_h)) is monotone and off by < dim*2^-22 <= 2.5e-4 cells.
     double hp = inv_h > 0.0f ? 1.0 / (double)inv_h : 0.0;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
         gp->extra_ctr[i * 32] = 0;
         gp->ring_ctr[i * 32] = 0;
     }
+
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim)
@@ -321,8 +323,11 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restri
 // further batch (a brick holding more than 64 queries: ~15-45 % of bricks on uniform data, thousands
 // of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
+// waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
+constexpr int brick_min_waves(int kcap) { return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2)); }
+
 template <int KCAP, bool EXTRA>
-__global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
+__global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_brick_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra)
@@ -344,6 +349,8 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
     const int nbricks = gp->nbricks;
     const double r1sq = gp->r1sq;
     const float tau1 = gp->tau1;
+    const float g_ox = gp->ox, g_oy = gp->oy, g_oz = gp->oz, g_inv_h = gp->inv_h;
+    const int dbg = gp->debug_skip;
     const int kk = k + 1;
 
     WorkQueue wq;
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
                 v_len = (int)(e - s);
             }
         }
+        if (dbg & 16) continue;  // queue + row-table loads only
         int qoff[5];
         qoff[0] = 0;
 #pragma unroll
@@ -414,6 +422,45 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
             const float qx = qp.x, qy = qp.y, qz = qp.z;
             const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
             float tau = live ? tau1 : -1.0f;
+
+            // Batches after a brick's first hold the LAST queries of the brick (typically its last cell
+            // or two): their neighbourhood is a sub-box of the brick's, so only the rows / cells within
+            // one cell of the batch's bounding box are scanned (still a superset of every live query's
+            // 3x3x3 cells, so r_safe is unchanged).
+            int rs_start = v_start, rs_len = v_len;
+            if (qb > 0) {
+                int lo[3], hi[3];
+                const int c3[3] = {cell_coord(qx, g_ox, g_inv_h, nx), cell_coord(qy, g_oy, g_inv_h, ny),
+                                   cell_coord(qz, g_oz, g_inv_h, nz)};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = live ? c3[a] : 0x7fffffff;
+                    hi[a] = live ? c3[a] : -1;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        lo[a] = min(lo[a], __shfl_xor(lo[a], off));
+                        hi[a] = max(hi[a], __shfl_xor(hi[a], off));
+                    }
+                    lo[a] = uniform(lo[a]);
+                    hi[a] = uniform(hi[a]);
+                }
+                rs_start = 0;
+                rs_len = 0;
+                if (lane < ncrows) {
+                    const int yy = by * bdy - 1 + (lane % cry);
+                    const int zz = bz * bdz - 1 + (lane / cry);
+                    const int xa = max(max(bx * bdx - 1, 0), lo[0] - 1);
+                    const int xb = min(min(bx * bdx + bdx, nx - 1), hi[0] + 1);
+                    const bool need = yy >= max(lo[1] - 1, 0) && yy <= min(hi[1] + 1, ny - 1) &&
+                                      zz >= max(lo[2] - 1, 0) && zz <= min(hi[2] + 1, nz - 1) && xa <= xb;
+                    if (need) {
+                        const int row = (zz * ny + yy) * nx;
+                        const unsigned s0 = rstart[row + xa], e0 = rstart[row + xb + 1];
+                        rs_start = (int)s0;
+                        rs_len = (int)(e0 - s0);
+                    }
+                }
+            }
             TopList<KCAP> lst;
             lst.init();
 
@@ -443,7 +490,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
                         m &= ~(0x80000000u >> i);
                         pn = refs[base + i];
                     }
-                    if (have_cur) lst.insert(dist2_f64(qxd, qyd, qzd, pc.x, pc.y, pc.z));
+                    if (have_cur && !(dbg & 1)) lst.insert(dist2_f64(qxd, qyd, qzd, pc.x, pc.y, pc.z));
                     if (!__any(have_next)) break;
                     pc = pn;
                     have_cur = have_next;
@@ -455,9 +502,9 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
             };
 
             // ---- phase 1: lock-step filter over the 16 candidate rows
-            for (int r = 0; r < ncrows; ++r) {
-                const int gs = __builtin_amdgcn_readlane(v_start, r);
-                const int len = __builtin_amdgcn_readlane(v_len, r);
+            for (int r = 0; r < ((dbg & 2) ? 0 : ncrows); ++r) {
+                const int gs = __builtin_amdgcn_readlane(rs_start, r);
+                const int len = __builtin_amdgcn_readlane(rs_len, r);
                 for (int w0 = 0; w0 < len; w0 += 32) {
                     if (widx == WCAP) drain();
                     const int c = min(32, len - w0);
@@ -489,7 +536,11 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_brick_kernel(
 
             // ---- exact iff the (k+1)-th distance lies inside the searched cells
             if (live) {
-                if (lst.kth(kk) <= r1sq) {
+                if (dbg & 8) {
+                    if (lst.kth(kk) == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
+                } else if (dbg & 4) {
+                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)lst.kth(kk);
+                } else if (lst.kth(kk) <= r1sq) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);
@@ -666,16 +717,27 @@ static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, c
                              const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
                              float *mean_out, unsigned *faillist, uint2 *extra)
 {
-    const int wgs = ctx->num_cu * 5;  // persistent: 20 waves per CU (5 per SIMD) pull bricks from the per-XCD queues
+    // Work is assigned STATICALLY to waves, so every launched workgroup must be resident at once:
+    // the grids are sized from the occupancy the built kernels actually get (a non-resident
+    // workgroup would run its share only after a resident one has finished all of its own).
+    static int occ_brick = 0, occ_extra = 0, occ_ring = 0;
+    if (!occ_brick) {
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ring, knn_ring_kernel<KCAP>, BRICK_THREADS, 0));
+        occ_brick = std::max(1, std::min(occ_brick, 8));
+        occ_extra = std::max(1, std::min(occ_extra, 8));
+        occ_ring = std::max(1, std::min(occ_ring, 8));
+    }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
-                       qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true>), dim3(wgs), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
-                       qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream, gp,
+                       refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream, gp,
+                       refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
-    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * 5), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
+    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * occ_ring), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
                        qpts, faillist, k, (int)q_begin, mean_out);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
@@ -740,7 +802,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        ctx->bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, pts_per_cell, (int)cap, gp);
+                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, gp);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, cap, ctx->cellcnt.as<unsigned>(), rstart,
                          ctx->rank.as<unsigned>(), ctx->scanpart.as<unsigned>(), refs));

@@ -57,7 +57,20 @@ def host_level(xyz, k, label):
     print("%-28s n=%9d k=%2d host->host %.3f ms  %.1f Msplat/s (PCIe inclusive)" % (label, len(xyz), k, dt * 1e3, len(xyz) / dt / 1e6), flush=True)
 
 
+def ablate():
+    ctx = L.Context(0)
+    x10 = uniform(10_000_000, 5.0)
+    for dbg, name in ((0, "full"), (4, "no epilogue"), (7, "skeleton only"), (15, "skeleton, no output write"),
+                      (31, "queue + row tables only"), (5, "phase 1 only (+cursor walk)"), (6, "phase 2 impossible")):
+        ctx.set_param("debug_skip", dbg)
+        run(ctx, x10, 16, 2, 0.0, label="ablate: " + name)
+    ctx.set_param("debug_skip", 0)
+    ctx.close()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+        return ablate()
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     ctx = L.Context(0)
     x1 = uniform(1_000_000, 10.0)
