@@ -775,10 +775,15 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
     // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts
-    // ~2 (k+1) points inside h (measured optimum at k = 8, 16, 32: profiles/r01_probe_*.log).
-    const double pts_per_cell = ctx->grid_points_per_cell > 0.0 ? ctx->grid_points_per_cell
-                                                                 : std::max(2.0, 0.47 * (double)(k + 1));
-
+    // ~2 (k+1) points inside h (measured optimum at k = 8, 16, 25, 32: profiles/r01_sweep_m.log).
+    // A brick's population cells*m should stay <= ~58 so that its queries fit ONE 64-lane batch
+    // (at 64 on average 47 % of the bricks need a second one): k = 16 -> m = 7.25, not 8.
+    double pts_per_cell = ctx->grid_points_per_cell;
+    if (!(pts_per_cell > 0.0)) {
+        pts_per_cell = std::max(2.0, 0.47 * (double)(k + 1));
+        for (int cells = 8; cells >= 1; cells /= 2)
+            if (pts_per_cell * cells > 58.0 && pts_per_cell * cells <= 66.0) pts_per_cell = 58.0 / cells;
+    }
     GSX_CHECK(ctx->packed.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(ctx->rank.reserve(sizeof(unsigned) * (size_t)n_ref));
     GSX_CHECK(ctx->cellcnt.reserve(sizeof(unsigned) * (size_t)(cap + 1)));

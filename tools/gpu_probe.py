@@ -68,9 +68,26 @@ def ablate():
     ctx.close()
 
 
+def sweep():
+    ctx = L.Context(0)
+    x1 = uniform(1_000_000, 10.0)
+    x10 = uniform(10_000_000, 5.0)
+    for m in (6.5, 7.0, 7.25, 7.5, 7.75, 8.0):
+        run(ctx, x1, 16, 2, m, reps=5, label="sweep 1M")
+    for m in (6.5, 7.0, 7.25, 7.5, 7.75, 8.0):
+        run(ctx, x10, 16, 2, m, label="sweep 10M")
+    for m in (10.0, 11.0, 12.2, 13.5):
+        run(ctx, x1, 25, 2, m, reps=5, label="sweep 1M k25")
+    for m in (3.5, 4.2, 5.0):
+        run(ctx, x1, 8, 2, m, reps=5, label="sweep 1M k8")
+    ctx.close()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         return ablate()
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        return sweep()
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     ctx = L.Context(0)
     x1 = uniform(1_000_000, 10.0)
