@@ -139,8 +139,8 @@ void gsx_ctx_destroy(gsx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->slots)
         for (auto e : s.ev) (void)hipEventDestroy(e);
-    gsx::DevBuf *bufs[] = {&c->packed, &c->qsorted, &c->rank, &c->cellcnt, &c->cellstart, &c->qcellcnt,
-                           &c->qcellstart, &c->qrank, &c->scanpart, &c->gridparams, &c->bboxpart, &c->faillist, &c->extraitems,
+    gsx::DevBuf *bufs[] = {&c->packed, &c->qsorted, &c->bucketpts, &c->bkcnt, &c->cellstart,
+                           &c->qcellstart, &c->gridparams, &c->bboxpart, &c->faillist, &c->extraitems,
                            &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
     delete c;

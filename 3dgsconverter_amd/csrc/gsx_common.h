@@ -75,11 +75,10 @@ struct gsx_ctx {
     // SOR workspace
     gsx::DevBuf packed;      // float4[n_ref]  (brute: original order; grid: cell-sorted refs)
     gsx::DevBuf qsorted;     // float4[q_count] cell-sorted queries when q != all refs
-    gsx::DevBuf rank;        // u32[n_ref] rank of a point inside its cell
-    gsx::DevBuf cellcnt;     // u32[cap+1]
+    gsx::DevBuf bucketpts;   // float4[n_ref] points grouped by bucket (between the two sort levels)
+    gsx::DevBuf bkcnt;       // u32 bucket sizes | starts | cursors
     gsx::DevBuf cellstart;   // u32[cap+1]
-    gsx::DevBuf qcellcnt, qcellstart, qrank;
-    gsx::DevBuf scanpart;    // u32 block partials
+    gsx::DevBuf qcellstart;
     gsx::DevBuf gridparams;  // GridParams + work counters
     gsx::DevBuf bboxpart;    // float[6 * blocks]
     gsx::DevBuf faillist;    // u32[q_count]

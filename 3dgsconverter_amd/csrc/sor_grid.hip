@@ -7,9 +7,9 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   bbox_partial -> grid_params            per-axis min/max, cell edge h for ~m pts/cell
-//   cell_count                             cell id per point, atomic histogram, rank in cell
-//   scan_partials / scan_top / scan_apply  exclusive scan -> cell_start
-//   cell_scatter                           counting sort into float4 {x,y,z,orig} (x-fastest cells)
+//   bucket_hist / bucket_scan / bucket_scatter / bucket_sort
+//                                          two-level counting sort into float4 {x,y,z,orig}: every
+//                                          per-point atomic is an LDS atomic (see the kernels)
 //   knn_brick                              one WAVE per 2x2x2-cell brick (~56 queries)
 //   knn_ring                               expanding-ring exact fallback for the few queries
 //                                          whose (k+1)-th neighbour is farther than one cell
@@ -31,7 +31,10 @@ namespace gsx {
 
 
 constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index rounding bound, see r_safe)
-constexpr int SCAN_BLOCK = 2048;    // elements per scan block (256 threads x 8)
+constexpr int MAX_BUCKETS = 4096;         // LDS histogram bins of the coarse pass
+constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 KiB)
+constexpr int BUCKET_POINTS = 4096;       // target points per bucket
+constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
 
@@ -134,6 +137,8 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
         if (!(h > hmin)) h = hmin;
     }
     int nx, ny, nz;
+    int bg = 1, bny = 1, bnz = 1;
+    long long padded = 0;
     float inv_h;
     for (int it = 0; it < 256; ++it) {
         inv_h = (float)(1.0 / h);
@@ -141,24 +146,44 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
         nx = (int)((v[3] - v[0]) * inv_h) + 1;
         ny = (int)((v[4] - v[1]) * inv_h) + 1;
         nz = (int)((v[5] - v[2]) * inv_h) + 1;
-        bool ok = nx <= MAX_DIM && ny <= MAX_DIM && nz <= MAX_DIM && nx > 0 && ny > 0 && nz > 0 &&
-                  (long long)nx * ny * nz <= (long long)cell_cap;
+        bool ok = nx <= MAX_DIM && ny <= MAX_DIM && nz <= MAX_DIM && nx > 0 && ny > 0 && nz > 0;
+        if (ok) {
+            // bucket = bg x bg x-rows, ~BUCKET_POINTS points; at most MAX_BUCKETS buckets, MAX_BUCKET_CELLS cells each
+            double per_row = (double)nx * pts_per_cell;
+            bg = (int)(sqrt((double)BUCKET_POINTS / (per_row > 1.0 ? per_row : 1.0)) + 0.5);
+            if (bg < 1) bg = 1;
+            if (bg > (ny > nz ? ny : nz)) bg = ny > nz ? ny : nz;  // never wider than the grid itself
+            while (bg > 1 && (long long)bg * bg * nx > MAX_BUCKET_CELLS) --bg;
+            for (;;) {
+                bny = (ny + bg - 1) / bg;
+                bnz = (nz + bg - 1) / bg;
+                if ((long long)bny * bnz <= MAX_BUCKETS) break;
+                ++bg;
+            }
+            padded = (long long)bny * bnz * bg * bg * nx;
+            ok = (long long)bg * bg * nx <= MAX_BUCKET_CELLS && padded <= (long long)cell_cap;
+        }
         if (ok) break;
         h *= 1.1;
     }
     bool bad = v[6] > 0.0f;  // NaN or inf anywhere in the cloud
     for (int a = 0; a < 6; ++a) bad |= !(fabsf(v[a]) < 3.0e38f);
-    if (bad || !(nx > 0 && ny > 0 && nz > 0) || (long long)nx * ny * nz > (long long)cell_cap) {
+    if (bad || !(nx > 0 && ny > 0 && nz > 0) || padded <= 0 || padded > (long long)cell_cap ||
+        (long long)bg * bg * nx > MAX_BUCKET_CELLS) {
         // no grid can be built; an exhaustive search would be O(N^2): refuse instead (host raises)
         bad = true;
         nx = ny = nz = 1;
+        bg = bny = bnz = 1;
         inv_h = 0.0f;
     }
     gp->ox = v[0]; gp->oy = v[1]; gp->oz = v[2];
     gp->inv_h = inv_h;
     gp->h = (float)h;
     gp->nx = nx; gp->ny = ny; gp->nz = nz;
-    gp->ncells = nx * ny * nz;
+    gp->bk_g = bg; gp->bk_ny = bny; gp->bk_nz = bnz;
+    gp->bk_count = bny * bnz;
+    gp->bk_cells = bg * bg * nx;
+    gp->ncells = gp->bk_count * gp->bk_cells;
     // brick = the cells one wave owns.  Its ~pts_per_cell * cells queries should fill 64 lanes in ONE
     // batch (a second batch repeats the whole neighbourhood scan): 2x2x2 cells up to ~8 pts/cell
     // (k <= 16), then 2x2x1, 2x1x1, 1x1x1 as k -- hence the cell population -- grows.
@@ -195,31 +220,66 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim
     return min(max(c, 0), dim - 1);
 }
 
-__device__ __forceinline__ int cell_of(const GridParams &g, float x, float y, float z)
+// Cell index space is BUCKET-MAJOR: all cells of bucket (by, bz) are contiguous, inside a bucket the
+// x-rows follow each other, inside a row the cells run along x.  Every x-row of cells is therefore
+// still one contiguous range of the sorted array (what knn_brick / knn_ring walk), and a bucket's
+// cells can be laid out by the workgroup that sorts the bucket without any global scan.
+__device__ __forceinline__ int row_base(const GridParams &g, int cy, int cz)
 {
-    int cx = cell_coord(x, g.ox, g.inv_h, g.nx);
-    int cy = cell_coord(y, g.oy, g.inv_h, g.ny);
-    int cz = cell_coord(z, g.oz, g.inv_h, g.nz);
-    return (cz * g.ny + cy) * g.nx + cx;
+    const int by = cy / g.bk_g, bz = cz / g.bk_g;
+    return (bz * g.bk_ny + by) * g.bk_cells + ((cz - bz * g.bk_g) * g.bk_g + (cy - by * g.bk_g)) * g.nx;
 }
 
-// ---------------------------------------------------------------- counting sort by cell
-__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned *__restrict__ p, const GridParams *__restrict__ gp)
+__device__ __forceinline__ int bucket_of(const GridParams &g, int cy, int cz)
 {
-    const int n = gp->ncells + 1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+    return (cz / g.bk_g) * g.bk_ny + cy / g.bk_g;
 }
 
-__global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                         const float *__restrict__ z, int64_t stride, int first, int n,
-                                                         const GridParams *__restrict__ gp, unsigned *__restrict__ cnt,
-                                                         unsigned *__restrict__ rank)
+// ---------------------------------------------------------------- two-level counting sort by cell
+// The points arrive in arbitrary order.  A one-level counting sort needs one returning device-scope
+// atomic and one random 16-byte write per point (measured 0.69 ms per 10M points: the L2 atomic
+// units, not HBM, are the limit).  Two levels keep every per-point atomic in LDS:
+//   A1 bucket_hist    tile of 16k points -> LDS histogram over <= 4096 buckets -> one global
+//                     atomic per (tile, non-empty bucket)
+//   A0 bucket_scan    exclusive scan of the bucket sizes (one workgroup)
+//   A2 bucket_scatter same tiles: reserve a run per (tile, bucket) with ONE returning atomic, rank
+//                     inside the run with LDS atomics, write float4 {x,y,z,orig} runs
+//   B  bucket_sort    one workgroup per bucket: LDS histogram over the bucket's cells, LDS scan ->
+//                     cell_start (bucket base + local prefix, no global scan), LDS cursors -> final
+//                     position; reads are contiguous, writes stay inside the bucket's ~64 KiB window.
+__global__ __launch_bounds__(256) void bucket_hist_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, int64_t stride, int first, int n,
+                                                          const GridParams *__restrict__ gp,
+                                                          unsigned *__restrict__ bk_cnt)
 {
+    __shared__ unsigned hist[MAX_BUCKETS];
     const GridParams g = *gp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int64_t s = (int64_t)(first + i) * stride;
-        int c = cell_of(g, x[s], y[s], z[s]);
-        rank[i] = atomicAdd(&cnt[c], 1u);
+    if (g.bad_input) return;
+    const int ntiles = (n + BIN_TILE - 1) / BIN_TILE;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        for (int i = threadIdx.x; i < g.bk_count; i += 256) hist[i] = 0;
+        __syncthreads();
+        const int lo = t * BIN_TILE, hi = min(n, lo + BIN_TILE);
+        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {   // 4 independent loads in flight per lane
+            float py[4], pz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, hi - 1);
+                const int64_t s = (int64_t)(first + i) * stride;
+                py[u] = y[s];
+                pz[u] = z[s];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 256 * u < hi)
+                    atomicAdd(&hist[bucket_of(g, cell_coord(py[u], g.oy, g.inv_h, g.ny), cell_coord(pz[u], g.oz, g.inv_h, g.nz))], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.bk_count; i += 256) {
+            const unsigned c = hist[i];
+            if (c) atomicAdd(&bk_cnt[i], c);
+        }
+        __syncthreads();
     }
 }
 
@@ -247,72 +307,144 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigne
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void scan_partials_kernel(const unsigned *__restrict__ cnt,
-                                                            const GridParams *__restrict__ gp,
-                                                            unsigned *__restrict__ part)
+// bk_start[0..bk_count] = exclusive scan of bk_cnt; bk_cursor = copy of bk_start; bk_cnt re-zeroed for the next call
+__global__ __launch_bounds__(256) void bucket_scan_kernel(const GridParams *__restrict__ gp, unsigned *__restrict__ bk_cnt,
+                                                          unsigned *__restrict__ bk_start, unsigned *__restrict__ bk_cursor)
 {
     __shared__ unsigned wsum[4];
-    const int n = gp->ncells;
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 8;
-    unsigned s = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += (base + j < n) ? cnt[base + j] : 0u;
-    unsigned tot;
-    (void)block_exclusive_scan_256(s, &tot, wsum);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void scan_top_kernel(unsigned *__restrict__ part, int nparts)
-{
-    __shared__ unsigned wsum[4];
+    const int nb = gp->bk_count;
     unsigned carry = 0;
-    for (int b = 0; b < nparts; b += 256) {
-        int i = b + threadIdx.x;
-        unsigned v = i < nparts ? part[i] : 0u;
+    for (int b = 0; b < nb; b += 256) {
+        const int i = b + threadIdx.x;
+        const unsigned v = i < nb ? bk_cnt[i] : 0u;
         unsigned tot;
-        unsigned ex = block_exclusive_scan_256(v, &tot, wsum);
-        if (i < nparts) part[i] = carry + ex;
+        const unsigned ex = block_exclusive_scan_256(v, &tot, wsum);
+        if (i < nb) {
+            bk_start[i] = carry + ex;
+            bk_cursor[i] = carry + ex;
+            bk_cnt[i] = 0;
+        }
         carry += tot;
     }
+    if (threadIdx.x == 0) bk_start[nb] = carry;
 }
 
-__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned *__restrict__ cnt,
-                                                         const GridParams *__restrict__ gp,
-                                                         const unsigned *__restrict__ part,
-                                                         unsigned *__restrict__ start)
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, int64_t stride, int first, int n,
+                                                             const GridParams *__restrict__ gp,
+                                                             unsigned *__restrict__ bk_cursor, float4 *__restrict__ out)
 {
-    __shared__ unsigned wsum[4];
-    const int n = gp->ncells;
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 8;
-    if (blockIdx.x * SCAN_BLOCK > n) return;  // uniform per block
-    unsigned v[8], s = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        v[j] = (base + j < n) ? cnt[base + j] : 0u;
-        s += v[j];
-    }
-    unsigned tot;
-    unsigned ex = block_exclusive_scan_256(s, &tot, wsum) + part[blockIdx.x];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (base + j <= n) start[base + j] = ex;  // start[n] = total
-        ex += v[j];
-    }
-}
-
-__global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                           const float *__restrict__ z, int64_t stride, int first, int n,
-                                                           const GridParams *__restrict__ gp,
-                                                           const unsigned *__restrict__ start,
-                                                           const unsigned *__restrict__ rank, float4 *__restrict__ out)
-{
+    __shared__ unsigned hist[MAX_BUCKETS];   // per-bucket count of this tile, then the running rank
+    __shared__ unsigned base[MAX_BUCKETS];   // start of this tile's run inside the bucket's region
     const GridParams g = *gp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int64_t s = (int64_t)(first + i) * stride;
-        float px = x[s], py = y[s], pz = z[s];
-        int c = cell_of(g, px, py, pz);
-        unsigned dst = start[c] + rank[i];
-        out[dst] = make_float4(px, py, pz, __uint_as_float((unsigned)(first + i)));
+    if (g.bad_input) return;
+    const int ntiles = (n + BIN_TILE - 1) / BIN_TILE;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        for (int i = threadIdx.x; i < g.bk_count; i += 256) hist[i] = 0;
+        __syncthreads();
+        const int lo = t * BIN_TILE, hi = min(n, lo + BIN_TILE);
+        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {
+            float py[4], pz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, hi - 1);
+                const int64_t s = (int64_t)(first + i) * stride;
+                py[u] = y[s];
+                pz[u] = z[s];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 256 * u < hi)
+                    atomicAdd(&hist[bucket_of(g, cell_coord(py[u], g.oy, g.inv_h, g.ny), cell_coord(pz[u], g.oz, g.inv_h, g.nz))], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.bk_count; i += 256) {
+            const unsigned c = hist[i];
+            if (c) base[i] = atomicAdd(&bk_cursor[i], c);
+            hist[i] = 0;
+        }
+        __syncthreads();
+        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {   // second sweep over the (L2-hot) tile
+            float px[4], py[4], pz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, hi - 1);
+                const int64_t s = (int64_t)(first + i) * stride;
+                px[u] = x[s];
+                py[u] = y[s];
+                pz[u] = z[s];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < hi) {
+                    const int b = bucket_of(g, cell_coord(py[u], g.oy, g.inv_h, g.ny), cell_coord(pz[u], g.oz, g.inv_h, g.nz));
+                    const unsigned r = atomicAdd(&hist[b], 1u);
+                    out[base[b] + r] = make_float4(px[u], py[u], pz[u], __uint_as_float((unsigned)(first + i)));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__restrict__ gp,
+                                                          const unsigned *__restrict__ bk_start,
+                                                          const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                          unsigned *__restrict__ cell_start)
+{
+    __shared__ unsigned cnt[MAX_BUCKET_CELLS];
+    __shared__ unsigned wsum[4];
+    const GridParams g = *gp;
+    const int b = blockIdx.x;
+    if (g.bad_input || b >= g.bk_count) return;
+    const int cells = g.bk_cells;
+    const unsigned s0 = bk_start[b], s1 = bk_start[b + 1];
+    const int by = b % g.bk_ny, bz = b / g.bk_ny;
+    for (int i = threadIdx.x; i < cells; i += 256) cnt[i] = 0;
+    __syncthreads();
+    auto local_cell = [&](const float4 p) {
+        const int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx);
+        const int cy = cell_coord(p.y, g.oy, g.inv_h, g.ny);
+        const int cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
+        return ((cz - bz * g.bk_g) * g.bk_g + (cy - by * g.bk_g)) * g.nx + cx;
+    };
+    for (unsigned i0 = s0 + threadIdx.x; i0 < s1; i0 += 1024) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = in[min(i0 + 256u * u, s1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256u * u < s1) atomicAdd(&cnt[local_cell(p[u])], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the bucket's cells: each thread owns a contiguous segment
+    const int seg = (cells + 255) / 256;
+    const int c0 = min(cells, (int)threadIdx.x * seg), c1 = min(cells, c0 + seg);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cnt[c];
+    unsigned tot;
+    unsigned run = block_exclusive_scan_256(sum, &tot, wsum);
+    for (int c = c0; c < c1; ++c) {
+        const unsigned v = cnt[c];
+        cnt[c] = run;   // becomes the cursor of the cell
+        run += v;
+    }
+    __syncthreads();
+    unsigned *cs = cell_start + (size_t)b * cells;
+    for (int i = threadIdx.x; i < cells; i += 256) cs[i] = s0 + cnt[i];
+    if (b == g.bk_count - 1 && threadIdx.x == 0) cell_start[(size_t)g.bk_count * cells] = s1;
+    __syncthreads();
+    for (unsigned i0 = s0 + threadIdx.x; i0 < s1; i0 += 1024) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = in[min(i0 + 256u * u, s1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256u * u < s1) {
+                const unsigned r = atomicAdd(&cnt[local_cell(p[u])], 1u);
+                out[s0 + r] = p[u];
+            }
     }
 }
 
@@ -350,6 +482,11 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
     const double r1sq = gp->r1sq;
     const float tau1 = gp->tau1;
     const float g_ox = gp->ox, g_oy = gp->oy, g_oz = gp->oz, g_inv_h = gp->inv_h;
+    const int bk_g = gp->bk_g, bk_ny = gp->bk_ny, bk_cells = gp->bk_cells;
+    auto row_base_g = [&](int cy, int cz) {  // bucket-major cell index of cell (0, cy, cz)
+        const int by_ = cy / bk_g, bz_ = cz / bk_g;
+        return (bz_ * bk_ny + by_) * bk_cells + ((cz - bz_ * bk_g) * bk_g + (cy - by_ * bk_g)) * nx;
+    };
     const int dbg = gp->debug_skip;
     const int kk = k + 1;
 
@@ -381,7 +518,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
             const bool valid = (isq ? (lane < 20 && r < nqrows) : r < ncrows) && yy >= 0 && yy < ny && zz >= 0 && zz < nz;
             if (valid) {
                 const unsigned *st = isq ? qstart : rstart;
-                const int row = (zz * ny + yy) * nx;
+                const int row = row_base_g(yy, zz);
                 unsigned s = st[row + xa], e = st[row + xb + 1];
                 v_start = (int)s;
                 v_len = (int)(e - s);
@@ -454,7 +591,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
                     const bool need = yy >= max(lo[1] - 1, 0) && yy <= min(hi[1] + 1, ny - 1) &&
                                       zz >= max(lo[2] - 1, 0) && zz <= min(hi[2] + 1, nz - 1) && xa <= xb;
                     if (need) {
-                        const int row = (zz * ny + yy) * nx;
+                        const int row = row_base_g(yy, zz);
                         const unsigned s0 = rstart[row + xa], e0 = rstart[row + xb + 1];
                         rs_start = (int)s0;
                         rs_len = (int)(e0 - s0);
@@ -626,7 +763,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                     int s = 0, len = 0;
                     if (r < nrows) {
                         const int zz = z0 + r / nyr, yy = y0 + r % nyr;
-                        const int row = (zz * g.ny + yy) * g.nx;
+                        const int row = row_base(g, yy, zz);
                         s = (int)rstart[row + x0];
                         len = (int)rstart[row + x1 + 1] - s;
                     }
@@ -666,7 +803,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
             } else {
                 for (int zz = z0; zz <= z1; ++zz)
                     for (int yy = y0; yy <= y1; ++yy) {
-                        const int row = (zz * g.ny + yy) * g.nx;
+                        const int row = row_base(g, yy, zz);
                         const int s = (int)rstart[row + x0], e = (int)rstart[row + x1 + 1];
                         for (int j = s + lane; j < e; j += 64) consider(refs[j]);
                     }
@@ -746,20 +883,21 @@ static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, c
 
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
-// Bin (x,y,z)[first, first+n) with the grid in gp: cnt/start/rank/sorted are outputs.
+// Sort (x,y,z)[first, first+n) by cell of the grid in gp: `sorted` and `start` (cell_start) are outputs.
 static int bin_points(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
-                      int64_t n, GridParams *gp, int64_t cell_cap, unsigned *cnt, unsigned *start, unsigned *rank,
-                      unsigned *part, float4 *sorted)
+                      int64_t n, GridParams *gp, unsigned *start, float4 *sorted)
 {
-    const int nparts = div_up(cell_cap + 1, SCAN_BLOCK);
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(grid_blocks(ctx, cell_cap)), dim3(256), 0, ctx->stream, cnt, gp);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(grid_blocks(ctx, n)), dim3(256), 0, ctx->stream, x, y, z, stride,
-                       (int)first, (int)n, gp, cnt, rank);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(nparts), dim3(256), 0, ctx->stream, cnt, gp, part);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, ctx->stream, part, nparts);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nparts), dim3(256), 0, ctx->stream, cnt, gp, part, start);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid_blocks(ctx, n)), dim3(256), 0, ctx->stream, x, y, z, stride,
-                       (int)first, (int)n, gp, start, rank, sorted);
+    unsigned *bk_cnt = ctx->bkcnt.as<unsigned>();
+    unsigned *bk_start = bk_cnt + MAX_BUCKETS;
+    unsigned *bk_cursor = bk_start + MAX_BUCKETS + 1;
+    float4 *tmp = ctx->bucketpts.as<float4>();
+    const int tiles = (int)std::min<int64_t>(div_up(n, BIN_TILE), (int64_t)ctx->num_cu * 4);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n, gp,
+                       bk_cnt);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, gp, bk_cnt, bk_start, bk_cursor);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n,
+                       gp, bk_cursor, tmp);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(MAX_BUCKETS), dim3(256), 0, ctx->stream, gp, bk_start, tmp, sorted, start);
     GSX_HIP(hipGetLastError());
     return 0;
 }
@@ -770,7 +908,6 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
     const int64_t cap = grid_cell_cap(n_ref);
-    const int nparts = div_up(cap + 1, SCAN_BLOCK);
     const bool all = (q_begin == 0 && q_count == n_ref);
     const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
@@ -785,18 +922,18 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
             if (pts_per_cell * cells > 58.0 && pts_per_cell * cells <= 66.0) pts_per_cell = 58.0 / cells;
     }
     GSX_CHECK(ctx->packed.reserve(sizeof(float4) * (size_t)n_ref));
-    GSX_CHECK(ctx->rank.reserve(sizeof(unsigned) * (size_t)n_ref));
-    GSX_CHECK(ctx->cellcnt.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+    GSX_CHECK(ctx->bucketpts.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(ctx->cellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
-    GSX_CHECK(ctx->scanpart.reserve(sizeof(unsigned) * (size_t)nparts));
+    if (!ctx->bkcnt.p) {  // bucket sizes | bucket starts | bucket cursors; sizes are re-zeroed by bucket_scan_kernel
+        GSX_CHECK(ctx->bkcnt.reserve(sizeof(unsigned) * (3 * MAX_BUCKETS + 8)));
+        GSX_HIP(hipMemsetAsync(ctx->bkcnt.p, 0, sizeof(unsigned) * (3 * MAX_BUCKETS + 8), ctx->stream));
+    }
     GSX_CHECK(ctx->gridparams.reserve(sizeof(GridParams)));
     GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     GSX_CHECK(ctx->faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
     GSX_CHECK(ctx->extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
     if (!all) {
         GSX_CHECK(ctx->qsorted.reserve(sizeof(float4) * (size_t)q_count));
-        GSX_CHECK(ctx->qrank.reserve(sizeof(unsigned) * (size_t)q_count));
-        GSX_CHECK(ctx->qcellcnt.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
         GSX_CHECK(ctx->qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
     }
     GridParams *gp = ctx->gridparams.as<GridParams>();
@@ -809,14 +946,12 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
                        (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, gp);
     GSX_HIP(hipGetLastError());
-    GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, cap, ctx->cellcnt.as<unsigned>(), rstart,
-                         ctx->rank.as<unsigned>(), ctx->scanpart.as<unsigned>(), refs));
+    GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, rstart, refs));
     const float4 *qpts = refs;
     const unsigned *qstart = rstart;
     if (!all) {
-        GSX_CHECK(bin_points(ctx, x, y, z, stride, q_begin, q_count, gp, cap, ctx->qcellcnt.as<unsigned>(),
-                             ctx->qcellstart.as<unsigned>(), ctx->qrank.as<unsigned>(),
-                             ctx->scanpart.as<unsigned>(), ctx->qsorted.as<float4>()));
+        GSX_CHECK(bin_points(ctx, x, y, z, stride, q_begin, q_count, gp, ctx->qcellstart.as<unsigned>(),
+                             ctx->qsorted.as<float4>()));
         qpts = ctx->qsorted.as<float4>();
         qstart = ctx->qcellstart.as<unsigned>();
     }

@@ -7,7 +7,11 @@ struct GridParams {
     float ox, oy, oz, inv_h;
     float h;
     int nx, ny, nz;
-    int ncells;
+    int ncells;          // padded: bk_count * bk_cells (cell index space, bucket-major)
+    int bk_g;            // a BUCKET is bk_g x bk_g complete x-rows of cells (the unit of the 2-level sort)
+    int bk_ny, bk_nz;    // buckets along y and z
+    int bk_count;        // bk_ny * bk_nz
+    int bk_cells;        // cells per bucket = bk_g * bk_g * nx
     int nbx, nby, nbz;
     int nbricks;
     int bdx, bdy, bdz;  // brick size in cells: (2,2,2), (2,2,1), (2,1,1) or (1,1,1)
