@@ -607,6 +607,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
             // ---- phase 2: walk this lane's set bits, exact f64 distance, sorted insert
             auto drain = [&]() __attribute__((always_inline)) {
                 wave_sync();  // wbase[] written by lane 0 is visible to every lane
+                if (dbg & 32) nzw = 0;  // profiling: masks are built but never walked
                 unsigned m = 0;
                 int base = 0;
                 // software pipeline: the gather of candidate n+1 is in flight while candidate n goes
@@ -649,14 +650,15 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
                     const float neg_tau = -tau;  // dead lanes: tau = -1 => t > 0 => bit 0
                     unsigned m = 0;
                     int i = 0;
+                    // 4 candidates per scalar load (s_load_dwordx16), 8 in flight
+                    struct Quad { float4 v[4]; };
+                    const Quad *__restrict__ pq = reinterpret_cast<const Quad *>(p);
                     for (; i + 8 <= c; i += 8) {
-                        float4 P[8];
+                        const Quad a = pq[i / 4], b = pq[i / 4 + 1];  // wave-uniform addresses
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) P[u] = p[i + u];  // wave-uniform address: scalar loads
+                        for (int u = 0; u < 4; ++u) m = shift_in_lt(m, qx, qy, qz, a.v[u].x, a.v[u].y, a.v[u].z, neg_tau);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            m = shift_in_lt(m, qx, qy, qz, P[u].x, P[u].y, P[u].z, neg_tau);
-                        }
+                        for (int u = 0; u < 4; ++u) m = shift_in_lt(m, qx, qy, qz, b.v[u].x, b.v[u].y, b.v[u].z, neg_tau);
                     }
                     for (; i < c; ++i) {
                         float4 P = p[i];

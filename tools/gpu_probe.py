@@ -61,7 +61,7 @@ def ablate():
     ctx = L.Context(0)
     x10 = uniform(10_000_000, 5.0)
     for dbg, name in ((0, "full"), (4, "no epilogue"), (7, "skeleton only"), (15, "skeleton, no output write"),
-                      (31, "queue + row tables only"), (5, "phase 1 only (+cursor walk)"), (6, "phase 2 impossible")):
+                      (31, "queue + row tables only"), (5, "phase 1 + cursor walk, no insert"), (36, "phase 1 only, no walk")):
         ctx.set_param("debug_skip", dbg)
         run(ctx, x10, 16, 2, 0.0, label="ablate: " + name)
     ctx.set_param("debug_skip", 0)
