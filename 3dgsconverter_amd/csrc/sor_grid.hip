@@ -480,6 +480,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
     const int nqrows = bdy * bdz;             // <= 4 query x-rows
     const int nbricks = gp->nbricks;
     const double r1sq = gp->r1sq;
+    const double hp = gp->hprime;
     const float tau1 = gp->tau1;
     const float g_ox = gp->ox, g_oy = gp->oy, g_oz = gp->oz, g_inv_h = gp->inv_h;
     const int bk_g = gp->bk_g, bk_ny = gp->bk_ny, bk_cells = gp->bk_cells;
@@ -559,6 +560,43 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
             const float qx = qp.x, qy = qp.y, qz = qp.z;
             const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
             float tau = live ? tau1 : -1.0f;
+            double racc_sq = r1sq;  // this lane's acceptance radius^2 (== the exact value its filter bound comes from)
+            // Queries next to the cloud's bounding box see only part of their neighbourhood ball, so
+            // their (k+1)-th neighbour is farther than one cell and they would all go to knn_ring.  But
+            // where the brick's neighbourhood is cut by the GRID boundary nothing exists beyond that
+            // face, so it does not limit the guaranteed radius: r_safe(q) = distance to the nearest
+            // face of the searched box that has cells behind it (>= h').  The filter radius is widened
+            // only as far as the missing ball volume requires (so phase 2 sees the usual ~30 candidates).
+            {
+                const int ulo[3] = {bx * bdx - 1, by * bdy - 1, bz * bdz - 1};
+                const int uhi[3] = {bx * bdx + bdx, by * bdy + bdy, bz * bdz + bdz};
+                const int dim[3] = {nx, ny, nz};
+                const bool boundary = ulo[0] <= 0 || ulo[1] <= 0 || ulo[2] <= 0 || uhi[0] >= nx - 1 || uhi[1] >= ny - 1 ||
+                                      uhi[2] >= nz - 1;
+                if (boundary) {  // wave-uniform
+                    // f32 is enough: the 1e-3*h' margin dwarfs its rounding (<= dims * 2^-23 * h' ~ 1e-4 h')
+                    const float hf = (float)hp;
+                    const float rel[3] = {qx - g_ox, qy - g_oy, qz - g_oz};
+                    const float r1 = hf * (1.0f - 1e-3f);
+                    float rsafe = 3.0e38f, frac = 1.0f;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        // faces of the searched box with cells behind them (margin as in grid_params_kernel)
+                        if (ulo[a] > 0) rsafe = fminf(rsafe, rel[a] - (float)ulo[a] * hf - 2e-3f * hf);
+                        if (uhi[a] < dim[a] - 1) rsafe = fminf(rsafe, (float)(uhi[a] + 1) * hf - rel[a] - 2e-3f * hf);
+                        // part of [q - r1, q + r1] that lies inside the grid along this axis
+                        const float tl = fminf(fmaxf(rel[a], 0.0f), r1);
+                        const float th = fminf(fmaxf((float)dim[a] * hf - rel[a], 0.0f), r1);
+                        frac *= (tl + th) / (2.0f * r1);
+                    }
+                    float rq = r1 * cbrtf(1.0f / fmaxf(frac, 0.125f));
+                    rq = fminf(rq, rsafe);
+                    if (rq > r1 && live) {
+                        racc_sq = (double)rq * (double)rq;
+                        tau = bound_from(racc_sq);
+                    }
+                }
+            }
 
             // Batches after a brick's first hold the LAST queries of the brick (typically its last cell
             // or two): their neighbourhood is a sub-box of the brick's, so only the rows / cells within
@@ -679,7 +717,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
                     if (lst.kth(kk) == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
                 } else if (dbg & 4) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)lst.kth(kk);
-                } else if (lst.kth(kk) <= r1sq) {
+                } else if (lst.kth(kk) <= racc_sq) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);

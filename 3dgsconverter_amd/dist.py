@@ -65,6 +65,9 @@ class HipCompute:
         return out
 
 
+_equal_shards_checked = set()  # (group id, n_local): the size check costs two collectives + a host sync, do it once
+
+
 def sharded_sor(xyz_local, k: int, threshold_factor: float, compute, group=None, algo: int = 0) -> ShardedSorResult:
     """xyz_local: (n_local,3) float32 tensor, same n_local on every rank (index shard `rank`)."""
     import torch
@@ -74,12 +77,15 @@ def sharded_sor(xyz_local, k: int, threshold_factor: float, compute, group=None,
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_local = xyz_local.shape[0]
     if world > 1:
-        sizes = torch.tensor([n_local], dtype=torch.int64, device=xyz_local.device)
-        lo, hi = sizes.clone(), sizes.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-        if int(lo) != int(hi):
-            raise ValueError("sharded_sor needs equally sized index shards (got %d..%d)" % (int(lo), int(hi)))
+        key = (id(group), n_local, world)
+        if key not in _equal_shards_checked:
+            sizes = torch.tensor([n_local], dtype=torch.int64, device=xyz_local.device)
+            lo, hi = sizes.clone(), sizes.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            if int(lo) != int(hi):
+                raise ValueError("sharded_sor needs equally sized index shards (got %d..%d)" % (int(lo), int(hi)))
+            _equal_shards_checked.add(key)
         xyz_all = torch.empty((world * n_local, 3), dtype=xyz_local.dtype, device=xyz_local.device)
         dist.all_gather_into_tensor(xyz_all, xyz_local.contiguous(), group=group)
     else:
