@@ -198,3 +198,60 @@ def test_degenerate_geometries(lib):
         for algo in (BRUTE, GRID):
             res = lib.sor_filter(xyz, 16, 1.0, algo=algo, want_info=True)
             assert _explain(res["mean_dists"], ref) == "ok", (name, algo, res["info"])
+
+
+_TORCH_SCRIPT = r"""
+import importlib, json, sys
+import numpy as np
+import torch                      # FIRST: libgsx_hip.so must bind to the HIP runtime torch bundles
+sys.path.insert(0, sys.argv[1])
+gdist = importlib.import_module("3dgsconverter_amd.dist")
+from oracle import datasets
+spec = json.loads(sys.argv[2])
+xyz = datasets.make(spec["dataset"])
+t = torch.from_numpy(xyz).to(torch.device("cuda", 0))
+res = gdist.sharded_sor(t, spec["k"], spec["sigma"], gdist.HipCompute(0))
+torch.cuda.synchronize()
+np.save(sys.argv[3], res.mask_local.cpu().numpy())
+np.save(sys.argv[4], np.concatenate([res.stats.cpu().numpy(), res.mean_dists_local.cpu().numpy()]))
+"""
+
+
+def test_torch_plumbing_and_sharded_entry_point(golden_cases, golden_arrays, tmp_path):
+    """bench.py's path: torch tensors in HBM -> dist.sharded_sor(HipCompute) -> mask, single process
+    (world 1).  Runs in its own interpreter because torch must be imported BEFORE libgsx_hip.so (both
+    link a libamdhip64.so.7; whichever loads first serves both, and torch only works with its own)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    case = golden_cases["sor"]["sor_u100k_k8_s1"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = json.dumps({"dataset": case["dataset"], "k": case["k_used"], "sigma": case["sigma_used"]})
+    m, o = str(tmp_path / "mask.npy"), str(tmp_path / "out.npy")
+    r = subprocess.run([sys.executable, "-c", _TORCH_SCRIPT, root, spec, m, o], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mask = np.load(m).astype(bool)
+    out = np.load(o)
+    np.testing.assert_array_equal(np.packbits(mask), golden_arrays["sor_u100k_k8_s1__mask"])
+    assert np.float32(out[2]).tobytes() == f32_from_hex(case["threshold_hex"]).tobytes()
+    assert sha16(out[3:].astype(np.float32).tobytes()) == case["mean_dists_sha"]
+
+
+def test_sor_50m_k32_config4_single_gpu(lib):
+    """BASELINE.json configs[3] size on ONE GPU (it fits 288 GB easily): 50M splats, k=32.  Checks a
+    random query subset against the scalar C restatement and the mask against numpy on the GPU's own
+    mean distances (the statistics are bit-exact, so the mask must be identical)."""
+    n = 50_000_000
+    xyz = datasets.uniform(n, 10.0, 0)
+    res = lib.sor_filter(xyz, 32, 1.0, algo=GRID, want_info=True)
+    md = res["mean_dists"]
+    assert np.isfinite(md).all() and (md > 0).all()
+    q = np.sort(np.random.default_rng(2).choice(n, 48, replace=False))
+    ref = osor.mean_dists_brute_subset_c(xyz, 32, q)
+    assert _explain(md[q], ref) == "ok", res["info"]
+    m, s, t = osor.threshold_numpy(md, 1.0)
+    assert np.float32(t).tobytes() == np.float32(res["threshold"]).tobytes()
+    np.testing.assert_array_equal(res["mask"], md < t)
+    assert res["info"]["n_fallback"] < 0.02 * n
