@@ -10,42 +10,132 @@
 // The data stays resident in HBM across iterations (the reference re-uploads it for every
 // kernel call).
 //
-// assign: one lane per point, the point's D coordinates live in registers; centroids are
-// read with wave-uniform addresses, i.e. through the scalar cache straight into SGPR
-// operands of the VALU ops -- no LDS, no per-lane centroid traffic.  2 VALU ops per
-// (point, centroid, dim): bound by FP32 VALU issue, not HBM.
-// update: float64 hardware atomics (order-insensitive to ~1e-16, unlike the reference's f32
-// atomics), then one pass over K x D.
+// assign (+ the accumulation half of update, fused): two points per lane with their D
+// coordinates in registers; centroids are read with wave-uniform addresses, i.e. through the
+// scalar cache straight into SGPR operands of packed-f32 VALU ops -- no per-lane centroid
+// traffic.  2 VALU lane-ops per (point, centroid, dim): bound by FP32 VALU issue, not HBM
+// (SURVEY.md 8(d)).  Cluster sums are float64 hardware atomics (order-insensitive to ~1e-16,
+// unlike the reference's f32 atomics), in HBM or -- for small codebooks -- in LDS; one small
+// kernel per iteration divides and re-zeroes.
 #include "gsx_common.h"
 
 namespace gsx {
 
-template <int D>
-__global__ __launch_bounds__(256) void kmeans_assign_kernel(const float *__restrict__ data, int64_t n,
-                                                            const float *__restrict__ cent, int k,
-                                                            int32_t *__restrict__ labels)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Work split: a workgroup of NW waves owns 128 points (2 per lane: rows p and p+64 of the
+// tile) and each wave scans 1/NW of the centroids; the per-wave winners are merged in
+// centroid order with strict '<', which is the sequential scan's "lowest index wins".
+// Splitting K instead of N keeps every SIMD busy for the small N of a SOG chunk (156 250 rows
+// are only 1 221 tiles), and with NW=16 a tile is one CU-filling workgroup of short waves.
+// The two points of a lane share each scalar-loaded centroid value through one v_pk_add_f32 +
+// one v_pk_fma_f32 (dims still accumulated in order for each point).  The tile sits in LDS,
+// so k_means_update's accumulation runs in the same launch.
+constexpr int KM_TILE = 128;
+
+template <int D, int NW, bool LACC>
+__global__ __launch_bounds__(64 * NW) void kmeans_assign_kernel(const float *__restrict__ data, int64_t n,
+                                                                 const float *__restrict__ cent, int k,
+                                                                 int32_t *__restrict__ labels,
+                                                                 double *__restrict__ sums, unsigned *__restrict__ counts)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ii = i < n ? i : n - 1;
-    float xv[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xv[d] = data[ii * D + d];
-    float best = 1e20f;  // gpu_ops.py:60
-    int bi = -1;
-    for (int c = 0; c < k; ++c) {
-        const float *__restrict__ cc = cent + (int64_t)c * D;  // wave-uniform: scalar loads
-        float dist = 0.0f;
+    constexpr int DP = D | 1;  // odd LDS row stride: conflict-free per-lane row reads
+    __shared__ float s_tile[KM_TILE * DP];
+    __shared__ float s_best[NW][KM_TILE];
+    __shared__ int s_idx[NW][KM_TILE];
+    // LACC (k * D <= KM_LACC_MAX): the workgroup walks many tiles and keeps the cluster sums in
+    // LDS (ds_add_f64), flushing once -- a small codebook over a large N would otherwise
+    // serialise on k * D global atomic addresses (measured 15 ms / iteration at 30M x 1, k=256)
+    extern __shared__ double s_acc[];  // [k * D] sums, then [k] counts
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_acc + (LACC ? k * D : 0));
+    if (LACC) {
+        for (int e = threadIdx.x; e < k * D; e += 64 * NW) s_acc[e] = 0.0;
+        for (int e = threadIdx.x; e < k; e += 64 * NW) s_cnt[e] = 0u;
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = (int)(((int64_t)k * w) / NW), c1 = (int)(((int64_t)k * (w + 1)) / NW);
+    const int64_t tiles = (n + KM_TILE - 1) / KM_TILE;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t base = tile * KM_TILE;
+        const int rows = (int)(n - base < KM_TILE ? n - base : KM_TILE);
+        __syncthreads();  // previous tile fully consumed (and the LACC zeroing done)
+        // the tile's rows are contiguous in the row-major input: one coalesced copy into LDS
+        for (int e = threadIdx.x; e < rows * D; e += 64 * NW) {
+            const int r = e / D;
+            s_tile[r * DP + (e - r * D)] = data[base * D + e];
+        }
+        __syncthreads();
+        const int ra = lane < rows ? lane : rows - 1;
+        const int rb = lane + 64 < rows ? lane + 64 : rows - 1;
+        f32x2 xv[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            float diff = xv[d] - cc[d];
-            dist = __builtin_fmaf(diff, diff, dist);
+            xv[d].x = s_tile[ra * DP + d];
+            xv[d].y = s_tile[rb * DP + d];
         }
-        if (dist < best) {
-            best = dist;
-            bi = c;
+        f32x2 best = {1e20f, 1e20f};  // gpu_ops.py:60
+        int bia = -1, bib = -1;
+        for (int c = c0; c < c1; ++c) {
+            // wave-uniform address: s_load into SGPRs, broadcast to both halves of the packed
+            // op by op_sel.  (Issuing a row's s_loads behind one wait by hand changed nothing:
+            // four waves per SIMD already cover the scalar-cache latency.)
+            const float *__restrict__ cc = cent + (int64_t)c * D;
+            f32x2 dist = {0.0f, 0.0f};
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const f32x2 cv = {cc[d], cc[d]};
+                const f32x2 diff = xv[d] - cv;
+                dist = __builtin_elementwise_fma(diff, diff, dist);  // dims in order (gpu_ops.py:63-66)
+            }
+            if (dist.x < best.x) {
+                best.x = dist.x;
+                bia = c;
+            }
+            if (dist.y < best.y) {
+                best.y = dist.y;
+                bib = c;
+            }
+        }
+        s_best[w][lane] = best.x;
+        s_best[w][lane + 64] = best.y;
+        s_idx[w][lane] = bia;
+        s_idx[w][lane + 64] = bib;
+        __syncthreads();
+        if (threadIdx.x < KM_TILE) {
+            float b = s_best[0][threadIdx.x];
+            int bi = s_idx[0][threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) {
+                const float v = s_best[q][threadIdx.x];
+                if (v < b) {
+                    b = v;
+                    bi = s_idx[q][threadIdx.x];
+                }
+            }
+            s_idx[0][threadIdx.x] = bi;
+            if (threadIdx.x < rows) {
+                labels[base + threadIdx.x] = bi;
+                atomicAdd(LACC ? &s_cnt[bi] : &counts[bi], 1u);
+            }
+        }
+        __syncthreads();
+        // k_means_update's accumulation (gpu_ops.py:83-89) while the tile is still in LDS
+        for (int e = threadIdx.x; e < rows * D; e += 64 * NW) {
+            const int r = e / D, d = e - r * D;
+            const int64_t slot = (int64_t)s_idx[0][r] * D + d;
+            unsafeAtomicAdd(LACC ? &s_acc[slot] : &sums[slot], (double)s_tile[r * DP + d]);
         }
     }
-    if (i < n) labels[i] = bi;
+    if (LACC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < k; e += 64 * NW) {
+            const unsigned cnt = s_cnt[e];
+            if (cnt == 0u) continue;
+            atomicAdd(&counts[e], cnt);
+            for (int d = 0; d < D; ++d) unsafeAtomicAdd(&sums[(int64_t)e * D + d], s_acc[e * D + d]);
+        }
+    }
 }
 
 // any D (slow path): coordinates re-read from memory
@@ -86,15 +176,22 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
     }
 }
 
-__global__ __launch_bounds__(256) void kmeans_finalize_kernel(const double *__restrict__ sums,
-                                                              const unsigned *__restrict__ counts, int k, int D,
-                                                              float *__restrict__ cent)
+// one workgroup per centroid (gpu_ops.py:91-96: inv = 1/float(cnt); centroid *= inv; an empty
+// cluster keeps the 0 it was reset to); also re-zeroes the accumulators for the next iteration
+// (gpu_ops.py:77-81) so that the fused assign+accumulate kernel needs no memset in between
+__global__ __launch_bounds__(64) void kmeans_finalize_reset_kernel(double *__restrict__ sums, unsigned *__restrict__ counts,
+                                                                   int D, float *__restrict__ cent)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * D) return;
-    const unsigned cnt = counts[e / D];
-    // gpu_ops.py:91-96: inv = 1/float(cnt); centroid *= inv; an empty cluster keeps the 0 it was reset to
-    cent[e] = cnt > 0 ? (float)sums[e] * (1.0f / (float)cnt) : 0.0f;
+    const int c = blockIdx.x;
+    const unsigned cnt = counts[c];
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const int64_t e = (int64_t)c * D + d;
+        cent[e] = cnt > 0 ? (float)sums[e] * inv : 0.0f;
+        sums[e] = 0.0;
+    }
+    __syncthreads();  // every lane has read counts[c]
+    if (threadIdx.x == 0) counts[c] = 0u;
 }
 
 // ---- quantize_to_codebook (formats/sog.py:408-419) ----------------------------------------
@@ -121,23 +218,45 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float *__restrict__
     }
 }
 
+constexpr int KM_LACC_MAX = 2048;  // k * D doubles of LDS accumulators (16 KiB + counts)
+
 template <int D>
-static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const float *cent, int k, int32_t *labels)
+static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const float *cent, int k, int32_t *labels,
+                            double *sums, unsigned *counts)
 {
-    hipLaunchKernelGGL((kmeans_assign_kernel<D>), dim3(div_up(n, 256)), dim3(256), 0, c->stream, data, n, cent, k, labels);
+    const int64_t tiles = div_up(n, KM_TILE);
+    if constexpr (D <= 4) {
+        if (k * D <= KM_LACC_MAX && tiles > (int64_t)c->num_cu * 8) {
+            const size_t lds = sizeof(double) * (size_t)k * D + sizeof(unsigned) * (size_t)k;
+            hipLaunchKernelGGL((kmeans_assign_kernel<D, 4, true>), dim3(c->num_cu * 8), dim3(256), lds, c->stream, data, n,
+                               cent, k, labels, sums, counts);
+            return;
+        }
+    }
+    // few tiles and enough centroids per wave: split K sixteen ways (one workgroup fills a CU)
+    if (tiles < (int64_t)c->num_cu * 32 && k >= 128)
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, 16, false>), dim3((unsigned)tiles), dim3(1024), 0, c->stream, data, n,
+                           cent, k, labels, sums, counts);
+    else
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, 4, false>), dim3((unsigned)tiles), dim3(256), 0, c->stream, data, n,
+                           cent, k, labels, sums, counts);
 }
 
-static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, const float *cent, int k, int32_t *labels)
+// returns 0 and sets *fused when the templated kernel (assign + accumulate in one launch) ran
+static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, const float *cent, int k, int32_t *labels,
+                         double *sums, unsigned *counts, bool *fused)
 {
+    *fused = true;
     switch (d) {
-        case 1: launch_assign_t<1>(c, data, n, cent, k, labels); break;
-        case 2: launch_assign_t<2>(c, data, n, cent, k, labels); break;
-        case 3: launch_assign_t<3>(c, data, n, cent, k, labels); break;
-        case 4: launch_assign_t<4>(c, data, n, cent, k, labels); break;
-        case 9: launch_assign_t<9>(c, data, n, cent, k, labels); break;
-        case 24: launch_assign_t<24>(c, data, n, cent, k, labels); break;
-        case 45: launch_assign_t<45>(c, data, n, cent, k, labels); break;
+        case 1: launch_assign_t<1>(c, data, n, cent, k, labels, sums, counts); break;
+        case 2: launch_assign_t<2>(c, data, n, cent, k, labels, sums, counts); break;
+        case 3: launch_assign_t<3>(c, data, n, cent, k, labels, sums, counts); break;
+        case 4: launch_assign_t<4>(c, data, n, cent, k, labels, sums, counts); break;
+        case 9: launch_assign_t<9>(c, data, n, cent, k, labels, sums, counts); break;
+        case 24: launch_assign_t<24>(c, data, n, cent, k, labels, sums, counts); break;
+        case 45: launch_assign_t<45>(c, data, n, cent, k, labels, sums, counts); break;
         default:
+            *fused = false;
             hipLaunchKernelGGL(kmeans_assign_generic_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, data, n, d,
                                cent, k, labels);
     }
@@ -155,16 +274,17 @@ int kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k,
     double *sums = c->scratch3.as<double>();
     unsigned *counts = reinterpret_cast<unsigned *>(c->scratch3.as<char>() + sizeof(double) * kd);
     const int acc_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n * d, 256), (int64_t)c->num_cu * 16));
+    GSX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * kd + sizeof(unsigned) * (size_t)k, c->stream));
     for (int it = 0; it < max_iter; ++it) {
+        bool fused = false;
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_ASSIGN));
-        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev));
+        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused));
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
-        GSX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * kd + sizeof(unsigned) * (size_t)k, c->stream));
-        hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(acc_blocks), dim3(256), 0, c->stream, data_dev, n, d, labels_dev,
-                           sums, counts);
-        hipLaunchKernelGGL(kmeans_finalize_kernel, dim3(div_up((int64_t)kd, 256)), dim3(256), 0, c->stream, sums, counts, k,
-                           d, cent_dev);
+        if (!fused)
+            hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(acc_blocks), dim3(256), 0, c->stream, data_dev, n, d,
+                               labels_dev, sums, counts);
+        hipLaunchKernelGGL(kmeans_finalize_reset_kernel, dim3(k), dim3(64), 0, c->stream, sums, counts, d, cent_dev);
         GSX_HIP(hipGetLastError());
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_UPDATE));
     }

@@ -31,7 +31,8 @@ def test_single_assign_matches_oracle(gsx, n, d, k):
     assert (gap < 1e-5).all(), gap.max()
 
 
-@pytest.mark.parametrize("n,d,k,iters", [(4000, 9, 64, 10), (50000, 1, 256, 20), (20000, 45, 256, 10)])
+@pytest.mark.parametrize("n,d,k,iters", [(4000, 9, 64, 10), (50000, 1, 256, 20), (20000, 45, 256, 10),
+                                         (300001, 1, 256, 20), (280000, 3, 64, 10)])  # last two: LDS-accumulator path
 def test_lloyd_trajectory_matches_oracle(gsx, n, d, k, iters):
     lib = gsx._lib
     data = _data(n, d, 3 * n + d)
