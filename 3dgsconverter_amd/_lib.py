@@ -53,6 +53,7 @@ SIGNATURES = {
     "gsx_dev_upload": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
+    "gsx_sor_knn_share_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
     "gsx_sor_mask_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_sor_filter": (_I, [_P, _P, _P, _I64, _I64, _I, _D, _I, _P, _P, _P, C.POINTER(SorInfo)]),
@@ -292,6 +293,14 @@ class Context:
         info = SorInfo() if want_info else None
         check(self.lib.gsx_sor_knn_dev(self.handle, x, y, z, stride, n_ref, q_begin, q_count, int(k), int(algo),
                                        mean_out, C.byref(info) if want_info else None), "gsx_sor_knn_dev")
+        return info.as_dict() if want_info else None
+
+    def sor_knn_share(self, x: int, y: int, z: int, stride: int, n: int, k: int, share: int, nshares: int,
+                      mean_out: int, algo: int = KNN_AUTO, want_info: bool = False):
+        info = SorInfo() if want_info else None
+        check(self.lib.gsx_sor_knn_share_dev(self.handle, x, y, z, stride, n, int(k), int(algo), int(share),
+                                             int(nshares), mean_out, C.byref(info) if want_info else None),
+              "gsx_sor_knn_share_dev")
         return info.as_dict() if want_info else None
 
     def sor_stats(self, mean_dists: int, n: int, threshold_factor: float, stats_out: int):

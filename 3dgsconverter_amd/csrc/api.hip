@@ -82,7 +82,7 @@ int launch_pack_points(gsx_ctx *, const float *, const float *, const float *, i
 int launch_knn_brute(gsx_ctx *, const float4 *, int64_t, int64_t, int64_t, const unsigned *, const unsigned *,
                      int64_t, int, float *);
 int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int,
-                    float *, gsx_sor_info *);
+                    float *, gsx_sor_info *, int share = 0, int nshares = 1);
 int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
 int launch_sor_mask(gsx_ctx *, const float *, int64_t, const float *, uint8_t *);
 int density_voxels_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int64_t,
@@ -266,6 +266,28 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
     }
     if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, info);
     GSX_FAIL("gsx_sor_knn_dev: unknown algo %d", algo);
+}
+
+int gsx_sor_knn_share_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                          int k, int algo, int share, int nshares, float *mean_out, gsx_sor_info *info)
+{
+    if (!c || !x || !y || !z || !mean_out) GSX_FAIL("gsx_sor_knn_share_dev: null argument");
+    if (nshares < 1 || share < 0 || share >= nshares) GSX_FAIL("gsx_sor_knn_share_dev: share %d of %d", share, nshares);
+    if (n <= 0 || n >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_knn_share_dev: n=%lld out of range", (long long)n);
+    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_knn_share_dev: k=%d not supported (1 <= k <= 64)", k);
+    if (stride < 1) GSX_FAIL("gsx_sor_knn_share_dev: bad stride");
+    GSX_HIP(hipSetDevice(c->device));
+    // every query belongs to exactly one share; the other shares' entries stay +0.0f so that the
+    // shares combine by a plain sum (x + 0 = x exactly)
+    GSX_HIP(hipMemsetAsync(mean_out, 0, sizeof(float) * (size_t)n, c->stream));
+    if (algo == GSX_KNN_AUTO) algo = n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID;
+    if (algo == GSX_KNN_BRUTE) {  // no spatial structure: the share is an index range
+        const int64_t q0 = n * share / nshares, q1 = n * (share + 1) / nshares;
+        if (q1 == q0) return 0;
+        return gsx_sor_knn_dev(c, x, y, z, stride, n, q0, q1 - q0, k, GSX_KNN_BRUTE, mean_out + q0, info);
+    }
+    if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n, 0, n, k, mean_out, info, share, nshares);
+    GSX_FAIL("gsx_sor_knn_share_dev: unknown algo %d", algo);
 }
 
 int gsx_sor_stats_dev(gsx_ctx *c, const float *md, int64_t n, double factor, float *stats_dev)

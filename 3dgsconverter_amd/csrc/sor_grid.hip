@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
 
 __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
                                                          double pts_per_cell, int cell_cap, int debug_skip,
-                                                         GridParams *__restrict__ gp)
+                                                         int share, int nshares, GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
     float v[7];
@@ -194,6 +194,9 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->bdx = bdx; gp->bdy = bdy; gp->bdz = bdz;
     gp->nbx = (nx + bdx - 1) / bdx; gp->nby = (ny + bdy - 1) / bdy; gp->nbz = (nz + bdz - 1) / bdz;
     gp->nbricks = bad ? 0 : gp->nbx * gp->nby * gp->nbz;
+    // bricks are numbered z-major, so a contiguous share is a slab of the cloud
+    gp->part_lo = (int)(((long long)gp->nbricks * share) / nshares);
+    gp->part_hi = (int)(((long long)gp->nbricks * (share + 1)) / nshares);
     gp->bad_input = bad ? 1u : 0u;
     gp->debug_skip = debug_skip;
     // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
@@ -478,7 +481,6 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
     const int cry = bdy + 2;                  // candidate rows per z-slab
     const int ncrows = cry * (bdz + 2);       // <= 16 candidate x-rows
     const int nqrows = bdy * bdz;             // <= 4 query x-rows
-    const int nbricks = gp->nbricks;
     const double r1sq = gp->r1sq;
     const double hp = gp->hprime;
     const float tau1 = gp->tau1;
@@ -492,11 +494,13 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
     const int kk = k + 1;
 
     WorkQueue wq;
-    wq_init(wq, EXTRA ? gp->extra_ctr : gp->brick_ctr, EXTRA ? (int)gp->extra_count : nbricks, BRICK_THREADS / 64);
+    const int part_lo = gp->part_lo;
+    wq_init(wq, EXTRA ? gp->extra_ctr : gp->brick_ctr, EXTRA ? (int)gp->extra_count : gp->part_hi - part_lo,
+            BRICK_THREADS / 64);
     for (;;) {
         const int item = uniform(wq_next(wq));
         if (item < 0) break;
-        int b = item, qb = 0;
+        int b = item + part_lo, qb = 0;
         if (EXTRA) {
             const uint2 it = extra[item];
             b = uniform((int)it.x);
@@ -943,7 +947,7 @@ static int bin_points(gsx_ctx *ctx, const float *x, const float *y, const float 
 }
 
 int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
-                    int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info)
+                    int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info, int share, int nshares)
 {
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
@@ -984,7 +988,7 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        ctx->bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, gp);
+                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, gp);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, rstart, refs));
     const float4 *qpts = refs;

@@ -14,6 +14,7 @@ struct GridParams {
     int bk_cells;        // cells per bucket = bk_g * bk_g * nx
     int nbx, nby, nbz;
     int nbricks;
+    int part_lo, part_hi;  // bricks [part_lo, part_hi) are this call's share (multi-GPU: one share per rank)
     int bdx, bdy, bdz;  // brick size in cells: (2,2,2), (2,2,1), (2,1,1) or (1,1,1)
     int debug_skip;     // profiling only (results become wrong): 1 = skip phase 2, 2 = skip phase 1, 4 = skip epilogue
     float tau1;      // f32 filter bound for r1sq

@@ -1,19 +1,24 @@
-"""Multi-GPU SOR: one process per GPU, splats sharded BY INDEX, RCCL over xGMI.
+"""Multi-GPU SOR: one process per GPU, RCCL over xGMI.
 
 The reference is single-process; this is the MI355X-native scale-out of
-its SOR path.  Rank r owns the contiguous index range
-[r*n_local, (r+1)*n_local) of the cloud, resident in its own HBM as (n_local,3) rows.
+its SOR path.  Rank r holds the contiguous index range
+[r*n_local, (r+1)*n_local) of the cloud in its own HBM as (n_local,3) rows (how a loader would
+hand out a file), and gets the survivor mask of exactly that range back.
 
 One step:
-  1. all-gather of the xyz rows  -> every GPU holds the full reference set (the only data
-     every query needs); torch.distributed backend "nccl" IS RCCL on ROCm;
-  2. each GPU bins the full set and computes exact KNN mean distances for ITS queries only
-     (gsx_sor_knn_dev with q_begin/q_count) -- no collective inside the kernel path;
-  3. all-gather of the f32 mean distances (4 B/splat).  NOT an all-reduce of partial
-     sums: the reference's threshold is numpy's pairwise f32 mean/std over the WHOLE array,
-     whose rounding depends on the global element order (8192-element pieces), so every
-     rank evaluates the statistics redundantly and bit-exactly on the gathered array;
-  4. mask of the local shard against the (identical on every rank) threshold.
+  1. all-gather of the xyz rows -> every GPU holds the full reference set (the only data every
+     query needs); torch.distributed backend "nccl" IS RCCL on ROCm;
+  2. every GPU bins the full set (identical grid on every rank) and computes exact KNN mean
+     distances for its SHARE OF THE GRID'S BRICKS -- a spatial slab, gsx_sor_knn_share_dev --
+     writing them at their original indices of a zero-filled n_total array.  (Sharing out the
+     QUERIES BY INDEX instead leaves every brick with 1/world of its lanes live: measured on one
+     GPU, 1/8 of the queries of an 8M cloud cost as much as all of them.)
+  3. sum all-reduce of that array: every entry has exactly one non-zero contributor, so the
+     sum is exact and every rank now holds the f32 mean distances of the whole cloud.  NOT an
+     all-reduce of partial STATISTICS: the reference's threshold is numpy's pairwise f32
+     mean/std over the whole array, whose rounding depends on the global element order
+     (8192-element pieces), so every rank evaluates it redundantly and bit-exactly;
+  4. mask of the local index range against the (identical on every rank) threshold.
 
 torch is only plumbing here (device memory, streams, the process group).  The compute
 callables are injectable so that the choreography can be exercised on CPU with the gloo
@@ -50,6 +55,15 @@ class HipCompute:
         out = t.empty(q_count, dtype=t.float32, device=xyz_all.device)
         base = xyz_all.data_ptr()
         self.ctx.sor_knn(base, base + 4, base + 8, 3, xyz_all.shape[0], q_begin, q_count, k, out.data_ptr(), algo=algo)
+        return out
+
+    def knn_share(self, xyz_all, k: int, share: int, nshares: int, algo: int = 0):
+        """f32[n_total]: this share's mean distances at their original indices, +0.0 elsewhere."""
+        t = self.torch
+        assert xyz_all.is_contiguous() and xyz_all.dtype == t.float32 and xyz_all.shape[1] == 3
+        out = t.empty(xyz_all.shape[0], dtype=t.float32, device=xyz_all.device)
+        base = xyz_all.data_ptr()
+        self.ctx.sor_knn_share(base, base + 4, base + 8, 3, xyz_all.shape[0], k, share, nshares, out.data_ptr(), algo=algo)
         return out
 
     def stats(self, md_all, threshold_factor: float):
@@ -90,12 +104,12 @@ def sharded_sor(xyz_local, k: int, threshold_factor: float, compute, group=None,
         dist.all_gather_into_tensor(xyz_all, xyz_local.contiguous(), group=group)
     else:
         xyz_all = xyz_local.contiguous()
-    md_local = compute.knn(xyz_all, rank * n_local, n_local, k, algo)
     if world > 1:
-        md_all = torch.empty(world * n_local, dtype=md_local.dtype, device=md_local.device)
-        dist.all_gather_into_tensor(md_all, md_local, group=group)
+        md_all = compute.knn_share(xyz_all, k, rank, world, algo)
+        dist.all_reduce(md_all, op=dist.ReduceOp.SUM, group=group)
+        md_local = md_all[rank * n_local:(rank + 1) * n_local].clone()  # own, aligned storage for the mask kernel
     else:
-        md_all = md_local
+        md_all = md_local = compute.knn(xyz_all, 0, n_local, k, algo)
     stats = compute.stats(md_all, threshold_factor)
     mask = compute.mask(md_local, stats)
     return ShardedSorResult(mask, md_local, stats, world * n_local)

@@ -100,6 +100,18 @@ int gsx_sor_knn_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z
                     int64_t n_ref, int64_t q_begin, int64_t q_count, int k, int algo,
                     float *mean_out_dev, gsx_sor_info *info /* nullable; forces a sync if given */);
 /*
+ * Multi-GPU building block: the same KNN over the whole cloud of n points, but
+ * only for the queries of share `share` of `nshares`.  The reference already treats queries as
+ * independent units -- data_processor.py:167-173 loops over 50 000-query chunks of one tree --
+ * here a share is a contiguous range of the grid's bricks, i.e. a spatial slab (an index range
+ * for the brute-force algorithm).  mean_out_dev has n entries in ORIGINAL order: the share's
+ * queries are written, every other entry is set to +0.0f, so the shares of all ranks combine
+ * with one sum all-reduce into exactly what gsx_sor_knn_dev computes for q = [0, n).
+ */
+int gsx_sor_knn_share_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
+                          int64_t n, int k, int algo, int share, int nshares, float *mean_out_dev,
+                          gsx_sor_info *info /* nullable; forces a sync if given */);
+/*
  * np.mean / np.std / threshold -- replaces data_processor.py:176-178 and
  * gpu_ops.py:259-261 with numpy's exact float32 arithmetic (8192-element buffered
  * pairwise sums, float64 division).  stats_dev[0..2] = mean, std, threshold.

@@ -1,5 +1,6 @@
-"""-m "not gpu": the multi-GPU choreography (index-sharded queries, all-gather of xyz, all-gather of
-mean distances, redundant exact statistics) on CPU with the gloo backend, world_size 2 and 3.
+"""-m "not gpu": the multi-GPU choreography (all-gather of xyz, one share of the queries per rank written
+into a zero-filled full-length array, sum all-reduce, redundant exact statistics, mask of the local
+index range) on CPU with the gloo backend, world_size 2 and 3.
 The compute callables are the oracle here (tests only); on the GPU they are the C ABI."""
 import os
 import socket
@@ -25,6 +26,20 @@ class OracleCompute:
         from oracle import sor as osor
         md = osor.mean_dists_ckdtree(xyz_all.numpy(), k, workers=2)
         return torch.from_numpy(md[q_begin:q_begin + q_count].copy())
+
+    def knn_share(self, xyz_all, k, share, nshares, algo=0):
+        # any partition of the queries works for the choreography; like the GPU one this is
+        # spatial (slabs along z), i.e. scattered in index space
+        import torch
+        from oracle import sor as osor
+        xyz = xyz_all.numpy()
+        md = osor.mean_dists_ckdtree(xyz, k, workers=2)
+        order = np.argsort(xyz[:, 2], kind="stable")
+        n = len(xyz)
+        mine = order[n * share // nshares: n * (share + 1) // nshares]
+        out = np.zeros(n, np.float32)
+        out[mine] = md[mine]
+        return torch.from_numpy(out)
 
     def stats(self, md_all, factor):
         import torch

@@ -106,6 +106,41 @@ def test_query_subrange_device_api(gsx, lib, algo):
     ctx.close()
 
 
+@pytest.mark.parametrize("algo,n,k,nshares", [(GRID, 200000, 16, 8), (GRID, 60000, 32, 3), (GRID, 5000, 8, 5),
+                                              (BRUTE, 3000, 16, 4), (GRID, 40000, 16, 1)])
+def test_query_shares_sum_to_the_whole(lib, algo, n, k, nshares):
+    """multi-GPU building block: the per-rank shares (spatial slabs of bricks) are disjoint, cover every
+    query, leave +0.0 elsewhere, and their plain f32 sum is bit-identical to the unsharded result"""
+    xyz = datasets.uniform(n, 10.0, 77) if n != 60000 else datasets.clustered(n, 5)
+    ref = osor.mean_dists_ckdtree(xyz, k)
+    ctx = lib.Context(0)
+    cols = [np.ascontiguousarray(xyz[:, a]) for a in range(3)]
+    d = [ctx.alloc(4 * n).upload(c) for c in cols]
+    out = ctx.alloc(4 * n)
+    total = np.zeros(n, np.float32)
+    owners = np.zeros(n, np.int32)
+    sizes = []
+    for share in range(nshares):
+        out.upload(np.full(n, np.nan, np.float32))  # the call must overwrite everything
+        ctx.sor_knn_share(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, k, share, nshares, out.ptr, algo=algo)
+        got = out.download(np.float32, n)
+        assert np.isfinite(got).all()
+        mine = got != 0
+        assert not np.signbit(got[~mine]).any()  # +0.0, not -0.0
+        owners += mine
+        sizes.append(int(mine.sum()))
+        total = total + got  # what the sum all-reduce does
+    zero_ref = int((ref == 0).sum())  # exact duplicates k+1 deep would have mean 0 (none in these clouds)
+    assert zero_ref == 0
+    assert (owners == 1).all(), (sizes, int((owners != 1).sum()))
+    assert _explain(total, ref) == "ok", sizes
+    if algo == GRID and n >= 200000:
+        assert max(sizes) < 1.25 * n / nshares, sizes  # slabs of a uniform cloud are balanced
+    for a in d + [out]:
+        a.free()
+    ctx.close()
+
+
 def test_stats_kernel_matches_numpy(lib):
     """gsx_sor_stats_dev == np.mean / np.std / threshold, bit for bit, at ragged sizes"""
     rng = np.random.default_rng(9)

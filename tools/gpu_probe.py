@@ -57,6 +57,39 @@ def host_level(xyz, k, label):
     print("%-28s n=%9d k=%2d host->host %.3f ms  %.1f Msplat/s (PCIe inclusive)" % (label, len(xyz), k, dt * 1e3, len(xyz) / dt / 1e6), flush=True)
 
 
+def shares():
+    """What one rank of an N-GPU weak-scaling step computes (N x 1M splats gathered, 1/N of the queries):
+    index range of queries (round-1 first design) vs share of the grid's bricks (gsx_sor_knn_share_dev)."""
+    ctx = L.Context(0)
+    for world in (1, 2, 4, 8):
+        n = world * 1_000_000
+        xyz = uniform(n, 10.0 * world ** (1.0 / 3.0))
+        cols = [np.ascontiguousarray(xyz[:, a]) for a in range(3)]
+        d = [ctx.alloc(4 * n).upload(c) for c in cols]
+        out = ctx.alloc(4 * n)
+        nq = n // world
+        for mode in ("index", "share"):
+            def step():
+                if mode == "index":
+                    ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, 3 * nq % n if world > 3 else 0, nq, 16, out.ptr, algo=2)
+                else:
+                    ctx.sor_knn_share(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, 16, world // 2, world, out.ptr, algo=2)
+            step()
+            ctx.set_timing(True); ctx.reset_timing(); ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / 3 * 1e3
+            slots = {name: ctx.timing(i) for i, name in enumerate(["knn", "bin", "fallback", "stats"])}
+            ctx.set_timing(False)
+            print("world=%d n_total=%8d mode=%-5s per-rank compute %.3f ms | %s" % (
+                world, n, mode, wall, " ".join("%s=%.3f" % (k_, v[1] / 3) for k_, v in slots.items())), flush=True)
+        for a in d + [out]:
+            a.free()
+    ctx.close()
+
+
 def ablate():
     ctx = L.Context(0)
     x10 = uniform(10_000_000, 5.0)
@@ -86,6 +119,8 @@ def sweep():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         return ablate()
+    if len(sys.argv) > 1 and sys.argv[1] == "shares":
+        return shares()
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         return sweep()
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
