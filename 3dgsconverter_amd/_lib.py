@@ -52,6 +52,8 @@ SIGNATURES = {
     "gsx_dev_free": (_I, [_P, _P]),
     "gsx_dev_upload": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
+    "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_knn_share_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
@@ -133,6 +135,42 @@ def _xyz_pointers(xyz_or_cols):
         raise ValueError("Requires 3D data")  # same message as gpu_ops.py:198
     base = a.ctypes.data
     return a, base, base + 4, base + 8, 3, a.shape[0]
+
+
+def host_gather_xyz(vertices: np.ndarray, names=("x", "y", "z")) -> np.ndarray:
+    """coords = np.column_stack((v['x'], v['y'], v['z'])) (data_processor.py:38,139) as float32 (N,3),
+    threaded (C ABI gsx_host_gather_f32).  Any layout the C routine cannot take goes through numpy."""
+    fields = vertices.dtype.fields or {}
+    ok = (vertices.ndim == 1 and vertices.flags.c_contiguous and
+          all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names))
+    if not ok:
+        return np.column_stack([np.asarray(vertices[nm], dtype=np.float32) for nm in names])
+    n = len(vertices)
+    out = np.empty((n, len(names)), dtype=np.float32)
+    if n == 0:
+        return out
+    offs = (_I64 * len(names))(*[int(fields[nm][1]) for nm in names])
+    check(load().gsx_host_gather_f32(vertices.ctypes.data, vertices.dtype.itemsize, n, offs, len(names), out.ctypes.data),
+          "gsx_host_gather_f32")
+    return out
+
+
+def host_compact_rows(rows: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """rows[mask] (data_processor.py:114,149) for a 1-D array of any (structured) dtype, threaded
+    (C ABI gsx_host_compact_rows).  Same result as numpy's boolean indexing: a new array, order kept."""
+    mask = np.asarray(mask)
+    if rows.ndim != 1 or mask.shape != rows.shape or mask.dtype != np.bool_ or rows.dtype.hasobject:
+        return rows[mask]
+    src = np.ascontiguousarray(rows)
+    m8 = np.ascontiguousarray(mask).view(np.uint8)
+    keep = int(np.count_nonzero(m8))
+    out = np.empty(keep, dtype=rows.dtype)
+    n_out = _I64()
+    if len(src):
+        check(load().gsx_host_compact_rows(src.ctypes.data, src.dtype.itemsize, len(src), m8.ctypes.data, out.ctypes.data,
+                                           keep, C.byref(n_out)), "gsx_host_compact_rows")
+        assert n_out.value == keep
+    return out
 
 
 def sor_filter(xyz, k: int, threshold_factor: float, algo: int = KNN_AUTO, want_mean: bool = True,

@@ -52,10 +52,9 @@ def _reference_class():
     return _REFERENCE_CLASS
 
 
-def _xyz_columns(vertices):
-    return (np.ascontiguousarray(vertices["x"], dtype=np.float32),
-            np.ascontiguousarray(vertices["y"], dtype=np.float32),
-            np.ascontiguousarray(vertices["z"], dtype=np.float32))
+def _xyz_rows(vertices):
+    """reference :38/:139 `coords` -- (N,3) float32, gathered from the AoS table by the threaded C routine"""
+    return _lib.host_gather_xyz(vertices)
 
 
 class DataProcessor:
@@ -76,9 +75,9 @@ class DataProcessor:
         if num_points == 0:
             return self.data
         status_print("[SOR] Determining outliers on GPU (HIP gfx950, exact KNN)...")
-        res = _lib.sor_filter(_xyz_columns(vertices), int(k), float(threshold_factor), want_mean=False)
+        res = _lib.sor_filter(_xyz_rows(vertices), int(k), float(threshold_factor), want_mean=False)
         self.last_sor = {"mean": res["mean"], "std": res["std"], "threshold": res["threshold"]}
-        self.data = vertices[res["mask"]]
+        self.data = _lib.host_compact_rows(vertices, res["mask"])  # reference :149
         status_print(f"After removing flyers (GPU), retained {len(self.data)} out of {num_points} vertices.")
         return self.data
 
@@ -100,7 +99,7 @@ class DataProcessor:
             status_print("Warning: Density filter removed all points.")
             self.data = self.data[:0]
             return self.data
-        cols = _xyz_columns(vertices)
+        cols = _xyz_rows(vertices)
         occ = _lib.density_voxels(cols, float(voxel_size), min_points)
         debug_print(f"[DEBUG] Found {occ['n_unique']} unique voxels.")
         if len(occ["dense_keys"]) == 0:
@@ -114,7 +113,7 @@ class DataProcessor:
             return self.data
         kept_keys = np.array(sorted(kept), dtype=np.int64).reshape(-1, 3)
         mask = _lib.density_mask(cols, float(voxel_size), kept_keys)
-        self.data = vertices[mask]
+        self.data = _lib.host_compact_rows(vertices, mask)  # reference :114
         status_print(f"Density Filter: Kept {kept_clusters} clusters (largest: {max_len} voxels).")
         status_print(f"After density filter, retained {len(self.data)} out of {len(vertices)} vertices.")
         return self.data

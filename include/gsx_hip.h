@@ -88,6 +88,22 @@ int gsx_dev_free(gsx_ctx *ctx, void *dptr);
 int gsx_dev_upload(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
+/* ---- Host-side row operations around every filter -- */
+/*
+ * out[r*ncols + c] = *(float*)((char*)rows + r*row_bytes + offsets[c]) -- replaces
+ * data_processor.py:38,139 (np.column_stack of the x,y,z fields of the structured array).
+ * Threaded; rows are opaque bytes.
+ */
+int gsx_host_gather_f32(const void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets,
+                        int ncols, float *out);
+/*
+ * Stable compaction of the rows with mask[r] != 0 -- replaces data_processor.py:114,149
+ * (self.data = vertices[mask]).  out must hold out_rows rows; *n_out = number of survivors
+ * (error if it exceeds out_rows).  Threaded.
+ */
+int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *mask,
+                          void *out, int64_t out_rows, int64_t *n_out);
+
 /* ---- Statistical Outlier Removal --------------------------------------- */
 /*
  * KNN mean distance -- replaces data_processor.py:156-173 (cKDTree build + chunked

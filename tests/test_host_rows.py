@@ -1,0 +1,82 @@
+"""-m "not gpu": the threaded host row operations of the C ABI (gsx_host_gather_f32, gsx_host_compact_rows)
+against the numpy expressions of the reference they replace (data_processor.py:38,139 column_stack;
+:114,149 vertices[mask]).  Byte-exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+gsx = importlib.import_module("3dgsconverter_amd")
+L = gsx._lib
+
+
+def _table(n, with_rgb=False, seed=0):
+    names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] \
+        + ["opacity"] + ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)]
+    fields = [(nm, "<f4") for nm in names]
+    if with_rgb:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]  # 251-byte rows: nothing is aligned
+    dt = np.dtype(fields)
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 255, size=(n, dt.itemsize), dtype=np.uint8)
+    raw[:, 3::4] &= 0x3F  # keep the float fields finite (exponent < 255)
+    return raw.reshape(-1).view(dt)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 1000, 300_001])
+@pytest.mark.parametrize("with_rgb", [False, True])
+def test_gather_equals_column_stack(n, with_rgb):
+    v = _table(n, with_rgb, seed=n)
+    got = L.host_gather_xyz(v)
+    ref = np.column_stack((v["x"], v["y"], v["z"]))
+    assert got.dtype == np.float32 and got.shape == (n, 3) and got.flags.c_contiguous
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_gather_other_layouts_go_through_numpy():
+    v = _table(1000)[::2]  # not contiguous
+    assert L.host_gather_xyz(v).tobytes() == np.column_stack((v["x"], v["y"], v["z"])).tobytes()
+    dt = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8")])
+    w = np.zeros(10, dt)
+    w["x"] = np.arange(10)
+    assert L.host_gather_xyz(w).dtype == np.float32 and (L.host_gather_xyz(w)[:, 0] == np.arange(10)).all()
+
+
+@pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (1, 0.0), (1000, 0.5), (300_001, 0.85), (300_001, 0.0), (300_001, 1.0),
+                                 (2_000_003, 0.03)])
+@pytest.mark.parametrize("with_rgb", [False, True])
+def test_compaction_equals_boolean_indexing(n, p, with_rgb):
+    v = _table(min(n, 300_001), with_rgb, seed=n)
+    if n > len(v):
+        v = np.resize(v, n)
+    mask = np.random.default_rng(n + 1).random(n) < p
+    got = L.host_compact_rows(v, mask)
+    ref = v[mask]
+    assert got.dtype == v.dtype and got.shape == ref.shape
+    assert got.tobytes() == ref.tobytes()
+    assert got.base is None or got.base is not v  # a new array, like numpy's
+
+
+def test_compaction_runs_and_plain_dtypes():
+    a = np.arange(100_000, dtype=np.int64)
+    mask = np.zeros(len(a), bool)
+    mask[10:5000] = True
+    mask[-3:] = True
+    mask[50_000] = True
+    np.testing.assert_array_equal(L.host_compact_rows(a, mask), a[mask])
+    b = np.arange(12, dtype=np.float32).reshape(4, 3)  # not 1-D: numpy semantics
+    np.testing.assert_array_equal(L.host_compact_rows(b, np.array([1, 0, 1, 1], bool)), b[np.array([1, 0, 1, 1], bool)])
+
+
+def test_c_abi_rejects_bad_arguments():
+    lib = L.load()
+    import ctypes as C
+    n_out = C.c_int64()
+    rows = np.zeros(16, np.uint8)
+    mask = np.ones(4, np.uint8)
+    out = np.zeros(8, np.uint8)
+    assert lib.gsx_host_compact_rows(rows.ctypes.data, 4, 4, mask.ctypes.data, out.ctypes.data, 2, C.byref(n_out)) != 0
+    assert b"do not fit" in lib.gsx_last_error()
+    offs = (C.c_int64 * 1)(2)
+    assert lib.gsx_host_gather_f32(rows.ctypes.data, 4, 4, offs, 1, out.ctypes.data) != 0
+    assert b"outside the row" in lib.gsx_last_error()

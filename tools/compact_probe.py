@@ -1,0 +1,12 @@
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gsx = importlib.import_module("3dgsconverter_amd"); L = gsx._lib
+n = 10_000_000
+dt = np.dtype([("f%d" % i, "f4") for i in range(62)])
+data = np.zeros(n, dt); data["f0"] = np.arange(n)
+mask = np.random.default_rng(0).random(n) < 0.85
+print("thp:", open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip())
+for rep in range(4):
+    t0 = time.perf_counter(); out = L.host_compact_rows(data, mask); dtm = time.perf_counter() - t0
+    print("compact %.1f ms" % (dtm * 1e3), len(out)); del out
