@@ -94,7 +94,8 @@ extern "C" int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_
     char *dst = static_cast<char *>(out);
     {
         // the output is a fresh allocation: ask for huge pages before first touch (a hint; ignored
-        // where transparent huge pages are off) -- 4 KiB faults otherwise cost as much as the copy
+        // where transparent huge pages are off) -- 4 KiB first-touch faults otherwise dominate: 87 ->
+        // 16 ms for 10M x 248 B on the MI355X host.  (MADV_POPULATE_WRITE per thread was worse: 68 ms.)
         const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
         const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + (size_t)cnt[nt] * (size_t)row_bytes) & ~(uintptr_t)((2u << 20) - 1);
         if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);

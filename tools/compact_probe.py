@@ -7,6 +7,18 @@ dt = np.dtype([("f%d" % i, "f4") for i in range(62)])
 data = np.zeros(n, dt); data["f0"] = np.arange(n)
 mask = np.random.default_rng(0).random(n) < 0.85
 print("thp:", open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip())
+def bench(tag):
+    for rep in range(3):
+        t0 = time.perf_counter(); out = L.host_compact_rows(data, mask); dtm = time.perf_counter() - t0
+        print(tag, "compact %.1f ms" % (dtm * 1e3), len(out)); del out
+bench("before HIP init:")
+ctx = L.Context(0)
+bench("after HIP init: ")
+keepalive = []
+for rep in range(8):
+    t0 = time.perf_counter(); out = L.host_compact_rows(data, mask); dtm = time.perf_counter() - t0
+    print("holding previous outputs: compact %.1f ms" % (dtm * 1e3)); keepalive.append(out)
+sys.exit(0)
 for rep in range(4):
     t0 = time.perf_counter(); out = L.host_compact_rows(data, mask); dtm = time.perf_counter() - t0
     print("compact %.1f ms" % (dtm * 1e3), len(out)); del out

@@ -40,6 +40,14 @@ def main(n=10_000_000):
         t("native compaction (threads)", lambda: L.host_compact_rows(data, mask))
     import importlib as il
     dp = il.import_module("3dgsconverter_amd.processing")
+    rows = L.host_gather_xyz(data)
+    occ = t("gsx_density_voxels host->host ((N,3) rows in)", lambda: L.density_voxels(rows, 1.1, 55000))
+    kk = occ["dense_keys"]
+    t("gsx_density_mask host->host", lambda: L.density_mask(rows, 1.1, kk))
+    t("gsx_sor_filter host->host ((N,3) rows in)", lambda: L.sor_filter(rows, 16, 1.0, want_mean=False))
+    p0 = dp.DataProcessor(data)
+    t("DataProcessor.apply_density_filter(s=0.5)", lambda: dp.DataProcessor(data).apply_density_filter(sensitivity=0.5), reps=2)
+    t("DataProcessor.remove_flyers(16, 1.0)", lambda: dp.DataProcessor(data).remove_flyers(16, 1.0), reps=2)
     def chain():
         p = dp.DataProcessor(data)
         p.apply_density_filter(sensitivity=0.5)
