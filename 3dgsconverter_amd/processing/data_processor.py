@@ -118,9 +118,42 @@ class DataProcessor:
         status_print(f"After density filter, retained {len(self.data)} out of {len(vertices)} vertices.")
         return self.data
 
+    # ------------------------------------------------------------------ O(N) row filters
+    # Same masks as the reference, computed by the same numpy expressions; only `self.data[mask]`
+    # -- 1.2 s per call at 10M splats in numpy -- goes through the threaded C compaction.
+    def apply_alpha_filter(self, min_opacity_u8):
+        """reference :184-213"""
+        debug_print(f"[DEBUG] Executing 'apply_alpha_filter' with min={min_opacity_u8}")
+        if 'opacity' not in self.data.dtype.names:
+            status_print("Warning: No opacity channel found. Alpha filter skipped.")
+            return
+        limit = min_opacity_u8
+        if limit <= 0:
+            return
+        if limit >= 255:
+            self.data = self.data[:0]
+            return
+        alpha_thresh = np.clip(limit / 255.0, 1e-6, 1.0 - 1e-6)
+        logit_thresh = np.log(alpha_thresh / (1.0 - alpha_thresh))
+        mask = self.data['opacity'] >= logit_thresh
+        original_len = len(self.data)
+        self.data = _lib.host_compact_rows(self.data, mask)
+        status_print(f"Alpha Filter (min {limit}): Retained {len(self.data)} out of {original_len} splats.")
+        return self.data
+
+    def crop_by_bbox(self, min_x, min_y, min_z, max_x, max_y, max_z):
+        """reference :215-231"""
+        d = self.data
+        mask = ((d['x'] >= min_x) & (d['x'] <= max_x) & (d['y'] >= min_y) & (d['y'] <= max_y) &
+                (d['z'] >= min_z) & (d['z'] <= max_z))
+        self.data = _lib.host_compact_rows(d, mask)
+        debug_print(f"[DEBUG] Number of vertices after cropping: {len(self.data)}")
+        status_print(f"After cropping, retained {len(self.data)} vertices.")
+        return self.data
+
     # ------------------------------------------------------------------ everything else: not on the hot path
     def __getattr__(self, name):
-        # apply_alpha_filter, crop_by_bbox, calculate_rgb..., cap_sh_degree, apply_auto_bbox (reference :184-354)
+        # add_rgb_from_sh, cap_sh_degree, apply_auto_bbox, ... (reference :233-354)
         if name.startswith("__"):
             raise AttributeError(name)
         try:

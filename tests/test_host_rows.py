@@ -80,3 +80,32 @@ def test_c_abi_rejects_bad_arguments():
     offs = (C.c_int64 * 1)(2)
     assert lib.gsx_host_gather_f32(rows.ctypes.data, 4, 4, offs, 1, out.ctypes.data) != 0
     assert b"outside the row" in lib.gsx_last_error()
+
+
+def test_alpha_and_bbox_filters_match_the_reference_expressions():
+    """DataProcessor.apply_alpha_filter / crop_by_bbox (reference data_processor.py:184-231): same masks,
+    threaded compaction"""
+    dp = importlib.import_module("3dgsconverter_amd.processing")
+    v = _table(50_000, seed=3)
+    rng = np.random.default_rng(4)
+    v["opacity"] = rng.normal(0, 3, len(v)).astype(np.float32)
+    for nm in "xyz":
+        v[nm] = rng.normal(0, 2, len(v)).astype(np.float32)
+    for limit in (1, 13, 128, 254):
+        a = np.clip(limit / 255.0, 1e-6, 1.0 - 1e-6)
+        ref = v[v["opacity"] >= np.log(a / (1.0 - a))]
+        p = dp.DataProcessor(v)
+        out = p.apply_alpha_filter(limit)
+        assert out is p.data and out.tobytes() == ref.tobytes()
+    p = dp.DataProcessor(v)
+    assert p.apply_alpha_filter(0) is None and p.data is v
+    p.apply_alpha_filter(255)
+    assert len(p.data) == 0 and p.data.dtype == v.dtype
+    box = (-1.0, -2.0, -0.5, 1.5, 2.0, 3.0)
+    ref = v[(v["x"] >= box[0]) & (v["x"] <= box[3]) & (v["y"] >= box[1]) & (v["y"] <= box[4]) &
+            (v["z"] >= box[2]) & (v["z"] <= box[5])]
+    p = dp.DataProcessor(v)
+    assert p.crop_by_bbox(*box).tobytes() == ref.tobytes() and 0 < len(ref) < len(v)
+    w = np.zeros(5, np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4")]))
+    p = dp.DataProcessor(w)
+    assert p.apply_alpha_filter(10) is None and p.data is w  # no opacity channel: skipped with a warning
