@@ -200,6 +200,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->brute_below = (int64_t)value;
     } else if (!strcmp(name, "debug_skip")) {
         c->debug_skip = (int)value;
+    } else if (!strcmp(name, "filter_mfma")) {
+        c->filter_mfma = value != 0.0;
     } else {
         GSX_FAIL("gsx_ctx_set_param: unknown parameter '%s'", name);
     }

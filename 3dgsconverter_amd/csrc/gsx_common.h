@@ -71,6 +71,7 @@ struct gsx_ctx {
     double grid_points_per_cell = 0.0;  // 0 = auto: 0.47 * (k + 1), see launch_knn_grid
     int64_t brute_below = 2048;
     int debug_skip = 0;  // profiling ablations of knn_brick (never set by the product path)
+    int filter_mfma = 0; // knn_brick phase 1: 0 = scalar-load f32 VALU filter (default), 1 = bf16-split MFMA filter
 
     // SOR workspace
     gsx::DevBuf packed;      // float4[n_ref]  (brute: original order; grid: cell-sorted refs)

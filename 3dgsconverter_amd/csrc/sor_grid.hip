@@ -52,6 +52,109 @@ __device__ __forceinline__ unsigned shift_in_lt(unsigned m, float qx, float qy, 
     return __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);
 }
 
+// ---- MFMA phase-1 filter (knn_brick<.., MF=true>) ------------------------------------------------
+// d2 - tau for 32 candidates x 32 queries is ONE v_mfma_f32_32x32x16_bf16: with coordinates taken
+// relative to the brick centre in CELL units (|u| <= ~2), every f32 value is split into bf16 pieces
+// (v = vh + vl, |v - vh - vl| <= 2^-18 |v|) and the K = 16 slots hold
+//     -2 p.q  ~  sum_c  ph_c*(-2 qh_c) + ph_c*(-2 ql_c) + pl_c*(-2 qh_c)          (9 slots)
+//     |p|^2   =  n1 + n2 + n3 (three bf16 pieces) times 1                          (3 slots)
+//     |q|^2 - tau - slack = s1 + s2 + s3, times 1                                  (3 slots, 1 spare)
+// bf16 x bf16 products are exact in the f32 accumulator.  Error of the accumulated value against
+// the true (d2 - tau), in cell units^2: dropped pl*ql and split residuals <= 2*3*3*2^-18*|p||q|
+// <= 1.4e-4, recentring + norm roundings <= 1e-5, 16 f32 accumulations of partial sums <= ~30:
+// <= 1e-4 even at 4 ulp each -- together < 3e-4.  MF_SLACK = 1e-3 (cell units^2, i.e. 0.05 % of the
+// radius at r ~ 1 cell) makes the filter conservative: every candidate with d2 <= tau sets its bit;
+// the few extra ones are discarded by the exact float64 phase 2 as before.
+// Lane layout (measured, tools/ubench/mfma_layout.hip): A/B lane l holds row/col l&31, k =
+// 8*(l>>5)+0..7; D lane l holds col l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5) for r in [0,16).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr float MF_SLACK = 1e-3f;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)  // RNE, lo -> bits 0..15
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// The sign bits come out of the accumulators in the order pos -> tile row (pos&3) + 8*((pos>>2)&3) +
+// 4*(pos>>4) (pos 0 = most significant mask bit).  Tile row r is therefore loaded with candidate
+// mf_cand_of_row(r), the inverse permutation, and mask bit 31-i means candidate i of the word exactly as
+// in the scalar filter.
+__host__ __device__ constexpr int mf_cand_of_row(int r) { return (r & 3) | (((r >> 3) & 3) << 2) | (((r >> 2) & 1) << 4); }
+
+// the K-slices of one candidate (cell-unit coordinates relative to the brick centre)
+__device__ __forceinline__ bf16x8 mf_candidate_operand(float ux, float uy, float uz, bool upper)
+{
+    const unsigned l0 = cvt_pk_bf16(ux, ux);       // (ph_x, ph_x)
+    const float lx = ux - bf_lo(l0);
+    const unsigned l1 = cvt_pk_bf16(lx, uy);       // (pl_x, ph_y)
+    const float ly = uy - bf_hi(l1);
+    const unsigned l2 = cvt_pk_bf16(uy, ly);       // (ph_y, pl_y)
+    const unsigned l3 = cvt_pk_bf16(uz, uz);       // (ph_z, ph_z)
+    const float lz = uz - bf_lo(l3);
+    const float n = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    const unsigned u0 = cvt_pk_bf16(lz, n);        // (pl_z, n1)
+    const float r1 = n - bf_hi(u0);
+    const unsigned t = cvt_pk_bf16(r1, r1);
+    const float r2 = r1 - bf_lo(t);
+    const unsigned u1 = cvt_pk_bf16(r1, r2);       // (n2, n3)
+    u32x4 w;
+    w.x = upper ? u0 : l0;
+    w.y = upper ? u1 : l1;
+    w.z = upper ? 0x3f803f80u : l2;                // (1, 1)
+    w.w = upper ? 0x00003f80u : l3;                // (1, 0)
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// the query's K-slices for both tiles: out_a = operand of the tile whose columns are queries
+// 0..31 (lanes 0..31), out_b = queries 32..63.  s = |q|^2 - tau - slack (+1e30 for a dead lane).
+__device__ __forceinline__ void mf_query_operands(float ux, float uy, float uz, float s, bf16x8 &out_a, bf16x8 &out_b)
+{
+    const unsigned hx = cvt_pk_bf16(ux, uy);       // (qh_x, qh_y)
+    const unsigned hz = cvt_pk_bf16(uz, uz);
+    const float hxf = bf_lo(hx), hyf = bf_hi(hx), hzf = bf_lo(hz);
+    const float lx = ux - hxf, ly = uy - hyf, lz = uz - hzf;
+    u32x4 lo, up;
+    lo.x = cvt_pk_bf16(-2.0f * hxf, -2.0f * lx);   // k0 k1
+    lo.y = cvt_pk_bf16(-2.0f * hxf, -2.0f * hyf);  // k2 k3
+    lo.z = cvt_pk_bf16(-2.0f * ly, -2.0f * hyf);   // k4 k5
+    lo.w = cvt_pk_bf16(-2.0f * hzf, -2.0f * lz);   // k6 k7
+    const unsigned t1 = cvt_pk_bf16(s, s);
+    const float r1 = s - bf_lo(t1);
+    const unsigned t2 = cvt_pk_bf16(r1, r1);
+    const float r2 = r1 - bf_lo(t2);
+    up.x = cvt_pk_bf16(-2.0f * hzf, 1.0f);         // k8 k9
+    up.y = 0x3f803f80u;                            // k10 k11
+    up.z = cvt_pk_bf16(s, r1);                     // k12 k13 = (s1, s2)
+    up.w = cvt_pk_bf16(r2, 0.0f);                  // k14 k15 = (s3, 0)
+    // tile A: lanes < 32 supply their own k0..7, lanes >= 32 the k8..15 of query (lane - 32);
+    // tile B: lanes < 32 the k0..7 of query (lane + 32), lanes >= 32 their own k8..15.
+    // v_permlane32_swap(x, y) exchanges x[32..63] with y[0..31]: one swap per dword makes both.
+    u32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto r = __builtin_amdgcn_permlane32_swap(lo[i], up[i], false, false);
+        a[i] = r[0];
+        b[i] = r[1];
+    }
+    out_a = __builtin_bit_cast(bf16x8, a);
+    out_b = __builtin_bit_cast(bf16x8, b);
+}
+
+// sign bits of the 16 accumulators -> bits 15..0 (register 0 first)
+__device__ __forceinline__ unsigned mf_sign_bits(const f32x16 &acc)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r]), 31);
+    return m;
+}
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -459,21 +562,29 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__re
 // of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
-constexpr int brick_min_waves(int kcap) { return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2)); }
+constexpr int brick_min_waves(int kcap, bool mf)
+{
+    // the MFMA filter keeps 16 accumulators + 12 operand registers live on top of the top-k list
+    return mf ? (kcap <= 17 ? 5 : (kcap <= 26 ? 3 : 2)) : (kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2)));
+}
 
-template <int KCAP, bool EXTRA>
-__global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_brick_kernel(
+template <int KCAP, bool EXTRA, bool MF>
+__global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_brick_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra)
 {
+    // the MFMA variant parks its query operands in LDS too: 22 words keep a workgroup under 32 KiB (5 per CU)
+    constexpr int WCAP = MF ? 22 : gsx::WCAP;
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
     __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
+    __shared__ u32x4 s_qop[MF ? BRICK_THREADS / 64 : 1][2][64];  // MFMA filter: the query operands of both tiles
 
     const int lane = lane_id();
     const int wv = uniform((int)(threadIdx.x >> 6));
     unsigned(*mask)[64] = s_mask[wv];
     unsigned *wbase = s_wbase[wv];
+    u32x4(*qop)[64] = s_qop[MF ? wv : 0];
 
     const int nx = gp->nx, ny = gp->ny, nz = gp->nz;
     const int nbx = gp->nbx, nby = gp->nby;
@@ -682,6 +793,78 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
             };
 
             // ---- phase 1: lock-step filter over the 16 candidate rows
+            if constexpr (MF) {
+                // cell-unit coordinates relative to the brick centre; see the MFMA notes at the top
+                const float hf = (float)hp;
+                const float ccx = g_ox + ((float)(bx * bdx) + 0.5f * (float)bdx) * hf;
+                const float ccy = g_oy + ((float)(by * bdy) + 0.5f * (float)bdy) * hf;
+                const float ccz = g_oz + ((float)(bz * bdz) + 0.5f * (float)bdz) * hf;
+                const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
+                const float nq2 = __builtin_fmaf(uqz, uqz, __builtin_fmaf(uqy, uqy, uqx * uqx));
+                const bool upper = lane >= 32;
+                float tau_built = -2.0f;  // tau the operands were built for
+                // The candidate rows are walked as one flat sequence of 32-candidate words; the point
+                // of word n+1 is requested before word n is processed (a per-lane 16-B load takes
+                // ~1-2k cycles from L2/HBM, one word is ~300 cycles of work).
+                const int nrows = (dbg & 2) ? 0 : ncrows;
+                struct Word { int r, w0, gs, c; };  // wave-uniform
+                auto next_word = [&](Word w) __attribute__((always_inline)) {
+                    // advance to the next word of the current row or to the first word of the next non-empty row
+                    int r = w.r, w0 = w.w0 + 32;
+                    int len = r >= 0 && r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
+                    while (r < nrows && w0 >= len) {
+                        ++r;
+                        w0 = 0;
+                        len = r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
+                    }
+                    Word o;
+                    o.r = r;
+                    o.w0 = w0;
+                    o.gs = r < nrows ? __builtin_amdgcn_readlane(rs_start, r & 15) : 0;
+                    o.c = min(32, len - w0);
+                    return o;
+                };
+                const int my_cand = mf_cand_of_row(lane & 31);
+                auto fetch = [&](const Word &w) __attribute__((always_inline)) {
+                    return w.r < nrows ? refs[w.gs + w.w0 + min(my_cand, w.c - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                };
+                Word w_cur = next_word(Word{-1, 0, 0, 0});
+                float4 p_cur = fetch(w_cur);
+                while (w_cur.r < nrows) {
+                    const Word w_n1 = next_word(w_cur);
+                    const float4 p_n1 = fetch(w_n1);
+                    if (widx == WCAP) drain();
+                    if (__any(tau != tau_built)) {  // first word, and after a drain tightened some lane's tau
+                        // (tau * inv_h) * inv_h: no overflow for tiny cells.  ALL lanes rebuild: the
+                        // operands are exchanged between the two half-waves.
+                        const float s_q = tau >= 0.0f ? nq2 - ((tau * g_inv_h) * g_inv_h * (1.0f + 1e-6f) + MF_SLACK) : 1.0e30f;
+                        bf16x8 opa, opb;
+                        mf_query_operands(uqx, uqy, uqz, s_q, opa, opb);
+                        qop[0][lane] = __builtin_bit_cast(u32x4, opa);  // parked in LDS: 8 fewer live VGPRs,
+                        qop[1][lane] = __builtin_bit_cast(u32x4, opb);  // two ds_read_b128 per word
+                        tau_built = tau;
+                    }
+                    const bf16x8 cand = mf_candidate_operand((p_cur.x - ccx) * g_inv_h, (p_cur.y - ccy) * g_inv_h,
+                                                             (p_cur.z - ccz) * g_inv_h, upper);
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    // lane l: tile a = rows-set (l>>5) of query l&31, tile b = of query 32 + (l&31)
+                    const bf16x8 opa = __builtin_bit_cast(bf16x8, qop[0][lane]);
+                    const unsigned ma = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opa, zero, 0, 0, 0));
+                    const bf16x8 opb = __builtin_bit_cast(bf16x8, qop[1][lane]);
+                    const unsigned mb = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opb, zero, 0, 0, 0));
+                    auto sw = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
+                    // now sw[0] = rows-set 0, sw[1] = rows-set 1 of THIS lane's query; drop the bits of
+                    // the clamped duplicates past the end of a partial word
+                    const unsigned m = ((sw[0] << 16) | (sw[1] & 0xffffu)) & (0xffffffffu << (32 - w_cur.c));
+                    if (dbg & 64) atomicAdd(&gp->exhaustive_count, (unsigned)__builtin_popcount(m));  // profiling: candidates passed
+                    mask[widx][lane] = m;
+                    if (lane == 0) wbase[widx] = (unsigned)(w_cur.gs + w_cur.w0);
+                    nzw |= (m != 0 ? 1u : 0u) << widx;
+                    ++widx;
+                    w_cur = w_n1;
+                    p_cur = p_n1;
+                }
+            } else {
             for (int r = 0; r < ((dbg & 2) ? 0 : ncrows); ++r) {
                 const int gs = __builtin_amdgcn_readlane(rs_start, r);
                 const int len = __builtin_amdgcn_readlane(rs_len, r);
@@ -707,11 +890,13 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP)) void knn_bric
                         m = shift_in_lt(m, qx, qy, qz, P.x, P.y, P.z, neg_tau);
                     }
                     m <<= (32 - c);  // candidate i of this word <-> bit 31-i
+                    if (dbg & 64) atomicAdd(&gp->exhaustive_count, (unsigned)__builtin_popcount(m));  // profiling: candidates passed
                     mask[widx][lane] = m;
                     if (lane == 0) wbase[widx] = (unsigned)(gs + w0);
                     nzw |= (m != 0 ? 1u : 0u) << widx;
                     ++widx;
                 }
+            }
             }
             drain();
 
@@ -893,7 +1078,7 @@ static int grid_blocks(const gsx_ctx *ctx, int64_t n, int per_thread = 1)
     return (int)std::max<int64_t>(1, std::min(want, cap));
 }
 
-template <int KCAP>
+template <int KCAP, bool MF>
 static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, const unsigned *rstart,
                              const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
                              float *mean_out, unsigned *faillist, uint2 *extra)
@@ -903,17 +1088,17 @@ static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, c
     // workgroup would run its share only after a resident one has finished all of its own).
     static int occ_brick = 0, occ_extra = 0, occ_ring = 0;
     if (!occ_brick) {
-        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false>, BRICK_THREADS, 0));
-        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false, MF>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true, MF>, BRICK_THREADS, 0));
         GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ring, knn_ring_kernel<KCAP>, BRICK_THREADS, 0));
         occ_brick = std::max(1, std::min(occ_brick, 8));
         occ_extra = std::max(1, std::min(occ_extra, 8));
         occ_ring = std::max(1, std::min(occ_ring, 8));
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream, gp,
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false, MF>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream, gp,
                        refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream, gp,
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true, MF>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream, gp,
                        refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
@@ -1004,13 +1189,20 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     unsigned *fl = ctx->faillist.as<unsigned>();
     uint2 *ex = ctx->extraitems.as<uint2>();
     int rc;
+    const bool mf = ctx->filter_mfma != 0;
     // list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
-    if (kk <= 9) rc = launch_brick_ring<9>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 17) rc = launch_brick_ring<17>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 26) rc = launch_brick_ring<26>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 33) rc = launch_brick_ring<33>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 51) rc = launch_brick_ring<51>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else rc = launch_brick_ring<65>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    if (kk <= 9) rc = mf ? launch_brick_ring<9, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<9, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 17) rc = mf ? launch_brick_ring<17, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<17, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 26) rc = mf ? launch_brick_ring<26, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<26, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 33) rc = mf ? launch_brick_ring<33, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<33, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else if (kk <= 51) rc = mf ? launch_brick_ring<51, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<51, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
+    else rc = mf ? launch_brick_ring<65, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
+                            : launch_brick_ring<65, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
     GSX_CHECK(rc);
 
     if (info) {

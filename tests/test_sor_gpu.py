@@ -141,6 +141,28 @@ def test_query_shares_sum_to_the_whole(lib, algo, n, k, nshares):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,n,k", [("uniform", 200000, 16), ("uniform", 120000, 32), ("uniform", 50000, 8),
+                                      ("clustered", 60000, 16), ("lattice", 0, 16), ("uniform", 30000, 50)])
+def test_mfma_filter_variant_is_exact_too(lib, name, n, k):
+    """knn_brick's optional phase-1 filter (ctx param filter_mfma=1: bf16-split v_mfma_f32_32x32x16_bf16 with a
+    conservative slack) must select a superset of the true neighbours, i.e. give bit-identical results"""
+    xyz = {"uniform": lambda: datasets.uniform(n, 10.0, 5), "clustered": lambda: datasets.clustered(n, 7),
+           "lattice": lambda: datasets.lattice(30)}[name]()
+    n = len(xyz)
+    ref = osor.mean_dists_ckdtree(xyz, k)
+    ctx = lib.Context(0)
+    ctx.set_param("filter_mfma", 1)
+    cols = [np.ascontiguousarray(xyz[:, a]) for a in range(3)]
+    d = [ctx.alloc(4 * n).upload(c) for c in cols]
+    out = ctx.alloc(4 * n)
+    info = ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, n, 0, n, k, out.ptr, algo=GRID, want_info=True)
+    got = out.download(np.float32, n)
+    assert _explain(got, ref) == "ok", info
+    for a in d + [out]:
+        a.free()
+    ctx.close()
+
+
 def test_stats_kernel_matches_numpy(lib):
     """gsx_sor_stats_dev == np.mean / np.std / threshold, bit for bit, at ragged sizes"""
     rng = np.random.default_rng(9)

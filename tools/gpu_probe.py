@@ -93,11 +93,15 @@ def shares():
 def ablate():
     ctx = L.Context(0)
     x10 = uniform(10_000_000, 5.0)
-    for dbg, name in ((0, "full"), (4, "no epilogue"), (7, "skeleton only"), (15, "skeleton, no output write"),
-                      (31, "queue + row tables only"), (5, "phase 1 + cursor walk, no insert"), (36, "phase 1 only, no walk")):
-        ctx.set_param("debug_skip", dbg)
-        run(ctx, x10, 16, 2, 0.0, label="ablate: " + name)
+    for mf in (1, 0):
+        ctx.set_param("filter_mfma", mf)
+        for dbg, name in ((0, "full"), (4, "no epilogue"), (7, "skeleton only"), (15, "skeleton, no output write"),
+                          (31, "queue + row tables only"), (5, "phase 1 + cursor walk, no insert"), (36, "phase 1 only, no walk"),
+                          (2, "no phase 1")):
+            ctx.set_param("debug_skip", dbg)
+            run(ctx, x10, 16, 2, 0.0, label="ablate mf=%d: %s" % (mf, name))
     ctx.set_param("debug_skip", 0)
+    ctx.set_param("filter_mfma", 1)
     ctx.close()
 
 
