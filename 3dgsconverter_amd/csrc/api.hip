@@ -139,9 +139,8 @@ void gsx_ctx_destroy(gsx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->slots)
         for (auto e : s.ev) (void)hipEventDestroy(e);
-    gsx::DevBuf *bufs[] = {&c->packed, &c->qsorted, &c->bucketpts, &c->bkcnt, &c->cellstart,
-                           &c->qcellstart, &c->gridparams, &c->bboxpart, &c->faillist, &c->extraitems,
-                           &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
+    for (auto &w : c->ws) w.release_all();
+    gsx::DevBuf *bufs[] = {&c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
     delete c;
 }
@@ -252,12 +251,12 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
     if (q_count == 0) return 0;
     if (algo == GSX_KNN_AUTO) algo = n_ref < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID;
     if (algo == GSX_KNN_BRUTE) {
-        GSX_CHECK(c->packed.reserve(sizeof(float4) * (size_t)n_ref));
+        GSX_CHECK(c->ws[0].packed.reserve(sizeof(float4) * (size_t)n_ref));
         GSX_CHECK(timing_begin(c, GSX_T_SOR_BIN));
-        GSX_CHECK(launch_pack_points(c, x, y, z, stride, n_ref, c->packed.as<float4>()));
+        GSX_CHECK(launch_pack_points(c, x, y, z, stride, n_ref, c->ws[0].packed.as<float4>()));
         GSX_CHECK(timing_end(c, GSX_T_SOR_BIN));
         GSX_CHECK(timing_begin(c, GSX_T_SOR_KNN));
-        GSX_CHECK(launch_knn_brute(c, c->packed.as<float4>(), n_ref, q_begin, q_count, nullptr, nullptr, 0, k, mean_out));
+        GSX_CHECK(launch_knn_brute(c, c->ws[0].packed.as<float4>(), n_ref, q_begin, q_count, nullptr, nullptr, 0, k, mean_out));
         GSX_CHECK(timing_end(c, GSX_T_SOR_KNN));
         if (info) {
             memset(info, 0, sizeof(*info));
@@ -376,7 +375,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     const int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
     if (used == GSX_KNN_GRID) {
         GridParams hgp;
-        GSX_HIP(hipMemcpy(&hgp, c->gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
+        GSX_HIP(hipMemcpy(&hgp, c->ws[0].gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
         if (hgp.bad_input) GSX_FAIL("gsx_sor_filter: coordinates are not finite (NaN/inf)");
     }
     if (info) {
@@ -385,7 +384,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
         info->algo = used;
         if (used == GSX_KNN_GRID) {
             GridParams hgp;
-            GSX_HIP(hipMemcpy(&hgp, c->gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
+            GSX_HIP(hipMemcpy(&hgp, c->ws[0].gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
             info->grid_dim[0] = hgp.nx; info->grid_dim[1] = hgp.ny; info->grid_dim[2] = hgp.nz;
             info->cell_size = hgp.h;
             info->n_cells = hgp.ncells;

@@ -248,10 +248,10 @@ static int compute_frame(gsx_ctx *c, const float *x, const float *y, const float
                          float voxel, VoxelFrame *dev_vf, VoxelFrame *host_vf)
 {
     const int blocks = blocks_for(c, n, 1024);
-    GSX_CHECK(c->bboxpart.reserve(sizeof(float) * 6 * (size_t)blocks));
+    GSX_CHECK(c->ws[0].bboxpart.reserve(sizeof(float) * 6 * (size_t)blocks));
     hipLaunchKernelGGL(bbox_partial_kernel2, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n,
-                       c->bboxpart.as<float>());
-    hipLaunchKernelGGL(voxel_frame_kernel, dim3(1), dim3(64), 0, c->stream, c->bboxpart.as<float>(), blocks, voxel, dev_vf);
+                       c->ws[0].bboxpart.as<float>());
+    hipLaunchKernelGGL(voxel_frame_kernel, dim3(1), dim3(64), 0, c->stream, c->ws[0].bboxpart.as<float>(), blocks, voxel, dev_vf);
     GSX_HIP(hipGetLastError());
     GSX_HIP(hipMemcpyAsync(host_vf, dev_vf, sizeof(VoxelFrame), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));

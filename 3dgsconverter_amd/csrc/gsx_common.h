@@ -51,6 +51,35 @@ struct DevBuf {
     T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Buffers of one grid-binned KNN run (sor_grid.hip).  Refinement levels > 0 re-run the pipeline on the
+// sub-cloud around the cells a uniform grid cannot resolve; each level owns a full set.
+constexpr int KNN_MAX_LEVELS = 5;
+struct KnnWs {
+    DevBuf packed;      // float4[n_ref]  (brute: original order; grid: cell-sorted refs)
+    DevBuf qsorted;     // float4[q_count] cell-sorted queries when q != all refs
+    DevBuf bucketpts;   // float4[n_ref] points grouped by bucket (between the two sort levels)
+    DevBuf bkcnt;       // u32 bucket sizes | starts | cursors
+    DevBuf cellstart;   // u32[cap+1]
+    DevBuf qcellstart;
+    DevBuf gridparams;  // GridParams + work counters
+    DevBuf bboxpart;    // float[7 * blocks]
+    DevBuf faillist;    // u32[q_count]
+    DevBuf extraitems;  // uint2[q_count/64 + 64]: (brick, first query) of every batch beyond a brick's first
+    // adaptive refinement (level L -> L+1)
+    DevBuf deferred;    // u32[nbricks]: bricks whose neighbourhood is too populated for this level's cells
+    DevBuf cellflag;    // u8[ncells]: 1 = cell belongs to the sub-cloud, 2 = ... of a deferred brick (its points are queries)
+    DevBuf subxyz;      // float[3 * n_sub] SoA sub-cloud
+    DevBuf submap;      // u32[2 * n_sub]: original index | this level's sorted index (bit 31 of the first: is a query)
+    DevBuf submean;     // float[n_sub] mean distances computed at the next level
+    DevBuf subkth;      // double[n_sub] (k+1)-th squared distance computed at the next level
+    void release_all()
+    {
+        DevBuf *all[] = {&packed, &qsorted, &bucketpts, &bkcnt, &cellstart, &qcellstart, &gridparams, &bboxpart,
+                         &faillist, &extraitems, &deferred, &cellflag, &subxyz, &submap, &submean, &subkth};
+        for (auto b : all) b->release();
+    }
+};
+
 struct TimingSlot {
     std::vector<hipEvent_t> ev;  // pairs: start, stop
     size_t used = 0;
@@ -73,17 +102,8 @@ struct gsx_ctx {
     int debug_skip = 0;  // profiling ablations of knn_brick (never set by the product path)
     int filter_mfma = 0; // knn_brick phase 1: 0 = scalar-load f32 VALU filter (default), 1 = bf16-split MFMA filter
 
-    // SOR workspace
-    gsx::DevBuf packed;      // float4[n_ref]  (brute: original order; grid: cell-sorted refs)
-    gsx::DevBuf qsorted;     // float4[q_count] cell-sorted queries when q != all refs
-    gsx::DevBuf bucketpts;   // float4[n_ref] points grouped by bucket (between the two sort levels)
-    gsx::DevBuf bkcnt;       // u32 bucket sizes | starts | cursors
-    gsx::DevBuf cellstart;   // u32[cap+1]
-    gsx::DevBuf qcellstart;
-    gsx::DevBuf gridparams;  // GridParams + work counters
-    gsx::DevBuf bboxpart;    // float[6 * blocks]
-    gsx::DevBuf faillist;    // u32[q_count]
-    gsx::DevBuf extraitems;  // uint2[q_count/64 + 64]: (brick, first query) of every batch beyond a brick's first
+    // SOR workspace: one KnnWs per refinement level of the KNN grid (level 0 = the whole cloud)
+    gsx::KnnWs ws[gsx::KNN_MAX_LEVELS];
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging
     gsx::DevBuf scratch2;

@@ -1113,13 +1113,13 @@ static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, c
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
 // Sort (x,y,z)[first, first+n) by cell of the grid in gp: `sorted` and `start` (cell_start) are outputs.
-static int bin_points(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
+static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
                       int64_t n, GridParams *gp, unsigned *start, float4 *sorted)
 {
-    unsigned *bk_cnt = ctx->bkcnt.as<unsigned>();
+    unsigned *bk_cnt = w.bkcnt.as<unsigned>();
     unsigned *bk_start = bk_cnt + MAX_BUCKETS;
     unsigned *bk_cursor = bk_start + MAX_BUCKETS + 1;
-    float4 *tmp = ctx->bucketpts.as<float4>();
+    float4 *tmp = w.bucketpts.as<float4>();
     const int tiles = (int)std::min<int64_t>(div_up(n, BIN_TILE), (int64_t)ctx->num_cu * 4);
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n, gp,
                        bk_cnt);
@@ -1134,6 +1134,7 @@ static int bin_points(gsx_ctx *ctx, const float *x, const float *y, const float 
 int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
                     int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info, int share, int nshares)
 {
+    KnnWs &w = ctx->ws[0];
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
     const int64_t cap = grid_cell_cap(n_ref);
@@ -1150,44 +1151,44 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
         for (int cells = 8; cells >= 1; cells /= 2)
             if (pts_per_cell * cells > 58.0 && pts_per_cell * cells <= 66.0) pts_per_cell = 58.0 / cells;
     }
-    GSX_CHECK(ctx->packed.reserve(sizeof(float4) * (size_t)n_ref));
-    GSX_CHECK(ctx->bucketpts.reserve(sizeof(float4) * (size_t)n_ref));
-    GSX_CHECK(ctx->cellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
-    if (!ctx->bkcnt.p) {  // bucket sizes | bucket starts | bucket cursors; sizes are re-zeroed by bucket_scan_kernel
-        GSX_CHECK(ctx->bkcnt.reserve(sizeof(unsigned) * (3 * MAX_BUCKETS + 8)));
-        GSX_HIP(hipMemsetAsync(ctx->bkcnt.p, 0, sizeof(unsigned) * (3 * MAX_BUCKETS + 8), ctx->stream));
+    GSX_CHECK(w.packed.reserve(sizeof(float4) * (size_t)n_ref));
+    GSX_CHECK(w.bucketpts.reserve(sizeof(float4) * (size_t)n_ref));
+    GSX_CHECK(w.cellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+    if (!w.bkcnt.p) {  // bucket sizes | bucket starts | bucket cursors; sizes are re-zeroed by bucket_scan_kernel
+        GSX_CHECK(w.bkcnt.reserve(sizeof(unsigned) * (3 * MAX_BUCKETS + 8)));
+        GSX_HIP(hipMemsetAsync(w.bkcnt.p, 0, sizeof(unsigned) * (3 * MAX_BUCKETS + 8), ctx->stream));
     }
-    GSX_CHECK(ctx->gridparams.reserve(sizeof(GridParams)));
-    GSX_CHECK(ctx->bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
-    GSX_CHECK(ctx->faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
-    GSX_CHECK(ctx->extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
+    GSX_CHECK(w.gridparams.reserve(sizeof(GridParams)));
+    GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
+    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
+    GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
     if (!all) {
-        GSX_CHECK(ctx->qsorted.reserve(sizeof(float4) * (size_t)q_count));
-        GSX_CHECK(ctx->qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
+        GSX_CHECK(w.qsorted.reserve(sizeof(float4) * (size_t)q_count));
+        GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
     }
-    GridParams *gp = ctx->gridparams.as<GridParams>();
-    float4 *refs = ctx->packed.as<float4>();
-    unsigned *rstart = ctx->cellstart.as<unsigned>();
+    GridParams *gp = w.gridparams.as<GridParams>();
+    float4 *refs = w.packed.as<float4>();
+    unsigned *rstart = w.cellstart.as<unsigned>();
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
-                       ctx->bboxpart.as<float>());
-    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->bboxpart.as<float>(), bbox_blocks,
+                       w.bboxpart.as<float>());
+    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, w.bboxpart.as<float>(), bbox_blocks,
                        (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, gp);
     GSX_HIP(hipGetLastError());
-    GSX_CHECK(bin_points(ctx, x, y, z, stride, 0, n_ref, gp, rstart, refs));
+    GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs));
     const float4 *qpts = refs;
     const unsigned *qstart = rstart;
     if (!all) {
-        GSX_CHECK(bin_points(ctx, x, y, z, stride, q_begin, q_count, gp, ctx->qcellstart.as<unsigned>(),
-                             ctx->qsorted.as<float4>()));
-        qpts = ctx->qsorted.as<float4>();
-        qstart = ctx->qcellstart.as<unsigned>();
+        GSX_CHECK(bin_points(ctx, w, x, y, z, stride, q_begin, q_count, gp, w.qcellstart.as<unsigned>(),
+                             w.qsorted.as<float4>()));
+        qpts = w.qsorted.as<float4>();
+        qstart = w.qcellstart.as<unsigned>();
     }
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
-    unsigned *fl = ctx->faillist.as<unsigned>();
-    uint2 *ex = ctx->extraitems.as<uint2>();
+    unsigned *fl = w.faillist.as<unsigned>();
+    uint2 *ex = w.extraitems.as<uint2>();
     int rc;
     const bool mf = ctx->filter_mfma != 0;
     // list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
