@@ -26,12 +26,13 @@ class GsxError(RuntimeError):
 class SorInfo(C.Structure):
     _fields_ = [("algo", C.c_int32), ("grid_dim", C.c_int32 * 3), ("cell_size", C.c_float),
                 ("n_cells", C.c_int64), ("n_bricks", C.c_int64), ("n_fallback", C.c_int64),
-                ("n_exhaustive", C.c_int64)]
+                ("n_exhaustive", C.c_int64), ("n_deferred_bricks", C.c_int64), ("n_refined", C.c_int64)]
 
     def as_dict(self):
         return {"algo": int(self.algo), "grid_dim": tuple(int(v) for v in self.grid_dim),
                 "cell_size": float(self.cell_size), "n_cells": int(self.n_cells), "n_bricks": int(self.n_bricks),
-                "n_fallback": int(self.n_fallback), "n_exhaustive": int(self.n_exhaustive)}
+                "n_fallback": int(self.n_fallback), "n_exhaustive": int(self.n_exhaustive),
+                "n_deferred_bricks": int(self.n_deferred_bricks), "n_refined": int(self.n_refined)}
 
 
 # name -> (restype, argtypes); every symbol include/gsx_hip.h declares

@@ -199,6 +199,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->brute_below = (int64_t)value;
     } else if (!strcmp(name, "debug_skip")) {
         c->debug_skip = (int)value;
+    } else if (!strcmp(name, "adaptive")) {
+        c->adaptive = value != 0.0;
     } else if (!strcmp(name, "filter_mfma")) {
         c->filter_mfma = value != 0.0;
     } else {
@@ -319,7 +321,10 @@ static gsx_ctx *g_host_ctx = nullptr;
 
 static int host_ctx(gsx_ctx **out)
 {
-    if (!g_host_ctx) GSX_CHECK(gsx_ctx_create(0, &g_host_ctx));
+    if (!g_host_ctx) {
+        GSX_CHECK(gsx_ctx_create(0, &g_host_ctx));
+        g_host_ctx->adaptive = 1;  // the host entry points are synchronous anyway
+    }
     GSX_HIP(hipSetDevice(g_host_ctx->device));
     *out = g_host_ctx;
     return 0;
@@ -391,6 +396,8 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
             info->n_bricks = hgp.nbricks;
             info->n_fallback = hgp.fail_count;
             info->n_exhaustive = hgp.exhaustive_count;
+            info->n_deferred_bricks = hgp.deferred_count;
+            info->n_refined = hgp.sub_count;
         }
     }
     return 0;

@@ -72,10 +72,13 @@ struct KnnWs {
     DevBuf submap;      // u32[2 * n_sub]: original index | this level's sorted index (bit 31 of the first: is a query)
     DevBuf submean;     // float[n_sub] mean distances computed at the next level
     DevBuf subkth;      // double[n_sub] (k+1)-th squared distance computed at the next level
+    DevBuf heavylist;   // u32[q_count] sorted indices of the knn_ring queries handed to knn_heavy
+    DevBuf heavypart;   // double[batch * chunks * KCAP] per-chunk partial top lists
     void release_all()
     {
         DevBuf *all[] = {&packed, &qsorted, &bucketpts, &bkcnt, &cellstart, &qcellstart, &gridparams, &bboxpart,
-                         &faillist, &extraitems, &deferred, &cellflag, &subxyz, &submap, &submean, &subkth};
+                         &faillist, &extraitems, &deferred, &cellflag, &subxyz, &submap, &submean, &subkth,
+                         &heavylist, &heavypart};
         for (auto b : all) b->release();
     }
 };
@@ -100,6 +103,7 @@ struct gsx_ctx {
     double grid_points_per_cell = 0.0;  // 0 = auto: 0.47 * (k + 1), see launch_knn_grid
     int64_t brute_below = 2048;
     int debug_skip = 0;  // profiling ablations of knn_brick (never set by the product path)
+    int adaptive = 0;    // 1: bricks too populated for the grid are re-run on a finer grid (one host sync per call)
     int filter_mfma = 0; // knn_brick phase 1: 0 = scalar-load f32 VALU filter (default), 1 = bf16-split MFMA filter
 
     // SOR workspace: one KnnWs per refinement level of the KNN grid (level 0 = the whole cloud)

@@ -23,6 +23,9 @@
 // private cursor, recomputes those distances in float64 exactly as cKDTree does and keeps
 // the k+1 smallest in a register-resident sorted list.  A query is exact iff its (k+1)-th
 // distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is farther.
+#include <chrono>
+#include <cstdlib>
+
 #include "gsx_common.h"
 #include "knn_common.h"
 #include "sor_grid_params.h"
@@ -36,6 +39,8 @@ constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 K
 constexpr int BUCKET_POINTS = 4096;       // target points per bucket
 constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
+constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
+constexpr int HEAVY_CHUNK = 8192;   // points of the sorted array one wave of knn_heavy_scan covers
 constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
 
 // Phase-1 filter step: shift the predicate "squared distance < tau" into the lane's bit mask.
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
 
 __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
                                                          double pts_per_cell, int cell_cap, int debug_skip,
-                                                         int share, int nshares, GridParams *__restrict__ gp)
+                                                         int share, int nshares, int defer_words, float parent_h,
+                                                         GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
     float v[7];
@@ -309,9 +315,17 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->hprime = hp;
     gp->r1sq = r1 * r1;
     gp->tau1 = bound_from(r1 * r1);
+    // refinement only pays while the cells keep shrinking (a cloud of identical points never would)
+    gp->defer_words = (parent_h > 0.0f && !((float)h < 0.8f * parent_h)) ? 0 : defer_words;
     gp->fail_count = 0;
     gp->exhaustive_count = 0;
     gp->extra_count = 0;
+    gp->heavy_limit = defer_words > 0 ? HEAVY_RING_CANDIDATES : 0;  // both need the host in the loop
+    gp->heavy_count = 0;
+    gp->deferred_count = 0;
+    gp->sub_count = 0;
+    gp->sub_queries = 0;
+    gp->refined_count = 0;
     for (int i = 0; i < 8; ++i) {
         gp->brick_ctr[i * 32] = 0;
         gp->extra_ctr[i * 32] = 0;
@@ -572,7 +586,8 @@ template <int KCAP, bool EXTRA, bool MF>
 __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_brick_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
-    float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra)
+    float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra,
+    unsigned *__restrict__ deferred, double *__restrict__ kth_out)
 {
     // the MFMA variant parks its query operands in LDS too: 22 words keep a workgroup under 32 KiB (5 per CU)
     constexpr int WCAP = MF ? 22 : gsx::WCAP;
@@ -646,6 +661,24 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 #pragma unroll
         for (int r = 0; r < 4; ++r) qoff[r + 1] = qoff[r] + __builtin_amdgcn_readlane(v_len, 16 + r);
         const int nq = qoff[4];
+        if (!EXTRA) {
+            // Adaptive refinement: the cost of this brick is batches x candidate words.  A uniform grid
+            // gives ~1.5 x 15; a brick inside (or next to) a cluster much denser than the cell size can
+            // reach millions.  Such a brick is not searched here: it goes on the deferred list, and the
+            // host re-runs the whole pipeline on the points of the deferred neighbourhoods with a grid
+            // sized for THEM (launch_knn_grid, refine_level).
+            const int dw = gp->defer_words;
+            if (dw > 0 && nq > 0) {
+                int ncand = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ncand += __builtin_amdgcn_readlane(v_len, r);
+                const int words = (ncand + 31) >> 5, batches = (nq + 63) >> 6;
+                if (words > dw || (long long)words * batches > 2LL * dw) {
+                    if (lane == 0) deferred[atomicAdd(&gp->deferred_count, 1u)] = (unsigned)b;
+                    continue;
+                }
+            }
+        }
         // A wave loops over up to LOCAL_BATCHES batches of its brick itself (the neighbourhood is hot in
         // the scalar cache / L2 then); the batches beyond that -- a brick inside a dense cluster can
         // hold thousands -- become items of the second launch.
@@ -908,6 +941,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)lst.kth(kk);
                 } else if (lst.kth(kk) <= racc_sq) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
+                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = lst.kth(kk);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);
                     faillist[slot] = (unsigned)qidx;
@@ -938,7 +972,7 @@ template <int KCAP>
 __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, int k, int q_begin,
-    float *__restrict__ mean_out)
+    float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ heavylist)
 {
     __shared__ double s_out[BRICK_THREADS / 64][KCAP];
     __shared__ int s_rs[BRICK_THREADS / 64][RING_ROWS];       // first point of each row
@@ -1009,6 +1043,10 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                     carry += __shfl(inc, 63);
                 }
                 const int total = carry;
+                if (g.heavy_limit > 0 && total > g.heavy_limit) {  // wave-uniform
+                    if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = faillist[t];
+                    break;
+                }
                 if (lane == 0) ro[nrows] = total;
                 wave_sync();
                 // every lane walks the flat candidate range with stride 64, 4 independent loads in flight
@@ -1030,6 +1068,19 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                         if (ok[u]) consider(p[u]);
                 }
             } else {
+                if (g.heavy_limit > 0) {
+                    int total = 0;
+                    for (int r = lane; r < nrows; r += 64) {
+                        const int row = row_base(g, y0 + r % nyr, z0 + r / nyr);
+                        total += (int)(rstart[row + x1 + 1] - rstart[row + x0]);
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+                    if (uniform(total) > g.heavy_limit) {
+                        if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = faillist[t];
+                        break;
+                    }
+                }
                 for (int zz = z0; zz <= z1; ++zz)
                     for (int yy = y0; yy <= y1; ++yy) {
                         const int row = row_base(g, yy, zz);
@@ -1061,12 +1112,128 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                     if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
                     double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
                 }
                 wave_sync();
                 break;
             }
             wave_sync();
         }
+    }
+}
+
+// ---------------------------------------------------------------- knn_heavy (ring queries next to a huge cell)
+// A far "floater" whose ring reaches a cell holding most of the cloud would make ONE wave scan
+// millions of candidates (measured: 11 ms for 9 such queries at 1M splats).  knn_ring hands these
+// queries over; here every wave takes (query, 8192-point chunk of the WHOLE sorted array), keeps
+// the k+1 smallest squared distances of its chunk, and a second kernel merges the chunks of a
+// query -- exhaustive, hence exact, and spread over the chip.
+template <int KCAP>
+struct LaneTop {
+    double a[KCAP];  // ascending, +inf padded
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) a[i] = __builtin_inf();
+    }
+    __device__ __forceinline__ void consider(double d)
+    {
+        if (d < a[KCAP - 1]) {
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i) {
+                double lo, hi;
+                asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a[i]), "v"(d));
+                asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a[i]), "v"(d));
+                a[i] = lo;
+                d = hi;
+            }
+        }
+    }
+    // the kk smallest over the whole wave -> out[0..kk) (written by lane 0)
+    __device__ __forceinline__ void wave_merge(int kk, int lane, double *out)
+    {
+        for (int r = 0; r < kk; ++r) {
+            const double mn = wave_min_f64(a[0]);
+            const unsigned long long eq = __ballot(a[0] == mn);
+            const int win = (int)__builtin_ctzll(eq);
+            if (lane == 0) out[r] = mn;
+            if (lane == win) {
+#pragma unroll
+                for (int i = 0; i + 1 < KCAP; ++i) a[i] = a[i + 1];
+                a[KCAP - 1] = __builtin_inf();
+            }
+        }
+    }
+};
+
+template <int KCAP>
+__global__ __launch_bounds__(BRICK_THREADS) void knn_heavy_scan_kernel(const float4 *__restrict__ refs, int n,
+                                                                       const float4 *__restrict__ qpts,
+                                                                       const unsigned *__restrict__ heavylist, int first,
+                                                                       int count, int k, double *__restrict__ part)
+{
+    const int lane = lane_id();
+    const int kk = k + 1;
+    const int nchunks = (n + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+    const long long items = (long long)count * nchunks;
+    const long long wave0 = (long long)blockIdx.x * (BRICK_THREADS / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (BRICK_THREADS / 64);
+    for (long long it = wave0; it < items; it += nwaves) {
+        const int qi = (int)(it / nchunks), c = (int)(it - (long long)qi * nchunks);
+        const float4 qp = qpts[heavylist[first + qi]];
+        const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
+        LaneTop<KCAP> top;
+        top.init();
+        const int j0 = c * HEAVY_CHUNK, j1 = min(n, j0 + HEAVY_CHUNK);
+        for (int j = j0 + lane; j < j1; j += 256) {
+            float4 p[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ok[u] = j + 64 * u < j1;
+                if (ok[u]) p[u] = refs[j + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) top.consider(dist2_f64(qxd, qyd, qzd, p[u].x, p[u].y, p[u].z));
+        }
+        top.wave_merge(kk, lane, part + (size_t)it * KCAP);
+    }
+}
+
+template <int KCAP>
+__global__ __launch_bounds__(BRICK_THREADS) void knn_heavy_merge_kernel(GridParams *__restrict__ gp, int n,
+                                                                        const float4 *__restrict__ qpts,
+                                                                        const unsigned *__restrict__ heavylist, int first,
+                                                                        int count, int k, int q_begin,
+                                                                        const double *__restrict__ part,
+                                                                        float *__restrict__ mean_out,
+                                                                        double *__restrict__ kth_out)
+{
+    __shared__ double s_out[BRICK_THREADS / 64][KCAP];
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    double *out = s_out[wv];
+    const int kk = k + 1;
+    const int nchunks = (n + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+    const int qi = blockIdx.x * (BRICK_THREADS / 64) + wv;
+    if (qi >= count) return;
+    LaneTop<KCAP> top;
+    top.init();
+    const double *mine = part + (size_t)qi * nchunks * KCAP;
+    for (int e = lane; e < nchunks * KCAP; e += 64)
+        if (e % KCAP < kk) top.consider(mine[e]);
+    top.wave_merge(kk, lane, out);
+    wave_sync();
+    const double kth = out[kk - 1];
+    for (int i = lane; i < kk; i += 64) out[i] = __dsqrt_rn(out[i]);
+    wave_sync();
+    if (lane == 0) {
+        const float4 qp = qpts[heavylist[first + qi]];
+        atomicAdd(&gp->exhaustive_count, 1u);
+        double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
+        mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
+        if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
     }
 }
 
@@ -1078,36 +1245,216 @@ static int grid_blocks(const gsx_ctx *ctx, int64_t n, int per_thread = 1)
     return (int)std::max<int64_t>(1, std::min(want, cap));
 }
 
+// ---------------------------------------------------------------- adaptive refinement (level L -> L+1)
+// Bucket-major index of cell (cx, cy, cz) -- the same mapping as row_base_g in knn_brick.
+__device__ __forceinline__ int cell_index_of(const GridParams *gp, int cx, int cy, int cz)
+{
+    const int g = gp->bk_g;
+    const int by_ = cy / g, bz_ = cz / g;
+    return (bz_ * gp->bk_ny + by_) * gp->bk_cells + ((cz - bz_ * g) * g + (cy - by_ * g)) * gp->nx + cx;
+}
+
+// one 64-thread block per deferred brick: flag the cells of its neighbourhood (pass 0: value 1) and its
+// own cells (pass 1: value 3 -- their points are the queries of the finer level)
+__global__ __launch_bounds__(64) void mark_cells_kernel(const GridParams *__restrict__ gp, const unsigned *__restrict__ deferred,
+                                                        uint8_t *__restrict__ cellflag, int own_pass)
+{
+    if (blockIdx.x >= gp->deferred_count) return;
+    const int b = (int)deferred[blockIdx.x];
+    const int nbx = gp->nbx, nby = gp->nby;
+    const int bz = b / (nbx * nby), brem = b - bz * nbx * nby, by = brem / nbx, bx = brem - by * nbx;
+    const int t = threadIdx.x;
+    const int dx = t & 3, dy = (t >> 2) & 3, dz = t >> 4;
+    if (dx >= gp->bdx + 2 || dy >= gp->bdy + 2 || dz >= gp->bdz + 2) return;
+    const int cx = bx * gp->bdx - 1 + dx, cy = by * gp->bdy - 1 + dy, cz = bz * gp->bdz - 1 + dz;
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= gp->nx || cy >= gp->ny || cz >= gp->nz) return;
+    const bool own = dx >= 1 && dx <= gp->bdx && dy >= 1 && dy <= gp->bdy && dz >= 1 && dz <= gp->bdz;
+    if (own_pass ? own : true) cellflag[cell_index_of(gp, cx, cy, cz)] = own_pass ? 3 : 1;
+}
+
+// gather the points of the flagged cells into a SoA sub-cloud (any order); wave-aggregated append
+__global__ __launch_bounds__(256) void gather_sub_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs, int n,
+                                                         const uint8_t *__restrict__ cellflag, float *__restrict__ sub,
+                                                         unsigned *__restrict__ sub_orig, unsigned *__restrict__ sub_sorted)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned flag = 0;
+    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) {
+        P = refs[j];
+        const int cx = cell_coord(P.x, gp->ox, gp->inv_h, gp->nx), cy = cell_coord(P.y, gp->oy, gp->inv_h, gp->ny),
+                  cz = cell_coord(P.z, gp->oz, gp->inv_h, gp->nz);
+        flag = cellflag[cell_index_of(gp, cx, cy, cz)];
+    }
+    const unsigned long long take = __ballot(flag != 0);
+    if (take == 0) return;
+    const int lane = lane_id();
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&gp->sub_count, (unsigned)__builtin_popcountll(take));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (flag != 0) {
+        const unsigned pos = base + (unsigned)__builtin_popcountll(take & ((1ull << lane) - 1ull));
+        sub[pos] = P.x;
+        sub[(size_t)n + pos] = P.y;
+        sub[2 * (size_t)n + pos] = P.z;
+        sub_orig[pos] = __float_as_uint(P.w) | (flag == 3 ? 0x80000000u : 0u);
+        sub_sorted[pos] = (unsigned)j;
+    }
+}
+
+// A finer-level result is the exact answer iff its (k+1)-th neighbour lies inside the region this
+// level guarantees to have gathered: every point outside the brick's neighbourhood is farther than
+// the distance to the nearest neighbourhood face that has cells behind it (same bound and margins
+// as knn_brick's boundary-aware acceptance radius).  Anything else goes to this level's knn_ring.
+__global__ __launch_bounds__(256) void merge_sub_kernel(GridParams *__restrict__ gp, const float *__restrict__ sub, int n,
+                                                        const unsigned *__restrict__ sub_orig,
+                                                        const unsigned *__restrict__ sub_sorted,
+                                                        const float *__restrict__ submean, const double *__restrict__ subkth,
+                                                        int q_begin, float *__restrict__ mean_out, double *__restrict__ kth_out,
+                                                        unsigned *__restrict__ faillist)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= gp->sub_count) return;
+    const unsigned so = sub_orig[i];
+    if (!(so >> 31)) return;  // only gathered as a reference point
+    const int orig = (int)(so & 0x7fffffffu);
+    const float q[3] = {sub[i], sub[(size_t)n + i], sub[2 * (size_t)n + i]};
+    const float o[3] = {gp->ox, gp->oy, gp->oz};
+    const int dim[3] = {gp->nx, gp->ny, gp->nz};
+    const int bd[3] = {gp->bdx, gp->bdy, gp->bdz};
+    const float hf = (float)gp->hprime;
+    float rsafe = 3.0e38f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int c = cell_coord(q[a], o[a], gp->inv_h, dim[a]);
+        const int bb = c / bd[a];
+        const int ulo = bb * bd[a] - 1, uhi = bb * bd[a] + bd[a];
+        const float rel = q[a] - o[a];
+        if (ulo > 0) rsafe = fminf(rsafe, rel - (float)ulo * hf - 2e-3f * hf);
+        if (uhi < dim[a] - 1) rsafe = fminf(rsafe, (float)(uhi + 1) * hf - rel - 2e-3f * hf);
+    }
+    const double kth = subkth[i];
+    if (rsafe > 0.0f && kth <= (double)rsafe * (double)rsafe) {
+        mean_out[orig - q_begin] = submean[i];
+        if (kth_out) kth_out[orig - q_begin] = kth;
+    } else {
+        faillist[atomicAdd(&gp->fail_count, 1u)] = sub_sorted[i];
+    }
+}
+
+struct BrickLaunch {
+    GridParams *gp;
+    const float4 *refs;
+    const unsigned *rstart;
+    const float4 *qpts;
+    const unsigned *qstart;
+    int k;
+    int64_t q_begin;
+    float *mean_out;
+    double *kth_out;
+    unsigned *faillist;
+    uint2 *extra;
+    unsigned *deferred;
+    unsigned *heavylist;
+};
+
 template <int KCAP, bool MF>
-static int launch_brick_ring(gsx_ctx *ctx, GridParams *gp, const float4 *refs, const unsigned *rstart,
-                             const float4 *qpts, const unsigned *qstart, int k, int64_t q_begin,
-                             float *mean_out, unsigned *faillist, uint2 *extra)
+static int launch_bricks(gsx_ctx *ctx, const BrickLaunch &a)
 {
     // Work is assigned STATICALLY to waves, so every launched workgroup must be resident at once:
     // the grids are sized from the occupancy the built kernels actually get (a non-resident
     // workgroup would run its share only after a resident one has finished all of its own).
-    static int occ_brick = 0, occ_extra = 0, occ_ring = 0;
+    static int occ_brick = 0, occ_extra = 0;
     if (!occ_brick) {
         GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false, MF>, BRICK_THREADS, 0));
         GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true, MF>, BRICK_THREADS, 0));
-        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ring, knn_ring_kernel<KCAP>, BRICK_THREADS, 0));
         occ_brick = std::max(1, std::min(occ_brick, 8));
         occ_extra = std::max(1, std::min(occ_extra, 8));
-        occ_ring = std::max(1, std::min(occ_ring, 8));
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false, MF>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream, gp,
-                       refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true, MF>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream, gp,
-                       refs, rstart, qpts, qstart, k, (int)q_begin, mean_out, faillist, extra);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false, MF>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream,
+                       a.gp, a.refs, a.rstart, a.qpts, a.qstart, a.k, (int)a.q_begin, a.mean_out, a.faillist, a.extra,
+                       a.deferred, a.kth_out);
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true, MF>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream,
+                       a.gp, a.refs, a.rstart, a.qpts, a.qstart, a.k, (int)a.q_begin, a.mean_out, a.faillist, a.extra,
+                       a.deferred, a.kth_out);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
+    return 0;
+}
+
+template <int KCAP>
+static int launch_ring(gsx_ctx *ctx, const BrickLaunch &a)
+{
+    static int occ_ring = 0;
+    if (!occ_ring) {
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ring, knn_ring_kernel<KCAP>, BRICK_THREADS, 0));
+        occ_ring = std::max(1, std::min(occ_ring, 8));
+    }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
-    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * occ_ring), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart,
-                       qpts, faillist, k, (int)q_begin, mean_out);
+    hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * occ_ring), dim3(BRICK_THREADS), 0, ctx->stream, a.gp, a.refs,
+                       a.rstart, a.qpts, a.faillist, a.k, (int)a.q_begin, a.mean_out, a.kth_out, a.heavylist);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
     return 0;
+}
+
+template <int KCAP>
+static int launch_heavy(gsx_ctx *ctx, KnnWs &w, const BrickLaunch &a, int64_t n_ref, unsigned heavy_count)
+{
+    const int nchunks = div_up(n_ref, HEAVY_CHUNK);
+    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(heavy_count, (256LL << 20) / ((int64_t)nchunks * KCAP * 8)));
+    GSX_CHECK(w.heavypart.reserve(sizeof(double) * (size_t)batch * nchunks * KCAP));
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
+    for (unsigned first = 0; first < heavy_count; first += (unsigned)batch) {
+        const int count = (int)std::min<unsigned>((unsigned)batch, heavy_count - first);
+        const int64_t items = (int64_t)count * nchunks;
+        const int blocks = (int)std::min<int64_t>(div_up(items, BRICK_THREADS / 64), (int64_t)ctx->num_cu * 8);
+        hipLaunchKernelGGL((knn_heavy_scan_kernel<KCAP>), dim3(blocks), dim3(BRICK_THREADS), 0, ctx->stream, a.refs, (int)n_ref,
+                           a.qpts, a.heavylist, (int)first, count, a.k, w.heavypart.as<double>());
+        hipLaunchKernelGGL((knn_heavy_merge_kernel<KCAP>), dim3(div_up(count, BRICK_THREADS / 64)), dim3(BRICK_THREADS), 0,
+                           ctx->stream, a.gp, (int)n_ref, a.qpts, a.heavylist, (int)first, count, a.k, (int)a.q_begin,
+                           w.heavypart.as<double>(), a.mean_out, a.kth_out);
+    }
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
+    return 0;
+}
+
+static int dispatch_heavy(gsx_ctx *ctx, KnnWs &w, const BrickLaunch &a, int64_t n_ref, unsigned heavy_count)
+{
+    const int kk = a.k + 1;
+    if (kk <= 9) return launch_heavy<9>(ctx, w, a, n_ref, heavy_count);
+    if (kk <= 17) return launch_heavy<17>(ctx, w, a, n_ref, heavy_count);
+    if (kk <= 26) return launch_heavy<26>(ctx, w, a, n_ref, heavy_count);
+    if (kk <= 33) return launch_heavy<33>(ctx, w, a, n_ref, heavy_count);
+    if (kk <= 51) return launch_heavy<51>(ctx, w, a, n_ref, heavy_count);
+    return launch_heavy<65>(ctx, w, a, n_ref, heavy_count);
+}
+
+// list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
+static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf)
+{
+    const int kk = a.k + 1;
+#define GSX_BRICKS(K) (mf ? launch_bricks<K, true>(ctx, a) : launch_bricks<K, false>(ctx, a))
+    if (kk <= 9) return GSX_BRICKS(9);
+    if (kk <= 17) return GSX_BRICKS(17);
+    if (kk <= 26) return GSX_BRICKS(26);
+    if (kk <= 33) return GSX_BRICKS(33);
+    if (kk <= 51) return GSX_BRICKS(51);
+    return GSX_BRICKS(65);
+#undef GSX_BRICKS
+}
+
+static int dispatch_ring(gsx_ctx *ctx, const BrickLaunch &a)
+{
+    const int kk = a.k + 1;
+    if (kk <= 9) return launch_ring<9>(ctx, a);
+    if (kk <= 17) return launch_ring<17>(ctx, a);
+    if (kk <= 26) return launch_ring<26>(ctx, a);
+    if (kk <= 33) return launch_ring<33>(ctx, a);
+    if (kk <= 51) return launch_ring<51>(ctx, a);
+    return launch_ring<65>(ctx, a);
 }
 
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
@@ -1131,14 +1478,18 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
     return 0;
 }
 
-int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
-                    int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info, int share, int nshares)
+constexpr int DEFER_WORDS = 512;  // ~35x the candidate words of a brick of a uniform cloud
+
+static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *y, const float *z, int64_t stride,
+                          int64_t n_ref, int64_t q_begin, int64_t q_count, int k, float *mean_out, double *kth_out,
+                          gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h)
 {
-    KnnWs &w = ctx->ws[0];
+    KnnWs &w = ctx->ws[level];
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
     const int64_t cap = grid_cell_cap(n_ref);
     const bool all = (q_begin == 0 && q_count == n_ref);
+    adaptive = adaptive && all && nshares == 1 && level + 1 < KNN_MAX_LEVELS;
     const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
     // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts
@@ -1162,6 +1513,10 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
     GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
+    if (adaptive) {
+        GSX_CHECK(w.deferred.reserve(sizeof(unsigned) * (size_t)(cap + 64)));  // nbricks <= ncells <= cap
+        GSX_CHECK(w.heavylist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
+    }
     if (!all) {
         GSX_CHECK(w.qsorted.reserve(sizeof(float4) * (size_t)q_count));
         GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));
@@ -1174,7 +1529,8 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        w.bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, w.bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, gp);
+                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? DEFER_WORDS : 0,
+                       parent_h, gp);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs));
     const float4 *qpts = refs;
@@ -1187,39 +1543,100 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
     }
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
-    unsigned *fl = w.faillist.as<unsigned>();
-    uint2 *ex = w.extraitems.as<uint2>();
-    int rc;
-    const bool mf = ctx->filter_mfma != 0;
-    // list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
-    if (kk <= 9) rc = mf ? launch_brick_ring<9, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<9, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 17) rc = mf ? launch_brick_ring<17, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<17, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 26) rc = mf ? launch_brick_ring<26, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<26, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 33) rc = mf ? launch_brick_ring<33, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<33, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else if (kk <= 51) rc = mf ? launch_brick_ring<51, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<51, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    else rc = mf ? launch_brick_ring<65, true>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex)
-                            : launch_brick_ring<65, false>(ctx, gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, fl, ex);
-    GSX_CHECK(rc);
+    BrickLaunch a{gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, kth_out, w.faillist.as<unsigned>(),
+                  w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>()};
+    GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0));
 
-    if (info) {
-        GridParams hgp;
+    GridParams hgp;
+    bool have_hgp = false;
+    if (adaptive) {
+        // the only host decision of the pipeline: did any brick ask for a finer grid?
         GSX_HIP(hipMemcpyAsync(&hgp, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
-        if (hgp.bad_input) GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
+        have_hgp = true;
+        if (getenv("GSX_TRACE_LEVELS"))
+            fprintf(stderr, "[gsx] level %d: n=%lld h=%.5g dims=%dx%dx%d bricks=%d defer_words=%d deferred=%u extra=%u fail=%u\n", level,
+                    (long long)n_ref, hgp.h, hgp.nx, hgp.ny, hgp.nz, hgp.nbricks, hgp.defer_words, hgp.deferred_count,
+                    hgp.extra_count, hgp.fail_count);
+        if (hgp.deferred_count > 0 && !hgp.bad_input) {
+            const unsigned nd = hgp.deferred_count;
+            GSX_CHECK(w.cellflag.reserve((size_t)hgp.ncells + 64));
+            GSX_CHECK(w.subxyz.reserve(sizeof(float) * 3 * (size_t)n_ref));
+            GSX_CHECK(w.submap.reserve(sizeof(unsigned) * 2 * (size_t)n_ref));
+            uint8_t *flag = w.cellflag.as<uint8_t>();
+            float *sub = w.subxyz.as<float>();
+            unsigned *sub_orig = w.submap.as<unsigned>(), *sub_sorted = sub_orig + n_ref;
+            GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
+            GSX_HIP(hipMemsetAsync(flag, 0, (size_t)hgp.ncells, ctx->stream));
+            hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 0);
+            hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 1);
+            hipLaunchKernelGGL(gather_sub_kernel, dim3(div_up(n_ref, 256)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref, flag,
+                               sub, sub_orig, sub_sorted);
+            GSX_HIP(hipGetLastError());
+            unsigned n_sub = 0;
+            GSX_HIP(hipMemcpyAsync(&n_sub, &gp->sub_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            GSX_HIP(hipStreamSynchronize(ctx->stream));
+            GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
+            if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level %d: sub-cloud %u points\n", level, n_sub);
+            if (n_sub == 0) GSX_FAIL("sor: refinement gathered no points for %u deferred bricks", nd);
+            GSX_CHECK(w.submean.reserve(sizeof(float) * (size_t)n_sub));
+            GSX_CHECK(w.subkth.reserve(sizeof(double) * (size_t)n_sub));
+            GSX_CHECK(knn_grid_level(ctx, level + 1, sub, sub + n_ref, sub + 2 * n_ref, 1, (int64_t)n_sub, 0, (int64_t)n_sub, k,
+                                     w.submean.as<float>(), w.subkth.as<double>(), nullptr, 0, 1, true, hgp.h));
+            hipLaunchKernelGGL(merge_sub_kernel, dim3(div_up((int64_t)n_sub, 256)), dim3(256), 0, ctx->stream, gp, sub, (int)n_ref,
+                               sub_orig, sub_sorted, w.submean.as<float>(), w.subkth.as<double>(), (int)q_begin, mean_out,
+                               kth_out, a.faillist);
+            GSX_HIP(hipGetLastError());
+        }
+    }
+    const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;
+    std::chrono::steady_clock::time_point t_ring0;
+    if (trace) {
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        t_ring0 = std::chrono::steady_clock::now();
+    }
+    GSX_CHECK(dispatch_ring(ctx, a));
+    if (adaptive) {
+        unsigned nheavy = 0;
+        GSX_HIP(hipMemcpyAsync(&nheavy, &gp->heavy_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (trace) fprintf(stderr, "[gsx] level %d: %u ring queries handed to knn_heavy\n", level, nheavy);
+        if (nheavy > 0) GSX_CHECK(dispatch_heavy(ctx, w, a, n_ref, nheavy));
+    }
+    if (trace) {
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        GridParams h3;
+        GSX_HIP(hipMemcpy(&h3, gp, sizeof(GridParams), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[gsx] level %d: knn_ring %.3f ms for %u queries (%u exhaustive)\n", level,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring0).count(), h3.fail_count,
+                h3.exhaustive_count);
+    }
+
+    if (info) {
+        GridParams h2;
+        GSX_HIP(hipMemcpyAsync(&h2, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (h2.bad_input) GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
         info->algo = GSX_KNN_GRID;
-        info->grid_dim[0] = hgp.nx; info->grid_dim[1] = hgp.ny; info->grid_dim[2] = hgp.nz;
-        info->cell_size = hgp.h;
-        info->n_cells = hgp.ncells;
-        info->n_bricks = hgp.nbricks;
-        info->n_fallback = hgp.fail_count;
-        info->n_exhaustive = hgp.exhaustive_count;
+        info->grid_dim[0] = h2.nx; info->grid_dim[1] = h2.ny; info->grid_dim[2] = h2.nz;
+        info->cell_size = h2.h;
+        info->n_cells = h2.ncells;
+        info->n_bricks = h2.nbricks;
+        info->n_fallback = h2.fail_count;
+        info->n_exhaustive = h2.exhaustive_count;
+        info->n_deferred_bricks = h2.deferred_count;
+        info->n_refined = h2.sub_count;
+    } else if (have_hgp && hgp.bad_input && level == 0) {
+        GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
     }
     return 0;
+}
+
+int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref,
+                    int64_t q_begin, int64_t q_count, int k, float *mean_out, gsx_sor_info *info, int share, int nshares)
+{
+    return knn_grid_level(ctx, 0, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, share, nshares,
+                          ctx->adaptive != 0, 0.0f);
 }
 
 }  // namespace gsx

@@ -15,6 +15,8 @@ struct GridParams {
     int nbx, nby, nbz;
     int nbricks;
     int part_lo, part_hi;  // bricks [part_lo, part_hi) are this call's share (multi-GPU: one share per rank)
+    int defer_words;       // > 0: a brick whose neighbourhood holds more than this many 32-candidate words (or
+                           // batches x words > 2x this) is not searched at this level but deferred to a finer grid
     int bdx, bdy, bdz;  // brick size in cells: (2,2,2), (2,2,1), (2,1,1) or (1,1,1)
     int debug_skip;     // profiling only (results become wrong): 1 = skip phase 2, 2 = skip phase 1, 4 = skip epilogue
     float tau1;      // f32 filter bound for r1sq
@@ -25,6 +27,13 @@ struct GridParams {
     unsigned exhaustive_count;
     unsigned extra_count;   // (brick, batch >= 1) work items appended by the first knn_brick pass
     unsigned bad_input;     // 1: non-finite coordinates -- the KNN kernels do nothing, the host reports an error
+    unsigned deferred_count;  // bricks appended to the deferred list by knn_brick
+    unsigned sub_count;       // points of the sub-cloud gathered around the deferred bricks
+    unsigned sub_queries;     // ... of which queries (points of the deferred bricks themselves)
+    unsigned refined_count;   // queries whose result came from a finer level
+    int heavy_limit;          // > 0: a knn_ring query whose ring holds more candidates than this is not scanned by its
+                              // single wave but handed to knn_heavy (the whole chip scans the whole cloud for it)
+    unsigned heavy_count;
     unsigned brick_ctr[8 * 32];   // dynamic-tail counters, one per XCD, separate cache lines
     unsigned extra_ctr[8 * 32];
     unsigned ring_ctr[8 * 32];

@@ -61,6 +61,8 @@ typedef struct gsx_sor_info {
     int64_t n_bricks;
     int64_t n_fallback;      /* queries re-done by the expanding-ring kernel     */
     int64_t n_exhaustive;    /* of those, queries that needed the whole cloud    */
+    int64_t n_deferred_bricks; /* bricks handed to a finer grid (adaptive mode)  */
+    int64_t n_refined;       /* points of the sub-cloud that finer grid was built on */
 } gsx_sor_info;
 
 /* ---- library / device -------------------------------------------------- */
@@ -79,7 +81,11 @@ int  gsx_ctx_set_timing(gsx_ctx *ctx, int enable);
 int  gsx_ctx_reset_timing(gsx_ctx *ctx);
 /* synchronises, then returns the number of recorded launches and their summed duration */
 int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *total_ms);
-/* tuning knobs (0 keeps the default): target points per cell of the KNN grid */
+/* knobs: "grid_points_per_cell" (0 = auto), "brute_below", "adaptive" (1: bricks of the KNN grid whose
+ * neighbourhood is far denser than the cell size are re-run on a finer grid built for them; costs
+ * one host synchronisation inside gsx_sor_knn_dev, so it is ON for the host entry point
+ * gsx_sor_filter and OFF by default for contexts driven through the asynchronous _dev calls),
+ * "filter_mfma" (DESIGN.md 5.4), "debug_skip" (profiling only) */
 int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
 
 /* raw device memory for hosts that have no other allocator (bench without torch) */

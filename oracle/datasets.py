@@ -35,6 +35,17 @@ def duplicates(n: int, seed: int = 0) -> np.ndarray:
     return xyz.astype(np.float32)
 
 
+def scene_with_floaters(n: int, seed: int = 0, far: float = 500.0) -> np.ndarray:
+    """What a captured 3DGS scene looks like to a uniform grid: 99.5 % of the splats in a 10^3 box, 0.5 % 'floaters'
+    spread over (2*far)^3 -- the bounding box is 10^6 times the volume that matters."""
+    rng = np.random.default_rng(seed)
+    n_out = max(1, n // 200)
+    pts = rng.random((n - n_out, 3)) * 10.0
+    out = rng.random((n_out, 3)) * (2.0 * far) - far
+    xyz = np.concatenate([pts, out]).astype(np.float32)
+    return xyz[rng.permutation(n)]
+
+
 def lattice(m: int) -> np.ndarray:
     """m^3 integer lattice: every neighbour shell is an exact tie."""
     g = np.arange(m, dtype=np.float32)

@@ -163,6 +163,37 @@ def test_mfma_filter_variant_is_exact_too(lib, name, n, k):
     ctx.close()
 
 
+def test_outlier_inflated_bounding_box_is_refined(lib):
+    """the realistic failure mode of a uniform grid: 0.5 % far floaters make the bounding box 10^6 x the volume of
+    the scene, the whole scene falls into one cell, and a single-level search would be quadratic (minutes at 1M).
+    The host entry point re-runs the deferred bricks on a finer grid; result identical to cKDTree."""
+    xyz = datasets.scene_with_floaters(150_000, 3)
+    ref = osor.sor(xyz, 16, 1.0)
+    import time
+    t0 = time.perf_counter()
+    res = lib.sor_filter(xyz, 16, 1.0, want_info=True)
+    dt = time.perf_counter() - t0
+    assert _explain(res["mean_dists"], ref["mean_dists"]) == "ok", res["info"]
+    np.testing.assert_array_equal(res["mask"], ref["mask"])
+    assert res["info"]["n_deferred_bricks"] > 0 and res["info"]["n_refined"] > 140_000, res["info"]
+    assert dt < 1.0, "refinement did not kick in: %.2f s" % dt  # single level: ~3 s of GPU time at this size
+    # the same cloud through the asynchronous device API with the knob off and on
+    ctx = lib.Context(0)
+    small = datasets.scene_with_floaters(30_000, 4)
+    rs = osor.mean_dists_ckdtree(small, 16)
+    cols = [np.ascontiguousarray(small[:, a]) for a in range(3)]
+    d = [ctx.alloc(4 * len(small)).upload(c) for c in cols]
+    out = ctx.alloc(4 * len(small))
+    for ad in (0, 1):
+        ctx.set_param("adaptive", ad)
+        info = ctx.sor_knn(d[0].ptr, d[1].ptr, d[2].ptr, 1, len(small), 0, len(small), 16, out.ptr, algo=GRID, want_info=True)
+        assert _explain(out.download(np.float32, len(small)), rs) == "ok", (ad, info)
+        assert (info["n_deferred_bricks"] > 0) == bool(ad)
+    for a in d + [out]:
+        a.free()
+    ctx.close()
+
+
 def test_stats_kernel_matches_numpy(lib):
     """gsx_sor_stats_dev == np.mean / np.std / threshold, bit for bit, at ragged sizes"""
     rng = np.random.default_rng(9)

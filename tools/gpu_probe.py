@@ -41,7 +41,7 @@ def run(ctx, xyz, k, algo, m=None, reps=3, label=""):
     msg = " ".join("%s=%.3fms" % (k_, v[1] / max(v[0], 1) * (v[0] / reps)) for k_, v in slots.items())
     print("%-28s n=%9d k=%2d algo=%d m=%s wall=%.3f ms  %.1f Msplat/s | %s | dims=%s cells=%d bricks=%d fallback=%d exh=%d"
           % (label, n, k, algo, m, wall, n / wall / 1e3, msg, info["grid_dim"], info["n_cells"], info["n_bricks"],
-             info["n_fallback"], info["n_exhaustive"]), flush=True)
+             info["n_fallback"], info["n_exhaustive"]) + (" deferred_bricks=%d refined_pts=%d" % (info["n_deferred_bricks"], info["n_refined"]) if info.get("n_deferred_bricks") else ""), flush=True)
     for a in d + [out, st, mk]:
         a.free()
 
@@ -140,8 +140,12 @@ def main():
     host_level(x1, 16, "host 1M")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import datasets
-    run(ctx, datasets.clustered(200_000, 1), 16, 2, 0.0, reps=1, label="clustered 200k")
-    run(ctx, datasets.clustered(1_000_000, 1), 16, 2, 0.0, reps=1, label="clustered 1M")
+    for ad in (0, 1):
+        ctx.set_param("adaptive", ad)
+        run(ctx, datasets.clustered(200_000, 1), 16, 2, 0.0, reps=1, label="clustered 200k adaptive=%d" % ad)
+        run(ctx, datasets.clustered(1_000_000, 1), 16, 2, 0.0, reps=1, label="clustered 1M adaptive=%d" % ad)
+        run(ctx, x1, 16, 2, 0.0, reps=5, label="uniform 1M adaptive=%d" % ad)
+    ctx.set_param("adaptive", 0)
     if not quick:
         run(ctx, x1, 16, 1, None, reps=1, label="brute 1M")
         x10 = uniform(10_000_000, 5.0)
