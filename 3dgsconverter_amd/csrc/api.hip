@@ -200,7 +200,9 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
     } else if (!strcmp(name, "debug_skip")) {
         c->debug_skip = (int)value;
     } else if (!strcmp(name, "adaptive")) {
-        c->adaptive = value != 0.0;
+        c->adaptive = (int)value;
+    } else if (!strcmp(name, "defer_words")) {
+        c->defer_words = (int)value;
     } else if (!strcmp(name, "filter_mfma")) {
         c->filter_mfma = value != 0.0;
     } else {

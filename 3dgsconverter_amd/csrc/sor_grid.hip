@@ -24,6 +24,7 @@
 // the k+1 smallest in a register-resident sorted list.  A query is exact iff its (k+1)-th
 // distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is farther.
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 
 #include "gsx_common.h"
@@ -322,6 +323,10 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->extra_count = 0;
     gp->heavy_limit = defer_words > 0 ? HEAVY_RING_CANDIDATES : 0;  // both need the host in the loop
     gp->heavy_count = 0;
+    for (int a = 0; a < 3; ++a) {
+        gp->qb_lo[a] = __builtin_inff();
+        gp->qb_hi[a] = -__builtin_inff();
+    }
     gp->deferred_count = 0;
     gp->sub_count = 0;
     gp->sub_queries = 0;
@@ -621,6 +626,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 
     WorkQueue wq;
     const int part_lo = gp->part_lo;
+    const int dw = EXTRA ? 0 : gp->defer_words;  // loaded once: gp is written by atomics, the compiler would reload it per brick
     wq_init(wq, EXTRA ? gp->extra_ctr : gp->brick_ctr, EXTRA ? (int)gp->extra_count : gp->part_hi - part_lo,
             BRICK_THREADS / 64);
     for (;;) {
@@ -667,7 +673,6 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
             // reach millions.  Such a brick is not searched here: it goes on the deferred list, and the
             // host re-runs the whole pipeline on the points of the deferred neighbourhoods with a grid
             // sized for THEM (launch_knn_grid, refine_level).
-            const int dw = gp->defer_words;
             if (dw > 0 && nq > 0) {
                 int ncand = 0;
 #pragma unroll
@@ -935,13 +940,14 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 
             // ---- exact iff the (k+1)-th distance lies inside the searched cells
             if (live) {
+                const double kth_d2 = lst.kth(kk);
                 if (dbg & 8) {
-                    if (lst.kth(kk) == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
+                    if (kth_d2 == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
                 } else if (dbg & 4) {
-                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)lst.kth(kk);
-                } else if (lst.kth(kk) <= racc_sq) {
+                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)kth_d2;
+                } else if (kth_d2 <= racc_sq) {
+                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth_d2;
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
-                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = lst.kth(kk);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);
                     faillist[slot] = (unsigned)qidx;
@@ -1272,10 +1278,61 @@ __global__ __launch_bounds__(64) void mark_cells_kernel(const GridParams *__rest
     if (own_pass ? own : true) cellflag[cell_index_of(gp, cx, cy, cz)] = own_pass ? 3 : 1;
 }
 
+__device__ __forceinline__ void atomic_min_f32(float *addr, float v)  // finite v; *addr starts at +inf
+{
+    if (v >= 0.0f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float *addr, float v)  // finite v; *addr starts at -inf
+{
+    if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+
+// bounding box and number of the finer level's queries (points of the cells flagged 3)
+__global__ __launch_bounds__(256) void query_bbox_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs, int n,
+                                                         const uint8_t *__restrict__ cellflag)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    bool isq = false;
+    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) {
+        P = refs[j];
+        const int cx = cell_coord(P.x, gp->ox, gp->inv_h, gp->nx), cy = cell_coord(P.y, gp->oy, gp->inv_h, gp->ny),
+                  cz = cell_coord(P.z, gp->oz, gp->inv_h, gp->nz);
+        isq = cellflag[cell_index_of(gp, cx, cy, cz)] == 3;
+    }
+    const unsigned long long m = __ballot(isq);
+    if (m == 0) return;
+    float lo[3] = {isq ? P.x : __builtin_inff(), isq ? P.y : __builtin_inff(), isq ? P.z : __builtin_inff()};
+    float hi[3] = {isq ? P.x : -__builtin_inff(), isq ? P.y : -__builtin_inff(), isq ? P.z : -__builtin_inff()};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomic_min_f32(&gp->qb_lo[a], lo[a]);
+            atomic_max_f32(&gp->qb_hi[a], hi[a]);
+        }
+        atomicAdd(&gp->sub_queries, (unsigned)__builtin_popcountll(m));
+    }
+}
+
+struct ClipBox {
+    float lo[3], hi[3];  // reference points outside are not gathered
+    float r_cert;        // every such point is farther than this from every query (0 = no clipping)
+};
+
 // gather the points of the flagged cells into a SoA sub-cloud (any order); wave-aggregated append
 __global__ __launch_bounds__(256) void gather_sub_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs, int n,
-                                                         const uint8_t *__restrict__ cellflag, float *__restrict__ sub,
-                                                         unsigned *__restrict__ sub_orig, unsigned *__restrict__ sub_sorted)
+                                                         const uint8_t *__restrict__ cellflag, ClipBox clip,
+                                                         float *__restrict__ sub, unsigned *__restrict__ sub_orig,
+                                                         unsigned *__restrict__ sub_sorted)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned flag = 0;
@@ -1285,6 +1342,10 @@ __global__ __launch_bounds__(256) void gather_sub_kernel(GridParams *__restrict_
         const int cx = cell_coord(P.x, gp->ox, gp->inv_h, gp->nx), cy = cell_coord(P.y, gp->oy, gp->inv_h, gp->ny),
                   cz = cell_coord(P.z, gp->oz, gp->inv_h, gp->nz);
         flag = cellflag[cell_index_of(gp, cx, cy, cz)];
+        if (flag == 1 && clip.r_cert > 0.0f &&
+            !(P.x >= clip.lo[0] && P.x <= clip.hi[0] && P.y >= clip.lo[1] && P.y <= clip.hi[1] && P.z >= clip.lo[2] &&
+              P.z <= clip.hi[2]))
+            flag = 0;  // a reference point farther than r_cert from the box of the queries
     }
     const unsigned long long take = __ballot(flag != 0);
     if (take == 0) return;
@@ -1310,8 +1371,8 @@ __global__ __launch_bounds__(256) void merge_sub_kernel(GridParams *__restrict__
                                                         const unsigned *__restrict__ sub_orig,
                                                         const unsigned *__restrict__ sub_sorted,
                                                         const float *__restrict__ submean, const double *__restrict__ subkth,
-                                                        int q_begin, float *__restrict__ mean_out, double *__restrict__ kth_out,
-                                                        unsigned *__restrict__ faillist)
+                                                        int q_begin, float r_cert, float *__restrict__ mean_out,
+                                                        double *__restrict__ kth_out, unsigned *__restrict__ faillist)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= gp->sub_count) return;
@@ -1323,7 +1384,7 @@ __global__ __launch_bounds__(256) void merge_sub_kernel(GridParams *__restrict__
     const int dim[3] = {gp->nx, gp->ny, gp->nz};
     const int bd[3] = {gp->bdx, gp->bdy, gp->bdz};
     const float hf = (float)gp->hprime;
-    float rsafe = 3.0e38f;
+    float rsafe = r_cert > 0.0f ? r_cert : 3.0e38f;  // clipped references: see gather_sub_kernel
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const int c = cell_coord(q[a], o[a], gp->inv_h, dim[a]);
@@ -1478,7 +1539,7 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
     return 0;
 }
 
-constexpr int DEFER_WORDS = 512;  // ~35x the candidate words of a brick of a uniform cloud
+// candidate words of a brick's neighbourhood above which it is deferred (a uniform cloud has ~15)
 
 static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *y, const float *z, int64_t stride,
                           int64_t n_ref, int64_t q_begin, int64_t q_count, int k, float *mean_out, double *kth_out,
@@ -1529,7 +1590,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        w.bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, w.bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? DEFER_WORDS : 0,
+                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0,
                        parent_h, gp);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs));
@@ -1570,8 +1631,43 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_HIP(hipMemsetAsync(flag, 0, (size_t)hgp.ncells, ctx->stream));
             hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 0);
             hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 1);
+            hipLaunchKernelGGL(query_bbox_kernel, dim3(div_up(n_ref, 256)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref, flag);
+            GSX_HIP(hipGetLastError());
+            // The neighbourhood cells reach up to two of THIS level's cells beyond the queries; a stray
+            // far point among them (the very outliers that inflated the bounding box) would inflate the
+            // finer grid again.  Reference points farther than M from the queries' box are left out, and
+            // the finer level's answers are accepted only up to M: M = 4 x the cell edge the finer grid
+            // will get, i.e. ~5x its typical (k+1)-th neighbour distance.
+            ClipBox clip{};
+            {
+                GridParams hq;
+                GSX_HIP(hipMemcpyAsync(&hq, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
+                GSX_HIP(hipStreamSynchronize(ctx->stream));
+                double vol = 1.0, amax = 0.0;
+                int nd3 = 0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double e = (double)hq.qb_hi[ax] - (double)hq.qb_lo[ax];
+                    if (e > 0.0) { vol *= e; ++nd3; }
+                    amax = std::max({amax, std::fabs((double)hq.qb_lo[ax]), std::fabs((double)hq.qb_hi[ax])});
+                }
+                const double per = hq.sub_queries > 0 ? vol * pts_per_cell / (double)hq.sub_queries : 0.0;
+                const double h_est = nd3 == 3 ? std::cbrt(per) : (nd3 == 2 ? std::sqrt(per) : (nd3 == 1 ? per : 0.0));
+                const double M = std::max(4.0 * h_est, 0.01 * (double)hgp.h);
+                const double cert = M * (1.0 - 1e-3) - 4e-7 * amax;  // f32 rounding of lo - M / hi + M
+                if (ctx->adaptive == 1 && hq.sub_queries > 0 && M < 2.0 * (double)hgp.h && cert > 0.0) {
+                    for (int ax = 0; ax < 3; ++ax) {
+                        clip.lo[ax] = std::nextafterf((float)((double)hq.qb_lo[ax] - M), -__builtin_inff());
+                        clip.hi[ax] = std::nextafterf((float)((double)hq.qb_hi[ax] + M), __builtin_inff());
+                    }
+                    clip.r_cert = (float)cert;
+                }
+                if (getenv("GSX_TRACE_LEVELS"))
+                    fprintf(stderr, "[gsx] level %d: %u deferred queries in [%g,%g]x[%g,%g]x[%g,%g], clip margin %g\n", level,
+                            hq.sub_queries, hq.qb_lo[0], hq.qb_hi[0], hq.qb_lo[1], hq.qb_hi[1], hq.qb_lo[2], hq.qb_hi[2],
+                            (double)clip.r_cert);
+            }
             hipLaunchKernelGGL(gather_sub_kernel, dim3(div_up(n_ref, 256)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref, flag,
-                               sub, sub_orig, sub_sorted);
+                               clip, sub, sub_orig, sub_sorted);
             GSX_HIP(hipGetLastError());
             unsigned n_sub = 0;
             GSX_HIP(hipMemcpyAsync(&n_sub, &gp->sub_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -1584,8 +1680,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_CHECK(knn_grid_level(ctx, level + 1, sub, sub + n_ref, sub + 2 * n_ref, 1, (int64_t)n_sub, 0, (int64_t)n_sub, k,
                                      w.submean.as<float>(), w.subkth.as<double>(), nullptr, 0, 1, true, hgp.h));
             hipLaunchKernelGGL(merge_sub_kernel, dim3(div_up((int64_t)n_sub, 256)), dim3(256), 0, ctx->stream, gp, sub, (int)n_ref,
-                               sub_orig, sub_sorted, w.submean.as<float>(), w.subkth.as<double>(), (int)q_begin, mean_out,
-                               kth_out, a.faillist);
+                               sub_orig, sub_sorted, w.submean.as<float>(), w.subkth.as<double>(), (int)q_begin, clip.r_cert,
+                               mean_out, kth_out, a.faillist);
             GSX_HIP(hipGetLastError());
         }
     }

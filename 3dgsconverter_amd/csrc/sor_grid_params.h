@@ -31,6 +31,7 @@ struct GridParams {
     unsigned sub_count;       // points of the sub-cloud gathered around the deferred bricks
     unsigned sub_queries;     // ... of which queries (points of the deferred bricks themselves)
     unsigned refined_count;   // queries whose result came from a finer level
+    float qb_lo[3], qb_hi[3];  // bounding box of the points of the deferred bricks (the finer level's queries)
     int heavy_limit;          // > 0: a knn_ring query whose ring holds more candidates than this is not scanned by its
                               // single wave but handed to knn_heavy (the whole chip scans the whole cloud for it)
     unsigned heavy_count;
