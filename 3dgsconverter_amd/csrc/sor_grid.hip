@@ -1608,6 +1608,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                   w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>()};
     GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0));
 
+    const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;
     GridParams hgp;
     bool have_hgp = false;
     if (adaptive) {
@@ -1685,14 +1686,17 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_HIP(hipGetLastError());
         }
     }
-    const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;
     std::chrono::steady_clock::time_point t_ring0;
     if (trace) {
         GSX_HIP(hipStreamSynchronize(ctx->stream));
         t_ring0 = std::chrono::steady_clock::now();
     }
+    // a ring can only meet a huge cell if some brick was too populated for this level, i.e. deferred;
+    // otherwise knn_ring keeps every query (no hand-over list, no second host sync)
+    const bool heavy_possible = adaptive && have_hgp && hgp.deferred_count > 0;
+    if (adaptive && !heavy_possible) GSX_HIP(hipMemsetAsync(&gp->heavy_limit, 0, sizeof(int), ctx->stream));
     GSX_CHECK(dispatch_ring(ctx, a));
-    if (adaptive) {
+    if (heavy_possible) {
         unsigned nheavy = 0;
         GSX_HIP(hipMemcpyAsync(&nheavy, &gp->heavy_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
