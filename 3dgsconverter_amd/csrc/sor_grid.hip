@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const float *__rest
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__restrict__ gp,
                                                           const unsigned *__restrict__ bk_start,
                                                           const float4 *__restrict__ in, float4 *__restrict__ out,
-                                                          unsigned *__restrict__ cell_start)
+                                                          unsigned *__restrict__ cell_start, unsigned big_limit)
 {
     __shared__ unsigned cnt[MAX_BUCKET_CELLS];
     __shared__ unsigned wsum[4];
@@ -525,6 +525,8 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__re
     if (g.bad_input || b >= g.bk_count) return;
     const int cells = g.bk_cells;
     const unsigned s0 = bk_start[b], s1 = bk_start[b + 1];
+    if (b == g.bk_count - 1 && threadIdx.x == 0) cell_start[(size_t)g.bk_count * cells] = s1;
+    if (s1 - s0 > big_limit) return;  // sorted by the multi-workgroup path below
     const int by = b % g.bk_ny, bz = b / g.bk_ny;
     for (int i = threadIdx.x; i < cells; i += 256) cnt[i] = 0;
     __syncthreads();
@@ -558,7 +560,6 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__re
     __syncthreads();
     unsigned *cs = cell_start + (size_t)b * cells;
     for (int i = threadIdx.x; i < cells; i += 256) cs[i] = s0 + cnt[i];
-    if (b == g.bk_count - 1 && threadIdx.x == 0) cell_start[(size_t)g.bk_count * cells] = s1;
     __syncthreads();
     for (unsigned i0 = s0 + threadIdx.x; i0 < s1; i0 += 1024) {
         float4 p[4];
@@ -570,6 +571,106 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const GridParams *__re
                 const unsigned r = atomicAdd(&cnt[local_cell(p[u])], 1u);
                 out[s0 + r] = p[u];
             }
+    }
+}
+
+// ---- oversized buckets (adaptive mode only) -------------------------------------------------------
+// bucket_sort is one workgroup per bucket, sized for ~4096 points.  When far outliers inflate the
+// bounding box the whole scene lands in a handful of cells, i.e. ONE bucket holds millions of points
+// and that workgroup alone took 4.5 of the 7.5 ms of a refined 1M-splat run (40 of 53 ms at 10M).
+// Buckets above BIG_BUCKET points are instead sorted by all workgroups: every 8192-point chunk of the
+// bucket-grouped array counts its points per cell into the (zeroed) cell_start entries of the
+// bucket, one workgroup per big bucket turns the counts into cell starts + global cursors, and the
+// chunks scatter into runs reserved with one returning atomic per (chunk, non-empty cell).
+constexpr unsigned BIG_BUCKET = 32768;
+constexpr int BIG_CHUNK = 8192;
+
+// first bucket whose range contains position pos: largest b with bk_start[b] <= pos
+__device__ __forceinline__ int bucket_containing(const unsigned *bk_start, int nb, unsigned pos)
+{
+    int lo = 0, hi = nb;  // bk_start[nb] = n
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bk_start[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void big_bucket_kernel(const GridParams *__restrict__ gp, const unsigned *__restrict__ bk_start,
+                                                         int n, const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                         unsigned *cell_start /* counts (pass 1) */,
+                                                         unsigned *cursor /* global cursors (pass 2) */)
+{
+    __shared__ unsigned cnt[MAX_BUCKET_CELLS];
+    __shared__ unsigned base[SCATTER ? MAX_BUCKET_CELLS : 1];
+    const GridParams g = *gp;
+    if (g.bad_input) return;
+    const unsigned lo = (unsigned)blockIdx.x * BIG_CHUNK;
+    if (lo >= (unsigned)n) return;
+    const unsigned hi = min((unsigned)n, lo + BIG_CHUNK);
+    const int cells = g.bk_cells;
+    for (int b = bucket_containing(bk_start, g.bk_count, lo); b < g.bk_count; ++b) {  // block-uniform
+        const unsigned s0 = bk_start[b], s1 = bk_start[b + 1];
+        if (s0 >= hi) break;
+        if (s1 - s0 <= BIG_BUCKET) continue;
+        const unsigned p0 = max(lo, s0), p1 = min(hi, s1);
+        const int by = b % g.bk_ny, bz = b / g.bk_ny;
+        auto local_cell = [&](const float4 p) {
+            const int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx);
+            const int cy = cell_coord(p.y, g.oy, g.inv_h, g.ny);
+            const int cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
+            return ((cz - bz * g.bk_g) * g.bk_g + (cy - by * g.bk_g)) * g.nx + cx;
+        };
+        for (int i = threadIdx.x; i < cells; i += 256) cnt[i] = 0;
+        __syncthreads();
+        for (unsigned i = p0 + threadIdx.x; i < p1; i += 256) atomicAdd(&cnt[local_cell(in[i])], 1u);
+        __syncthreads();
+        unsigned *gc = (SCATTER ? cursor : cell_start) + (size_t)b * cells;
+        for (int i = threadIdx.x; i < cells; i += 256) {
+            const unsigned c = cnt[i];
+            if (c) {
+                const unsigned r = atomicAdd(&gc[i], c);
+                if (SCATTER) base[i] = r;
+            }
+            if (SCATTER) cnt[i] = 0;
+        }
+        __syncthreads();
+        if (SCATTER) {
+            for (unsigned i = p0 + threadIdx.x; i < p1; i += 256) {
+                const float4 p = in[i];
+                const int c = local_cell(p);
+                out[base[c] + atomicAdd(&cnt[c], 1u)] = p;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one workgroup per big bucket: counts in cell_start -> cell starts; cursors = copies
+__global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *__restrict__ gp,
+                                                              const unsigned *__restrict__ bk_start,
+                                                              unsigned *cell_start, unsigned *cursor)
+{
+    __shared__ unsigned wsum[4];
+    const GridParams g = *gp;
+    const int b = blockIdx.x;
+    if (g.bad_input || b >= g.bk_count) return;
+    const unsigned s0 = bk_start[b], s1 = bk_start[b + 1];
+    if (s1 - s0 <= BIG_BUCKET) return;
+    const int cells = g.bk_cells;
+    unsigned *cs = cell_start + (size_t)b * cells, *cu = cursor + (size_t)b * cells;
+    const int seg = (cells + 255) / 256;
+    const int c0 = min(cells, (int)threadIdx.x * seg), c1 = min(cells, c0 + seg);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cs[c];
+    unsigned tot;
+    unsigned run = s0 + block_exclusive_scan_256(sum, &tot, wsum);
+    for (int c = c0; c < c1; ++c) {
+        const unsigned v = cs[c];
+        cs[c] = run;
+        cu[c] = run;
+        run += v;
     }
 }
 
@@ -1289,37 +1390,56 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v)  // finite 
     else atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
 }
 
-// bounding box and number of the finer level's queries (points of the cells flagged 3)
+// bounding box and number of the finer level's queries (points of the cells flagged 3).  Grid-stride,
+// reduced per workgroup first: one set of same-address atomics per WAVE serialised in L2 and took
+// 12 ms at 10M splats.
 __global__ __launch_bounds__(256) void query_bbox_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs, int n,
                                                          const uint8_t *__restrict__ cellflag)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    bool isq = false;
-    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < n) {
-        P = refs[j];
+    __shared__ float s_red[4][6];
+    __shared__ unsigned s_cnt[4];
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    unsigned cnt = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float4 P = refs[j];
         const int cx = cell_coord(P.x, gp->ox, gp->inv_h, gp->nx), cy = cell_coord(P.y, gp->oy, gp->inv_h, gp->ny),
                   cz = cell_coord(P.z, gp->oz, gp->inv_h, gp->nz);
-        isq = cellflag[cell_index_of(gp, cx, cy, cz)] == 3;
+        if (cellflag[cell_index_of(gp, cx, cy, cz)] == 3) {
+            lo[0] = fminf(lo[0], P.x); lo[1] = fminf(lo[1], P.y); lo[2] = fminf(lo[2], P.z);
+            hi[0] = fmaxf(hi[0], P.x); hi[1] = fmaxf(hi[1], P.y); hi[2] = fmaxf(hi[2], P.z);
+            ++cnt;
+        }
     }
-    const unsigned long long m = __ballot(isq);
-    if (m == 0) return;
-    float lo[3] = {isq ? P.x : __builtin_inff(), isq ? P.y : __builtin_inff(), isq ? P.z : __builtin_inff()};
-    float hi[3] = {isq ? P.x : -__builtin_inff(), isq ? P.y : -__builtin_inff(), isq ? P.z : -__builtin_inff()};
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int a = 0; a < 3; ++a) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
         }
-    if (lane_id() == 0) {
+        cnt += __shfl_xor(cnt, off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomic_min_f32(&gp->qb_lo[a], lo[a]);
-            atomic_max_f32(&gp->qb_hi[a], hi[a]);
+            s_red[wv][a] = lo[a];
+            s_red[wv][3 + a] = hi[a];
         }
-        atomicAdd(&gp->sub_queries, (unsigned)__builtin_popcountll(m));
+        s_cnt[wv] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (c) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                atomic_min_f32(&gp->qb_lo[a], fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a])));
+                atomic_max_f32(&gp->qb_hi[a], fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a])));
+            }
+            atomicAdd(&gp->sub_queries, c);
+        }
     }
 }
 
@@ -1328,38 +1448,64 @@ struct ClipBox {
     float r_cert;        // every such point is farther than this from every query (0 = no clipping)
 };
 
-// gather the points of the flagged cells into a SoA sub-cloud (any order); wave-aggregated append
+// gather the points of the flagged cells into a SoA sub-cloud.  One workgroup per 8192-point chunk:
+// count, reserve the chunk's run with ONE atomic, then append in order (a returning atomic per wave
+// on the same counter cost 1.8 ms at 10M splats).
+constexpr int GATHER_CHUNK = 8192;
 __global__ __launch_bounds__(256) void gather_sub_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs, int n,
                                                          const uint8_t *__restrict__ cellflag, ClipBox clip,
                                                          float *__restrict__ sub, unsigned *__restrict__ sub_orig,
                                                          unsigned *__restrict__ sub_sorted)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned flag = 0;
-    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < n) {
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * GATHER_CHUNK, j1 = min(n, j0 + GATHER_CHUNK);
+    auto flag_of = [&](int j, float4 &P) -> unsigned {
         P = refs[j];
         const int cx = cell_coord(P.x, gp->ox, gp->inv_h, gp->nx), cy = cell_coord(P.y, gp->oy, gp->inv_h, gp->ny),
                   cz = cell_coord(P.z, gp->oz, gp->inv_h, gp->nz);
-        flag = cellflag[cell_index_of(gp, cx, cy, cz)];
+        unsigned flag = cellflag[cell_index_of(gp, cx, cy, cz)];
         if (flag == 1 && clip.r_cert > 0.0f &&
             !(P.x >= clip.lo[0] && P.x <= clip.hi[0] && P.y >= clip.lo[1] && P.y <= clip.hi[1] && P.z >= clip.lo[2] &&
               P.z <= clip.hi[2]))
             flag = 0;  // a reference point farther than r_cert from the box of the queries
+        return flag;
+    };
+    // pass 1: how many points of this chunk are taken, per wave (each wave owns a contiguous quarter)
+    const int q = (j1 - j0 + 3) / 4;
+    const int w0 = j0 + wv * q, w1 = min(j1, w0 + q);
+    unsigned mine = 0;
+    for (int j = w0 + lane; j < w1; j += 64) {
+        float4 P;
+        mine += flag_of(j, P) != 0;
     }
-    const unsigned long long take = __ballot(flag != 0);
-    if (take == 0) return;
-    const int lane = lane_id();
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&gp->sub_count, (unsigned)__builtin_popcountll(take));
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (flag != 0) {
-        const unsigned pos = base + (unsigned)__builtin_popcountll(take & ((1ull << lane) - 1ull));
-        sub[pos] = P.x;
-        sub[(size_t)n + pos] = P.y;
-        sub[2 * (size_t)n + pos] = P.z;
-        sub_orig[pos] = __float_as_uint(P.w) | (flag == 3 ? 0x80000000u : 0u);
-        sub_sorted[pos] = (unsigned)j;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) s_wave[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(&gp->sub_count, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned pos = s_base;
+    for (int i = 0; i < wv; ++i) pos += s_wave[i];
+    // pass 2: append
+    for (int jb = w0; jb < w1; jb += 64) {
+        const int j = jb + lane;
+        float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned flag = j < w1 ? flag_of(j, P) : 0u;
+        const unsigned long long take = __ballot(flag != 0);
+        if (flag != 0) {
+            const unsigned at = pos + (unsigned)__builtin_popcountll(take & ((1ull << lane) - 1ull));
+            sub[at] = P.x;
+            sub[(size_t)n + at] = P.y;
+            sub[2 * (size_t)n + at] = P.z;
+            sub_orig[at] = __float_as_uint(P.w) | (flag == 3 ? 0x80000000u : 0u);
+            sub_sorted[at] = (unsigned)j;
+        }
+        pos += (unsigned)__builtin_popcountll(take);
     }
 }
 
@@ -1522,8 +1668,9 @@ int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) +
 
 // Sort (x,y,z)[first, first+n) by cell of the grid in gp: `sorted` and `start` (cell_start) are outputs.
 static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
-                      int64_t n, GridParams *gp, unsigned *start, float4 *sorted)
+                      int64_t n, GridParams *gp, unsigned *start, float4 *sorted, int64_t cell_cap = 0, unsigned *cursor = nullptr)
 {
+    const bool big_path = cursor != nullptr;  // adaptive mode: oversized buckets are sorted by all workgroups
     unsigned *bk_cnt = w.bkcnt.as<unsigned>();
     unsigned *bk_start = bk_cnt + MAX_BUCKETS;
     unsigned *bk_cursor = bk_start + MAX_BUCKETS + 1;
@@ -1534,7 +1681,17 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, gp, bk_cnt, bk_start, bk_cursor);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n,
                        gp, bk_cursor, tmp);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(MAX_BUCKETS), dim3(256), 0, ctx->stream, gp, bk_start, tmp, sorted, start);
+    if (big_path) GSX_HIP(hipMemsetAsync(start, 0, sizeof(unsigned) * (size_t)(cell_cap + 1), ctx->stream));  // counts of big buckets
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(MAX_BUCKETS), dim3(256), 0, ctx->stream, gp, bk_start, tmp, sorted, start,
+                       big_path ? BIG_BUCKET : 0xffffffffu);
+    if (big_path) {
+        const int chunks = div_up(n, BIG_CHUNK);
+        hipLaunchKernelGGL((big_bucket_kernel<false>), dim3(chunks), dim3(256), 0, ctx->stream, gp, bk_start, (int)n, tmp, sorted,
+                           start, cursor);
+        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(MAX_BUCKETS), dim3(256), 0, ctx->stream, gp, bk_start, start, cursor);
+        hipLaunchKernelGGL((big_bucket_kernel<true>), dim3(chunks), dim3(256), 0, ctx->stream, gp, bk_start, (int)n, tmp, sorted,
+                           start, cursor);
+    }
     GSX_HIP(hipGetLastError());
     return 0;
 }
@@ -1593,7 +1750,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                        (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0,
                        parent_h, gp);
     GSX_HIP(hipGetLastError());
-    GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs));
+    if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
+    GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr));
     const float4 *qpts = refs;
     const unsigned *qstart = rstart;
     if (!all) {
@@ -1632,7 +1790,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_HIP(hipMemsetAsync(flag, 0, (size_t)hgp.ncells, ctx->stream));
             hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 0);
             hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 1);
-            hipLaunchKernelGGL(query_bbox_kernel, dim3(div_up(n_ref, 256)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref, flag);
+            hipLaunchKernelGGL(query_bbox_kernel, dim3(std::min(div_up(n_ref, 256), ctx->num_cu * 4)), dim3(256), 0, ctx->stream, gp,
+                               refs, (int)n_ref, flag);
             GSX_HIP(hipGetLastError());
             // The neighbourhood cells reach up to two of THIS level's cells beyond the queries; a stray
             // far point among them (the very outliers that inflated the bounding box) would inflate the
@@ -1667,8 +1826,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                             hq.sub_queries, hq.qb_lo[0], hq.qb_hi[0], hq.qb_lo[1], hq.qb_hi[1], hq.qb_lo[2], hq.qb_hi[2],
                             (double)clip.r_cert);
             }
-            hipLaunchKernelGGL(gather_sub_kernel, dim3(div_up(n_ref, 256)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref, flag,
-                               clip, sub, sub_orig, sub_sorted);
+            hipLaunchKernelGGL(gather_sub_kernel, dim3(div_up(n_ref, GATHER_CHUNK)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref,
+                               flag, clip, sub, sub_orig, sub_sorted);
             GSX_HIP(hipGetLastError());
             unsigned n_sub = 0;
             GSX_HIP(hipMemcpyAsync(&n_sub, &gp->sub_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
