@@ -399,7 +399,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
             info->n_fallback = hgp.fail_count;
             info->n_exhaustive = hgp.exhaustive_count;
             info->n_deferred_bricks = hgp.deferred_count;
-            info->n_refined = hgp.sub_count;
+            info->n_refined = (int64_t)c->ws[0].refined_total;
         }
     }
     return 0;

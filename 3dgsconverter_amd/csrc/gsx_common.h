@@ -74,6 +74,7 @@ struct KnnWs {
     DevBuf subkth;      // double[n_sub] (k+1)-th squared distance computed at the next level
     DevBuf heavylist;   // u32[q_count] sorted indices of the knn_ring queries handed to knn_heavy
     DevBuf heavypart;   // double[batch * chunks * KCAP] per-chunk partial top lists
+    uint64_t refined_total = 0;  // host-side: points gathered into sub-clouds by the current call
     void release_all()
     {
         DevBuf *all[] = {&packed, &qsorted, &bucketpts, &bkcnt, &cellstart, &qcellstart, &gridparams, &bboxpart,

@@ -23,7 +23,10 @@
 // private cursor, recomputes those distances in float64 exactly as cKDTree does and keeps
 // the k+1 smallest in a register-resident sorted list.  A query is exact iff its (k+1)-th
 // distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is farther.
+#include <algorithm>
 #include <chrono>
+#include <unordered_map>
+#include <vector>
 #include <cmath>
 #include <cstdlib>
 
@@ -1361,13 +1364,24 @@ __device__ __forceinline__ int cell_index_of(const GridParams *gp, int cx, int c
     return (bz_ * gp->bk_ny + by_) * gp->bk_cells + ((cz - bz_ * g) * g + (cy - by_ * g)) * gp->nx + cx;
 }
 
+// per component of deferred bricks: fresh counters and an empty query box
+__global__ void reset_refine_kernel(GridParams *gp)
+{
+    gp->sub_count = 0;
+    gp->sub_queries = 0;
+    for (int a = 0; a < 3; ++a) {
+        gp->qb_lo[a] = __builtin_inff();
+        gp->qb_hi[a] = -__builtin_inff();
+    }
+}
+
 // one 64-thread block per deferred brick: flag the cells of its neighbourhood (pass 0: value 1) and its
 // own cells (pass 1: value 3 -- their points are the queries of the finer level)
-__global__ __launch_bounds__(64) void mark_cells_kernel(const GridParams *__restrict__ gp, const unsigned *__restrict__ deferred,
-                                                        uint8_t *__restrict__ cellflag, int own_pass)
+__global__ __launch_bounds__(64) void mark_cells_kernel(const GridParams *__restrict__ gp, const unsigned *__restrict__ bricks,
+                                                        unsigned count, uint8_t *__restrict__ cellflag, int own_pass)
 {
-    if (blockIdx.x >= gp->deferred_count) return;
-    const int b = (int)deferred[blockIdx.x];
+    if (blockIdx.x >= count) return;
+    const int b = (int)bricks[blockIdx.x];
     const int nbx = gp->nbx, nby = gp->nby;
     const int bz = b / (nbx * nby), brem = b - bz * nbx * nby, by = brem / nbx, bx = brem - by * nbx;
     const int t = threadIdx.x;
@@ -1703,6 +1717,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                           gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h)
 {
     KnnWs &w = ctx->ws[level];
+    w.refined_total = 0;
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
     const int64_t cap = grid_cell_cap(n_ref);
@@ -1786,10 +1801,69 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             uint8_t *flag = w.cellflag.as<uint8_t>();
             float *sub = w.subxyz.as<float>();
             unsigned *sub_orig = w.submap.as<unsigned>(), *sub_sorted = sub_orig + n_ref;
+            // Deferred bricks that are far apart belong to different clusters with different densities:
+            // each connected group (bricks within 2 of each other, i.e. overlapping neighbourhoods)
+            // gets its own sub-cloud, hence its own bounding box and cell size.  At most 8 groups
+            // (the smallest ones are merged into the last).
+            std::vector<unsigned> dl(nd);
+            GSX_HIP(hipMemcpyAsync(dl.data(), a.deferred, sizeof(unsigned) * nd, hipMemcpyDeviceToHost, ctx->stream));
+            GSX_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<std::vector<unsigned>> groups;
+            {
+                std::unordered_map<unsigned, int> where;  // brick id -> index in dl
+                for (unsigned i = 0; i < nd; ++i) where[dl[i]] = (int)i;
+                std::vector<int> comp(nd, -1);
+                const int nbx = hgp.nbx, nby = hgp.nby, nbz = hgp.nbz;
+                for (unsigned s0i = 0; s0i < nd; ++s0i) {
+                    if (comp[s0i] >= 0) continue;
+                    const int c = (int)groups.size();
+                    groups.emplace_back();
+                    std::vector<unsigned> stack{s0i};
+                    comp[s0i] = c;
+                    while (!stack.empty()) {
+                        const unsigned i = stack.back();
+                        stack.pop_back();
+                        groups[c].push_back(dl[i]);
+                        const int b = (int)dl[i];
+                        const int bz = b / (nbx * nby), by = (b - bz * nbx * nby) / nbx, bx = b - bz * nbx * nby - by * nbx;
+                        for (int dz = -2; dz <= 2; ++dz)
+                            for (int dy = -2; dy <= 2; ++dy)
+                                for (int dx = -2; dx <= 2; ++dx) {
+                                    const int x2 = bx + dx, y2 = by + dy, z2 = bz + dz;
+                                    if (x2 < 0 || y2 < 0 || z2 < 0 || x2 >= nbx || y2 >= nby || z2 >= nbz) continue;
+                                    auto it = where.find((unsigned)((z2 * nby + y2) * nbx + x2));
+                                    if (it != where.end() && comp[it->second] < 0) {
+                                        comp[it->second] = c;
+                                        stack.push_back((unsigned)it->second);
+                                    }
+                                }
+                    }
+                }
+                std::sort(groups.begin(), groups.end(), [](const auto &l, const auto &r) { return l.size() > r.size(); });
+                while (groups.size() > 8) {
+                    groups[7].insert(groups[7].end(), groups.back().begin(), groups.back().end());
+                    groups.pop_back();
+                }
+                unsigned o = 0;
+                for (auto &g : groups) {
+                    std::copy(g.begin(), g.end(), dl.begin() + o);
+                    o += (unsigned)g.size();
+                }
+                if (groups.size() > 1) {  // one group: the device list is already it
+                    GSX_HIP(hipMemcpyAsync(a.deferred, dl.data(), sizeof(unsigned) * nd, hipMemcpyHostToDevice, ctx->stream));
+                    GSX_HIP(hipStreamSynchronize(ctx->stream));  // dl is a local
+                }
+            }
+            unsigned g_first = 0;
+            for (const auto &grp : groups) {
+            const unsigned g_count = (unsigned)grp.size();
+            const unsigned *g_list = a.deferred + g_first;
+            g_first += g_count;
             GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
             GSX_HIP(hipMemsetAsync(flag, 0, (size_t)hgp.ncells, ctx->stream));
-            hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 0);
-            hipLaunchKernelGGL(mark_cells_kernel, dim3(nd), dim3(64), 0, ctx->stream, gp, a.deferred, flag, 1);
+            hipLaunchKernelGGL(reset_refine_kernel, dim3(1), dim3(1), 0, ctx->stream, gp);
+            hipLaunchKernelGGL(mark_cells_kernel, dim3(g_count), dim3(64), 0, ctx->stream, gp, g_list, g_count, flag, 0);
+            hipLaunchKernelGGL(mark_cells_kernel, dim3(g_count), dim3(64), 0, ctx->stream, gp, g_list, g_count, flag, 1);
             hipLaunchKernelGGL(query_bbox_kernel, dim3(std::min(div_up(n_ref, 256), ctx->num_cu * 4)), dim3(256), 0, ctx->stream, gp,
                                refs, (int)n_ref, flag);
             GSX_HIP(hipGetLastError());
@@ -1822,7 +1896,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                     clip.r_cert = (float)cert;
                 }
                 if (getenv("GSX_TRACE_LEVELS"))
-                    fprintf(stderr, "[gsx] level %d: %u deferred queries in [%g,%g]x[%g,%g]x[%g,%g], clip margin %g\n", level,
+                    fprintf(stderr, "[gsx] level %d: group of %u bricks, %u deferred queries in [%g,%g]x[%g,%g]x[%g,%g], clip margin %g\n", level, g_count,
                             hq.sub_queries, hq.qb_lo[0], hq.qb_hi[0], hq.qb_lo[1], hq.qb_hi[1], hq.qb_lo[2], hq.qb_hi[2],
                             (double)clip.r_cert);
             }
@@ -1834,7 +1908,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_HIP(hipStreamSynchronize(ctx->stream));
             GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
             if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level %d: sub-cloud %u points\n", level, n_sub);
-            if (n_sub == 0) GSX_FAIL("sor: refinement gathered no points for %u deferred bricks", nd);
+            if (n_sub == 0) GSX_FAIL("sor: refinement gathered no points for %u deferred bricks", g_count);
             GSX_CHECK(w.submean.reserve(sizeof(float) * (size_t)n_sub));
             GSX_CHECK(w.subkth.reserve(sizeof(double) * (size_t)n_sub));
             GSX_CHECK(knn_grid_level(ctx, level + 1, sub, sub + n_ref, sub + 2 * n_ref, 1, (int64_t)n_sub, 0, (int64_t)n_sub, k,
@@ -1843,6 +1917,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                                sub_orig, sub_sorted, w.submean.as<float>(), w.subkth.as<double>(), (int)q_begin, clip.r_cert,
                                mean_out, kth_out, a.faillist);
             GSX_HIP(hipGetLastError());
+            w.refined_total += n_sub;
+            }
         }
     }
     std::chrono::steady_clock::time_point t_ring0;
@@ -1884,7 +1960,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         info->n_fallback = h2.fail_count;
         info->n_exhaustive = h2.exhaustive_count;
         info->n_deferred_bricks = h2.deferred_count;
-        info->n_refined = h2.sub_count;
+        info->n_refined = (int64_t)w.refined_total;
     } else if (have_hgp && hgp.bad_input && level == 0) {
         GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
     }
