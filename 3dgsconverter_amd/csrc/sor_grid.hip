@@ -710,6 +710,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
     __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
     __shared__ u32x4 s_qop[MF ? BRICK_THREADS / 64 : 1][2][64];  // MFMA filter: the query operands of both tiles
 
+    if (EXTRA && gp->extra_count == 0) return;  // the usual case: no brick shed a batch (an empty pass still cost 6.6 us)
     const int lane = lane_id();
     const int wv = uniform((int)(threadIdx.x >> 6));
     unsigned(*mask)[64] = s_mask[wv];
@@ -821,7 +822,6 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
             }
             const float4 qp = qpts[live ? qidx : 0];
             const float qx = qp.x, qy = qp.y, qz = qp.z;
-            const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
             float tau = live ? tau1 : -1.0f;
             double racc_sq = r1sq;  // this lane's acceptance radius^2 (== the exact value its filter bound comes from)
             // Queries next to the cloud's bounding box see only part of their neighbourhood ball, so
@@ -907,6 +907,8 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 
             // ---- phase 2: walk this lane's set bits, exact f64 distance, sorted insert
             auto drain = [&]() __attribute__((always_inline)) {
+                // widened here, not before phase 1: six registers that the filter loop does not have to carry
+                const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
                 wave_sync();  // wbase[] written by lane 0 is visible to every lane
                 if (dbg & 32) nzw = 0;  // profiling: masks are built but never walked
                 unsigned m = 0;
