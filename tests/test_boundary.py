@@ -141,3 +141,20 @@ def test_install_patches_reference_when_present(gsx):
     finally:
         gsx.uninstall()
     assert rdp.DataProcessor is orig
+
+
+def test_info_struct_layout_matches_the_header(gsx, tmp_path):
+    """the ctypes mirror of gsx_sor_info must have the C compiler's size and field offsets"""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "layout.c"
+    fields = [f[0] for f in gsx._lib.SorInfo._fields_]
+    body = "".join('printf("%%s %%zu\\n", "%s", offsetof(gsx_sor_info, %s));' % (f, f) for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gsx_hip.h"\nint main(void){printf("size %zu\\n", sizeof(gsx_sor_info));'
+                   + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["size"]) == C.sizeof(gsx._lib.SorInfo)
+    for f in fields:
+        assert int(out[f]) == getattr(gsx._lib.SorInfo, f).offset, f
