@@ -44,7 +44,8 @@ constexpr int BUCKET_POINTS = 4096;       // target points per bucket
 constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
-constexpr int HEAVY_CHUNK = 8192;   // points of the sorted array one wave of knn_heavy_scan covers
+constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of knn_heavy_scan covers (512 per lane: the
+                                    // per-lane top list stops changing after the first few dozen, and the wave merge amortises)
 constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
 
 // Phase-1 filter step: shift the predicate "squared distance < tau" into the lane's bit mask.
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
 // ---------------------------------------------------------------- knn_heavy (ring queries next to a huge cell)
 // A far "floater" whose ring reaches a cell holding most of the cloud would make ONE wave scan
 // millions of candidates (measured: 11 ms for 9 such queries at 1M splats).  knn_ring hands these
-// queries over; here every wave takes (query, 8192-point chunk of the WHOLE sorted array), keeps
+// queries over; here every wave takes (query, 32768-point chunk of the WHOLE sorted array), keeps
 // the k+1 smallest squared distances of its chunk, and a second kernel merges the chunks of a
 // query -- exhaustive, hence exact, and spread over the chip.
 template <int KCAP>

@@ -1,5 +1,5 @@
 #!/bin/bash
-GSX_TRACE_LEVELS=1 timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/adaptive.log
+timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/adaptive.log
 import sys, os, time
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
 import gpu_probe as g
