@@ -82,6 +82,8 @@ def make(spec: dict) -> np.ndarray:
         return lattice(spec["m"])
     if kind == "two_blobs":
         return two_blobs(spec["n"], spec.get("seed", 0), spec.get("ratio", 0.25), spec.get("gap", 6.0))
+    if kind == "scene_with_floaters":
+        return scene_with_floaters(spec["n"], spec.get("seed", 0), spec.get("far", 500.0))
     if kind == "centered":
         return centered(spec["n"], spec.get("extent", 10.0), spec.get("seed", 0))
     raise ValueError(kind)

@@ -52,6 +52,8 @@ SOR_CASES = [
     ("sor_u20k_int5", {"kind": "uniform", "n": 20000, "extent": 10.0, "seed": 6}, 25, 10.5, 5, False),
     ("sor_u20k_int10", {"kind": "uniform", "n": 20000, "extent": 10.0, "seed": 6}, 25, 10.5, 10, False),
     ("sor_centered40k_k16_s1", {"kind": "centered", "n": 40000, "extent": 200.0, "seed": 7}, 16, 1.0, None, False),
+    # a scene whose bounding box is inflated 10^6 x by far floaters (what SOR is for; adaptive grid on the GPU)
+    ("sor_scene150k_k16_s1", {"kind": "scene_with_floaters", "n": 150000, "seed": 3}, 16, 1.0, None, False),
 ]
 
 DENSITY_CASES = [
