@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
 constexpr int brick_min_waves(int kcap, bool mf)
 {
-    // the MFMA filter keeps 16 accumulators + 12 operand registers live on top of the top-k list
-    return mf ? (kcap <= 17 ? 5 : (kcap <= 26 ? 3 : 2)) : (kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2)));
+    (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
+    return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
 template <int KCAP, bool EXTRA, bool MF>
@@ -705,18 +705,17 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra,
     unsigned *__restrict__ deferred, double *__restrict__ kth_out)
 {
-    // the MFMA variant parks its query operands in LDS too: 22 words keep a workgroup under 32 KiB (5 per CU)
-    constexpr int WCAP = MF ? 22 : gsx::WCAP;
+    constexpr int WCAP = gsx::WCAP;
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
     __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
-    __shared__ u32x4 s_qop[MF ? BRICK_THREADS / 64 : 1][2][64];  // MFMA filter: the query operands of both tiles
+    __shared__ uint2 s_wseg[MF ? BRICK_THREADS / 64 : 1][MF ? WCAP : 1];  // MFMA words may span two rows: (c1, b2 - c1)
 
     if (EXTRA && gp->extra_count == 0) return;  // the usual case: no brick shed a batch (an empty pass still cost 6.6 us)
     const int lane = lane_id();
     const int wv = uniform((int)(threadIdx.x >> 6));
     unsigned(*mask)[64] = s_mask[wv];
     unsigned *wbase = s_wbase[wv];
-    u32x4(*qop)[64] = s_qop[MF ? wv : 0];
+    uint2 *wseg = s_wseg[MF ? wv : 0];
 
     const int nx = gp->nx, ny = gp->ny, nz = gp->nz;
     const int nbx = gp->nbx, nby = gp->nby;
@@ -900,8 +899,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                     }
                 }
             }
-            TopList<KCAP> lst;
-            lst.init();
+            TopList<KCAP> lst;  // initialised where phase 1 needs it live (see the MFMA single-drain path)
 
             int widx = 0;
             unsigned nzw = 0;
@@ -913,7 +911,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                 wave_sync();  // wbase[] written by lane 0 is visible to every lane
                 if (dbg & 32) nzw = 0;  // profiling: masks are built but never walked
                 unsigned m = 0;
-                int base = 0;
+                int base = 0, c1 = 32, base2 = 0;
                 // software pipeline: the gather of candidate n+1 is in flight while candidate n goes
                 // through the float64 distance + the 2*KCAP-op sorted insert
                 bool have_cur = false;
@@ -924,13 +922,18 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                         nzw &= nzw - 1;
                         m = mask[w][lane];
                         base = (int)wbase[w];
+                        if constexpr (MF) {
+                            const uint2 sg = wseg[w];
+                            c1 = (int)sg.x;
+                            base2 = (int)sg.y;
+                        }
                     }
                     const bool have_next = m != 0;
                     float4 pn = pc;
                     if (have_next) {
                         const int i = __builtin_clz(m);
                         m &= ~(0x80000000u >> i);
-                        pn = refs[base + i];
+                        pn = refs[(MF && i >= c1 ? base2 : base) + i];
                     }
                     if (have_cur && !(dbg & 1)) lst.insert(dist2_f64(qxd, qyd, qzd, pc.x, pc.y, pc.z));
                     if (!__any(have_next)) break;
@@ -944,7 +947,35 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
             };
 
             // ---- phase 1: lock-step filter over the 16 candidate rows
+            // MFMA variant: only when ALL mask words of the batch fit the LDS park (the usual case).  Then
+            // phase 2 runs exactly once, after phase 1, and the 2*KCAP registers of the top-k list are not
+            // live while the 16 accumulators and the operands are: both phases fit 5 waves/SIMD without
+            // spills (carrying the list through the MFMA loop cost 41-46 spilled dwords and made
+            // phase 2 40 % slower).  A batch with more words takes the scalar filter.
+            bool mf_done = false;
             if constexpr (MF) {
+                // number of words the cutting below will produce (same rule: a word holds at most two row segments)
+                int nwords = 0;
+                {
+                    int fill = 0, segs = 0;
+                    for (int r = 0; r < ncrows; ++r) {
+                        int len = __builtin_amdgcn_readlane(rs_len, r & 15);
+                        while (len > 0) {
+                            if (fill == 32 || segs == 2) {
+                                ++nwords;
+                                fill = 0;
+                                segs = 0;
+                            }
+                            const int take = min(len, 32 - fill);
+                            fill += take;
+                            len -= take;
+                            ++segs;
+                        }
+                    }
+                    nwords += fill > 0;
+                }
+                if (nwords <= WCAP && !(dbg & 2)) {
+                mf_done = true;
                 // cell-unit coordinates relative to the brick centre; see the MFMA notes at the top
                 const float hf = (float)hp;
                 const float ccx = g_ox + ((float)(bx * bdx) + 0.5f * (float)bdx) * hf;
@@ -953,69 +984,87 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                 const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
                 const float nq2 = __builtin_fmaf(uqz, uqz, __builtin_fmaf(uqy, uqy, uqx * uqx));
                 const bool upper = lane >= 32;
-                float tau_built = -2.0f;  // tau the operands were built for
-                // The candidate rows are walked as one flat sequence of 32-candidate words; the point
-                // of word n+1 is requested before word n is processed (a per-lane 16-B load takes
-                // ~1-2k cycles from L2/HBM, one word is ~300 cycles of work).
-                const int nrows = (dbg & 2) ? 0 : ncrows;
-                struct Word { int r, w0, gs, c; };  // wave-uniform
-                auto next_word = [&](Word w) __attribute__((always_inline)) {
-                    // advance to the next word of the current row or to the first word of the next non-empty row
-                    int r = w.r, w0 = w.w0 + 32;
-                    int len = r >= 0 && r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
-                    while (r < nrows && w0 >= len) {
+                // (tau * inv_h) * inv_h: no overflow for tiny cells; dead lanes (tau = -1) never pass
+                const float s_q = tau >= 0.0f ? nq2 - ((tau * g_inv_h) * g_inv_h * (1.0f + 1e-6f) + MF_SLACK) : 1.0e30f;
+                bf16x8 opa, opb;
+                mf_query_operands(uqx, uqy, uqz, s_q, opa, opb);
+                // The candidate rows are walked as ONE flat sequence cut into 32-candidate words; a word may
+                // continue into the next non-empty row (two segments at most), otherwise the ~25 % of rows
+                // with 33..40 candidates would each cost a second, almost empty, MFMA pair.  The points of
+                // words n+1 and n+2 are requested before word n is processed (a per-lane 16-B load takes
+                // ~1-2k cycles from L2/HBM, one word is ~400 cycles of work).
+                const int nrows = ncrows;
+                struct Word { int b1, c1, b2, c2, r, off; };  // wave-uniform; r/off = where the NEXT word starts
+                auto next_word = [&](int r, int off) __attribute__((always_inline)) {
+                    Word o{0, 0, 0, 0, r, off};
+                    int len = r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
+                    while (r < nrows && off >= len) {  // skip exhausted / empty rows
                         ++r;
-                        w0 = 0;
+                        off = 0;
                         len = r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
                     }
-                    Word o;
+                    if (r < nrows) {
+                        o.b1 = __builtin_amdgcn_readlane(rs_start, r & 15) + off;
+                        o.c1 = min(32, len - off);
+                        off += o.c1;
+                        if (o.c1 < 32) {  // row finished inside the word: continue with the next non-empty row
+                            do {
+                                ++r;
+                                off = 0;
+                                len = r < nrows ? __builtin_amdgcn_readlane(rs_len, r & 15) : 0;
+                            } while (r < nrows && len == 0);
+                            if (r < nrows) {
+                                o.b2 = __builtin_amdgcn_readlane(rs_start, r & 15);
+                                o.c2 = min(32 - o.c1, len);
+                                off = o.c2;
+                            }
+                        }
+                    }
                     o.r = r;
-                    o.w0 = w0;
-                    o.gs = r < nrows ? __builtin_amdgcn_readlane(rs_start, r & 15) : 0;
-                    o.c = min(32, len - w0);
+                    o.off = off;
                     return o;
                 };
                 const int my_cand = mf_cand_of_row(lane & 31);
                 auto fetch = [&](const Word &w) __attribute__((always_inline)) {
-                    return w.r < nrows ? refs[w.gs + w.w0 + min(my_cand, w.c - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c = w.c1 + w.c2;
+                    if (c == 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int t = min(my_cand, c - 1);  // slots past the end repeat the last candidate (masked out below)
+                    return refs[t < w.c1 ? w.b1 + t : w.b2 + (t - w.c1)];
                 };
-                Word w_cur = next_word(Word{-1, 0, 0, 0});
-                float4 p_cur = fetch(w_cur);
-                while (w_cur.r < nrows) {
-                    const Word w_n1 = next_word(w_cur);
-                    const float4 p_n1 = fetch(w_n1);
-                    if (widx == WCAP) drain();
-                    if (__any(tau != tau_built)) {  // first word, and after a drain tightened some lane's tau
-                        // (tau * inv_h) * inv_h: no overflow for tiny cells.  ALL lanes rebuild: the
-                        // operands are exchanged between the two half-waves.
-                        const float s_q = tau >= 0.0f ? nq2 - ((tau * g_inv_h) * g_inv_h * (1.0f + 1e-6f) + MF_SLACK) : 1.0e30f;
-                        bf16x8 opa, opb;
-                        mf_query_operands(uqx, uqy, uqz, s_q, opa, opb);
-                        qop[0][lane] = __builtin_bit_cast(u32x4, opa);  // parked in LDS: 8 fewer live VGPRs,
-                        qop[1][lane] = __builtin_bit_cast(u32x4, opb);  // two ds_read_b128 per word
-                        tau_built = tau;
-                    }
+                Word w_cur = next_word(0, 0);
+                Word w_n1 = next_word(w_cur.r, w_cur.off);
+                float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
+                while (w_cur.c1 > 0) {
+                    const Word w_n2 = next_word(w_n1.r, w_n1.off);
+                    const float4 p_n2 = fetch(w_n2);
                     const bf16x8 cand = mf_candidate_operand((p_cur.x - ccx) * g_inv_h, (p_cur.y - ccy) * g_inv_h,
                                                              (p_cur.z - ccz) * g_inv_h, upper);
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     // lane l: tile a = rows-set (l>>5) of query l&31, tile b = of query 32 + (l&31)
-                    const bf16x8 opa = __builtin_bit_cast(bf16x8, qop[0][lane]);
                     const unsigned ma = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opa, zero, 0, 0, 0));
-                    const bf16x8 opb = __builtin_bit_cast(bf16x8, qop[1][lane]);
                     const unsigned mb = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opb, zero, 0, 0, 0));
                     auto sw = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
                     // now sw[0] = rows-set 0, sw[1] = rows-set 1 of THIS lane's query; drop the bits of
                     // the clamped duplicates past the end of a partial word
-                    const unsigned m = ((sw[0] << 16) | (sw[1] & 0xffffu)) & (0xffffffffu << (32 - w_cur.c));
+                    const unsigned m = ((sw[0] << 16) | (sw[1] & 0xffffu)) & (0xffffffffu << (32 - (w_cur.c1 + w_cur.c2)));
                     if (dbg & 64) atomicAdd(&gp->exhaustive_count, (unsigned)__builtin_popcount(m));  // profiling: candidates passed
                     mask[widx][lane] = m;
-                    if (lane == 0) wbase[widx] = (unsigned)(w_cur.gs + w_cur.w0);
+                    if (lane == 0) {
+                        wbase[widx] = (unsigned)w_cur.b1;
+                        wseg[widx] = make_uint2((unsigned)w_cur.c1, (unsigned)(w_cur.b2 - w_cur.c1));
+                    }
                     nzw |= (m != 0 ? 1u : 0u) << widx;
                     ++widx;
                     w_cur = w_n1;
                     p_cur = p_n1;
+                    w_n1 = w_n2;
+                    p_n1 = p_n2;
                 }
-            } else {
+                lst.init();
+                }
+            }
+            if (!mf_done) {
+            lst.init();
             for (int r = 0; r < ((dbg & 2) ? 0 : ncrows); ++r) {
                 const int gs = __builtin_amdgcn_readlane(rs_start, r);
                 const int len = __builtin_amdgcn_readlane(rs_len, r);
@@ -1043,7 +1092,10 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                     m <<= (32 - c);  // candidate i of this word <-> bit 31-i
                     if (dbg & 64) atomicAdd(&gp->exhaustive_count, (unsigned)__builtin_popcount(m));  // profiling: candidates passed
                     mask[widx][lane] = m;
-                    if (lane == 0) wbase[widx] = (unsigned)(gs + w0);
+                    if (lane == 0) {
+                        wbase[widx] = (unsigned)(gs + w0);
+                        if constexpr (MF) wseg[widx] = make_uint2(32u, 0u);
+                    }
                     nzw |= (m != 0 ? 1u : 0u) << widx;
                     ++widx;
                 }
