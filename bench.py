@@ -141,7 +141,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_note": traffic_note, "algorithmic_bytes": int(alg_bytes),
-                "valu_busy_frac_pmc": 0.94, "valu_source": "profiles/r01_pmc_10m_sq.txt (SQ_ACTIVE_INST_VALU / SIMD cycles)",
+                "valu_busy_frac_pmc": 0.82, "valu_source": "profiles/r01_pmc_10m_sq.txt (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8), 10M splats)",
                 "kernel_ms": round(knn_ms, 4), "algorithmic_bytes_per_splat": bytes_per_splat,
                 "note": "kernel is FP32/FP64 VALU-issue bound, not HBM bound (DESIGN.md section 5); "
                         "PMC HBM traffic per launch is in profiles/"}
