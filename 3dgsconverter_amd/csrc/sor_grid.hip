@@ -15,20 +15,27 @@
 //                                          whose (k+1)-th neighbour is farther than one cell
 //
 // knn_brick: the 64 lanes of a wave are 64 queries of one brick (2x2x2 cells for k <= 16, fewer
-// cells for larger k).  The brick's neighbourhood (brick + 1 cell each way, 4x4x4 cells) is 16 x-rows, each a CONTIGUOUS range of the sorted array; the wave walks
-// those ranges in lock step with wave-uniform (scalar-cache) loads -- no LDS staging, no
-// per-lane addressing.  Phase 1 only FILTERS: 6 f32 ops for the squared distance, one
-// compare against r_safe^2 and one shift-or build a per-lane bit mask (32 candidates per
-// word, words parked in LDS).  Phase 2 walks each lane's set bits (~4.19*m of ~512) with a
-// private cursor, recomputes those distances in float64 exactly as cKDTree does and keeps
-// the k+1 smallest in a register-resident sorted list.  A query is exact iff its (k+1)-th
-// distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is farther.
+// cells for larger k).  The brick's neighbourhood (brick + 1 cell each way, 4x4x4 cells) is 16
+// x-rows, each a CONTIGUOUS range of the sorted array, which the wave walks in lock step.
+// Phase 1 only FILTERS: it builds a per-lane bit mask of the candidates
+// whose squared distance is below r_safe^2 (32 candidates per word, words parked in LDS) -- for a
+// batch whose words all fit the park with one v_mfma_f32_32x32x16_bf16 per 32 candidates x 32
+// queries on bf16-split coordinates (see "MFMA phase-1 filter" below), otherwise with 6 f32 ops per
+// candidate on scalar-cache loads and a sign-bit shift-in.  Phase 2 walks each lane's set bits
+// (~4.19*m of ~512) with a private cursor, recomputes those distances in float64 exactly as
+// cKDTree does and keeps the k+1 smallest in a register-resident sorted list.  A query is exact
+// iff its (k+1)-th distance is <= r_safe = h*(1-1e-3): every point outside the searched cells is
+// farther.
+//
+// Clouds the uniform grid cannot resolve (bounding box inflated by far outliers, clusters far
+// denser than a cell) are handled by knn_grid_level's adaptive refinement: bricks that would be
+// too expensive are deferred to a finer grid built on their neighbourhood, exactly.
 #include <algorithm>
 #include <chrono>
-#include <unordered_map>
-#include <vector>
 #include <cmath>
 #include <cstdlib>
+#include <unordered_map>
+#include <vector>
 
 #include "gsx_common.h"
 #include "knn_common.h"
