@@ -62,7 +62,11 @@ __device__ __forceinline__ void wq_init(WorkQueue &q, unsigned *ctr8x32, int n, 
     const int lo = (int)(((long long)n * y) / 8), hi = (int)(((long long)n * (y + 1)) / 8);
     const int wl = (int)(blockIdx.x >> 3) * waves_per_block + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     q.stride = (((int)gridDim.x + 7 - y) / 8) * waves_per_block;  // waves whose home is y
-    const int rounds = (int)(((long long)(hi - lo) * 85 / 100) / q.stride);  // full static rounds
+    // share handed out statically: 85 % when a wave gets dozens of items (the atomics cost more than the
+    // imbalance), less when it only gets a handful and one 2-batch brick too many is a 20 % longer wave
+    const int per_wave = n / max(1, (int)gridDim.x * waves_per_block);
+    const int pct = per_wave >= 16 ? 85 : (per_wave >= 6 ? 70 : 50);
+    const int rounds = (int)(((long long)(hi - lo) * pct / 100) / q.stride);  // full static rounds
     q.next = lo + wl;
     q.static_end = lo + rounds * q.stride;
     q.end = hi;
