@@ -42,7 +42,7 @@ void DevBuf::release()
 
 int timing_begin(gsx_ctx *ctx, int slot)
 {
-    if (!ctx->timing) return 0;
+    if (!ctx->timing || !((ctx->timing_mask >> slot) & 1u)) return 0;
     TimingSlot &s = ctx->slots[slot];
     if (s.used + 2 > s.ev.size()) {
         for (int i = 0; i < 64; ++i) {
@@ -57,7 +57,7 @@ int timing_begin(gsx_ctx *ctx, int slot)
 
 int timing_end(gsx_ctx *ctx, int slot)
 {
-    if (!ctx->timing) return 0;
+    if (!ctx->timing || !((ctx->timing_mask >> slot) & 1u)) return 0;
     TimingSlot &s = ctx->slots[slot];
     GSX_HIP(hipEventRecord(s.ev[s.used + 1], ctx->stream));
     s.used += 2;
@@ -199,6 +199,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->brute_below = (int64_t)value;
     } else if (!strcmp(name, "debug_skip")) {
         c->debug_skip = (int)value;
+    } else if (!strcmp(name, "timing_mask")) {
+        c->timing_mask = (unsigned)value;
     } else if (!strcmp(name, "adaptive")) {
         c->adaptive = (int)value;
     } else if (!strcmp(name, "defer_words")) {

@@ -97,6 +97,7 @@ struct gsx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    unsigned timing_mask = 0xffffffffu;  // slots that record events when timing is on (an event pair costs ~8 us of stream time)
     gsx::TimingSlot slots[GSX_T_SLOTS];
     int num_cu = 256;
 

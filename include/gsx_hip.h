@@ -85,7 +85,9 @@ int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *tota
  * neighbourhood is far denser than the cell size are re-run on a finer grid built for them; costs
  * one host synchronisation inside gsx_sor_knn_dev, so it is ON for the host entry point
  * gsx_sor_filter and OFF by default for contexts driven through the asynchronous _dev calls),
- * "filter_mfma" (1 = matrix-core phase-1 filter, default), "debug_skip" (profiling only) */
+ * "filter_mfma" (1 = matrix-core phase-1 filter, default), "timing_mask" (bit s set = slot
+ * GSX_T_s records events while timing is enabled; default all -- every event pair costs stream time),
+ * "debug_skip" (profiling only) */
 int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
 
 /* raw device memory for hosts that have no other allocator (bench without torch) */
