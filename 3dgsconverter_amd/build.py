@@ -36,6 +36,8 @@ def newest_dep() -> float:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("GSX_EXTRA_FLAGS", "").split()  # experiment builds only (e.g. -DGSX_ABLATE); forces a rebuild
+    force = force or bool(extra)
     os.makedirs(OBJ, exist_ok=True)
     dep_t = newest_dep()
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= dep_t:
@@ -45,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, src[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_t:
             return obj
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

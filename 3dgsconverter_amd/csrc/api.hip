@@ -198,7 +198,13 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
     } else if (!strcmp(name, "brute_below")) {
         c->brute_below = (int64_t)value;
     } else if (!strcmp(name, "debug_skip")) {
+#ifdef GSX_ABLATE
         c->debug_skip = (int)value;
+#else
+        if (value != 0.0) GSX_FAIL("debug_skip needs a profiling build of the library (-DGSX_ABLATE); this one computes exact results only");
+#endif
+    } else if (!strcmp(name, "phase2_net")) {
+        c->phase2_net = value != 0.0;
     } else if (!strcmp(name, "timing_mask")) {
         c->timing_mask = (unsigned)value;
     } else if (!strcmp(name, "adaptive")) {

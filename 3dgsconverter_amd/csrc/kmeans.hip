@@ -115,15 +115,20 @@ __global__ __launch_bounds__(64 * NW) void kmeans_assign_kernel(const float *__r
             }
             s_idx[0][threadIdx.x] = bi;
             if (threadIdx.x < rows) {
+                // bi == -1: every distance was NaN or >= 1e20 (non-finite or huge input).  The reference
+                // then indexes centroids[-1] (gpu_ops.py:85-88: undefined in Taichi); here the point keeps
+                // label -1 and contributes to no cluster.
                 labels[base + threadIdx.x] = bi;
-                atomicAdd(LACC ? &s_cnt[bi] : &counts[bi], 1u);
+                if (bi >= 0) atomicAdd(LACC ? &s_cnt[bi] : &counts[bi], 1u);
             }
         }
         __syncthreads();
         // k_means_update's accumulation (gpu_ops.py:83-89) while the tile is still in LDS
         for (int e = threadIdx.x; e < rows * D; e += 64 * NW) {
             const int r = e / D, d = e - r * D;
-            const int64_t slot = (int64_t)s_idx[0][r] * D + d;
+            const int lbl = s_idx[0][r];
+            if (lbl < 0) continue;  // unassignable point (see above)
+            const int64_t slot = (int64_t)lbl * D + d;
             unsafeAtomicAdd(LACC ? &s_acc[slot] : &sums[slot], (double)s_tile[r * DP + d]);
         }
     }
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
         const int64_t i = e / D;
         const int d = (int)(e - i * D);
         const int l = labels[i];
+        if (l < 0) continue;  // unassignable point: label -1, no contribution
         unsafeAtomicAdd(&sums[(int64_t)l * D + d], (double)data[e]);
         if (d == 0) atomicAdd(&counts[l], 1u);
     }

@@ -89,6 +89,126 @@ struct TopList {
     }
 };
 
+// ---- selection by sorting network (knn_brick phase 2) ----------------------------------------------
+// The bubble insert above costs 2*KCAP float64 ops per candidate, and a wave runs it max-over-lanes
+// times (~44 for ~30 candidates per lane at k = 16): 1500 of the ~4600 VALU instructions of a batch.
+// TopNet keeps the L smallest squared distances of the query's NEIGHBOURS -- the query itself is
+// excluded by its index, so L = k for the power-of-two k the headline configs use -- and takes
+// candidates in blocks of BS = min(L, 16): a block is sorted by Batcher's odd-even merge sort
+// (63 compare-exchanges for 16), merged into the list with the bitonic rule
+//     c[i] = min(a[i], b[L-1-i])   ->   c holds the L smallest and is bitonic
+// and log2(L) half-cleaner stages sort c again: (63 + 32) CE + 16 min = 206 ops per 16 candidates
+// at L = 16, i.e. 13 ops per candidate instead of 34.  All indices are compile-time constants:
+// the list and the block stay in VGPRs.
+__device__ __forceinline__ void ce_f64(double &lo, double &hi)  // compare-exchange, no NaNs ever
+{
+    double a, b;
+    asm("v_min_f64 %0, %1, %2" : "=v"(a) : "v"(lo), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(b) : "v"(lo), "v"(hi));
+    lo = a;
+    hi = b;
+}
+
+// Batcher's odd-even merge sort, ascending, N a power of two; fully unrolled (lo/r/N are constants)
+template <int N, int LO, int R, int SPAN>
+__device__ __forceinline__ void oe_merge(double *v)
+{
+    constexpr int STEP = R * 2;
+    if constexpr (STEP < SPAN) {
+        oe_merge<N, LO, STEP, SPAN>(v);
+        oe_merge<N, LO + R, STEP, SPAN>(v);
+#pragma unroll
+        for (int i = LO + R; i < LO + SPAN - R; i += STEP) ce_f64(v[i], v[i + R]);
+    } else {
+        ce_f64(v[LO], v[LO + R]);
+    }
+}
+template <int N, int LO, int SPAN>
+__device__ __forceinline__ void oe_sort(double *v)
+{
+    if constexpr (SPAN > 1) {
+        oe_sort<N, LO, SPAN / 2>(v);
+        oe_sort<N, LO + SPAN / 2, SPAN / 2>(v);
+        oe_merge<N, LO, 1, SPAN>(v);
+    }
+}
+
+template <int L>
+struct TopNet {
+    static_assert((L & (L - 1)) == 0 && L >= 8, "list length must be a power of two");
+    static constexpr int BS = L < 16 ? L : 16;
+    double a[L];  // ascending, +inf padded
+
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < L; ++i) a[i] = __builtin_inf();
+    }
+    // j-th smallest (1-based, wave-uniform j <= L); same select chain as TopList::kth
+    __device__ __forceinline__ double kth(int j) const
+    {
+        double r = a[L - 1];
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) {
+            r = (j - 1 == i) ? a[i] : r;
+            asm("" : "+v"(r));
+        }
+        return r;
+    }
+    // the list is still all +inf: the sorted block IS the list
+    __device__ __forceinline__ void assign_block(double (&b)[BS])
+    {
+        oe_sort<BS, 0, BS>(b);
+#pragma unroll
+        for (int i = 0; i < BS; ++i) a[i] = b[i];
+    }
+    __device__ __forceinline__ void merge_block(double (&b)[BS])
+    {
+        oe_sort<BS, 0, BS>(b);
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            double c;
+            asm("v_min_f64 %0, %1, %2" : "=v"(c) : "v"(a[L - BS + i]), "v"(b[BS - 1 - i]));
+            a[L - BS + i] = c;
+        }
+#pragma unroll
+        for (int half = L / 2; half >= 1; half /= 2)
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+                if ((i & half) == 0) ce_f64(a[i], a[i + half]);
+    }
+};
+
+// epilogue for TopNet: entries 0..k-1 are the neighbours (the query was never inserted)
+template <int L>
+__device__ __forceinline__ float mean_from_net(const TopNet<L> &lst, int k)
+{
+    double b[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) b[j] = __dsqrt_rn(lst.a[j]);
+    double res;
+    if (k < 8) {
+        res = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7 && j < L; ++j)
+            if (j < k) res = __dadd_rn(res, b[j]);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r[t] = b[t];
+        const int nfull = k - (k % 8);
+#pragma unroll
+        for (int j = 8; j < L; ++j)
+            if (j < nfull) r[j & 7] = __dadd_rn(r[j & 7], b[j]);
+        res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                        __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+#pragma unroll
+        for (int j = 8; j < L; ++j)
+            if (j >= nfull && j < k) res = __dadd_rn(res, b[j]);
+    }
+    return __double2float_rn(__ddiv_rn(res, (double)k));
+}
+
 // numpy pairwise sum of n <= 128 doubles read through a functor (loops_utils.h.src);
 // used where the values sit in LDS (dynamic indexing is free there)
 template <class F>

@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -699,14 +700,27 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
-constexpr int brick_min_waves(int kcap, bool mf)
+#ifndef GSX_NET_WAVES17
+#define GSX_NET_WAVES17 3
+#endif
+#ifndef GSX_NET_HB
+#define GSX_NET_HB 4
+#endif
+#ifndef GSX_NET_BF
+#define GSX_NET_BF 1
+#endif
+constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
+    // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
+    if (net) return kcap <= 9 ? 5 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? 3 : 2));
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
-template <int KCAP, bool EXTRA, bool MF>
-__global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_brick_kernel(
+// NET: phase 2 selects with TopNet<KCAP-1> (sorting-network blocks, the query excluded by index) instead
+// of the per-candidate bubble insert of TopList<KCAP>; needs KCAP-1 to be a power of two.
+template <int KCAP, bool EXTRA, bool MF, bool NET>
+__global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void knn_brick_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ qstart, int k, int q_begin,
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra,
@@ -714,8 +728,11 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 {
     constexpr int WCAP = gsx::WCAP;
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
+    // per mask word: first candidate (index into refs); (c1, b2 - c1): candidates of the first row segment and the
+    // offset of the second (MFMA words may span two rows).  Two narrow arrays: one 16-byte entry per word read
+    // with per-lane indices cost 0.14 ms at 10M splats (LDS bank conflicts)
     __shared__ unsigned s_wbase[BRICK_THREADS / 64][WCAP];
-    __shared__ uint2 s_wseg[MF ? BRICK_THREADS / 64 : 1][MF ? WCAP : 1];  // MFMA words may span two rows: (c1, b2 - c1)
+    __shared__ uint2 s_wseg[MF ? BRICK_THREADS / 64 : 1][MF ? WCAP : 1];
 
     if (EXTRA && gp->extra_count == 0) return;  // the usual case: no brick shed a batch (an empty pass still cost 6.6 us)
     const int lane = lane_id();
@@ -739,8 +756,13 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
         const int by_ = cy / bk_g, bz_ = cz / bk_g;
         return (bz_ * bk_ny + by_) * bk_cells + ((cz - bz_ * bk_g) * bk_g + (cy - by_ * bk_g)) * nx;
     };
+#ifdef GSX_ABLATE  // profiling build only (results become wrong): -DGSX_ABLATE + gsx_ctx_set_param("debug_skip")
     const int dbg = gp->debug_skip;
+#else
+    constexpr int dbg = 0;
+#endif
     const int kk = k + 1;
+    const int kq = NET ? k : kk;  // position of the acceptance distance in the list (NET lists do not hold the query)
 
     WorkQueue wq;
     const int part_lo = gp->part_lo;
@@ -906,7 +928,9 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                     }
                 }
             }
-            TopList<KCAP> lst;  // initialised where phase 1 needs it live (see the MFMA single-drain path)
+            // initialised where phase 1 needs it live (see the MFMA single-drain path)
+            typename std::conditional<NET, TopNet<NET ? KCAP - 1 : 8>, TopList<KCAP>>::type lst;
+            bool lst_empty = true;  // wave-uniform: no block merged yet (NET)
 
             int widx = 0;
             unsigned nzw = 0;
@@ -919,6 +943,76 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                 if (dbg & 32) nzw = 0;  // profiling: masks are built but never walked
                 unsigned m = 0;
                 int base = 0, c1 = 32, base2 = 0;
+                if constexpr (NET) {
+                    // Blocks of BS candidates per lane: the lane's next BS set bits are gathered (HB loads in
+                    // flight), their exact distances fill a register block (+inf where the lane has run out, and
+                    // for the query's own point), one sorting network orders the block and a bitonic merge folds
+                    // it into the list.  The wave repeats while any lane has bits left.
+                    using Net = TopNet<NET ? KCAP - 1 : 8>;
+                    constexpr int BS = Net::BS, HB = GSX_NET_HB < BS ? GSX_NET_HB : BS;
+                    const unsigned self_w = __float_as_uint(qp.w);
+                    for (;;) {
+                        double blk[BS];
+#pragma unroll
+                        for (int h0 = 0; h0 < BS; h0 += HB) {
+                            float4 pt[HB];
+                            bool ok[HB];
+#pragma unroll
+                            for (int j = 0; j < HB; ++j) {
+#if GSX_NET_BF >= 2
+                                {   // branch-free word advance: every lane reads a word, only lanes that ran dry keep it
+                                    const bool adv = m == 0 && nzw != 0;
+                                    const int w = adv ? __builtin_ctz(nzw) : 0;
+                                    nzw = adv ? (nzw & (nzw - 1)) : nzw;
+                                    const unsigned mw = mask[w][lane];
+                                    m = adv ? mw : m;
+                                    base = adv ? (int)wbase[w] : base;
+                                    if constexpr (MF) {
+                                        const uint2 sg = wseg[w];
+                                        c1 = adv ? (int)sg.x : c1;
+                                        base2 = adv ? (int)sg.y : base2;
+                                    }
+                                }
+#else
+                                if (m == 0 && nzw != 0) {
+                                    const int w = __builtin_ctz(nzw);
+                                    nzw &= nzw - 1;
+                                    m = mask[w][lane];
+                                    base = (int)wbase[w];
+                                    if constexpr (MF) {
+                                        const uint2 sg = wseg[w];
+                                        c1 = (int)sg.x;
+                                        base2 = (int)sg.y;
+                                    }
+                                }
+#endif
+                                ok[j] = m != 0;
+#if GSX_NET_BF
+                                // branch-free: a lane that has run out (m == 0) re-reads candidate 0 of its last
+                                // word (a valid, cached address) and the result is discarded below
+                                const int i = ok[j] ? __builtin_clz(m) : 0;
+                                m &= ~(0x80000000u >> i);  // m == 0 stays 0
+                                pt[j] = refs[(MF && i >= c1 ? base2 : base) + i];
+#else
+                                pt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (ok[j]) {
+                                    const int i = __builtin_clz(m);
+                                    m &= ~(0x80000000u >> i);
+                                    pt[j] = refs[(MF && i >= c1 ? base2 : base) + i];
+                                }
+#endif
+                            }
+#pragma unroll
+                            for (int j = 0; j < HB; ++j) {
+                                const double d = dist2_f64(qxd, qyd, qzd, pt[j].x, pt[j].y, pt[j].z);
+                                blk[h0 + j] = (ok[j] && __float_as_uint(pt[j].w) != self_w) ? d : __builtin_inf();
+                            }
+                        }
+                        if (uniform((int)lst_empty)) lst.assign_block(blk); else lst.merge_block(blk);
+                        lst_empty = false;
+                        if (!__any(m != 0 || nzw != 0)) break;
+                    }
+                } else {
                 // software pipeline: the gather of candidate n+1 is in flight while candidate n goes
                 // through the float64 distance + the 2*KCAP-op sorted insert
                 bool have_cur = false;
@@ -947,7 +1041,8 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
                     pc = pn;
                     have_cur = have_next;
                 }
-                tau = fminf(tau, bound_from(lst.kth(kk)));
+                }
+                tau = fminf(tau, bound_from(lst.kth(kq)));
                 widx = 0;
                 nzw = 0;
                 wave_sync();  // all reads of mask/wbase done before they are overwritten
@@ -1112,14 +1207,15 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF)) void knn_
 
             // ---- exact iff the (k+1)-th distance lies inside the searched cells
             if (live) {
-                const double kth_d2 = lst.kth(kk);
+                const double kth_d2 = lst.kth(kq);
                 if (dbg & 8) {
                     if (kth_d2 == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
                 } else if (dbg & 4) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)kth_d2;
                 } else if (kth_d2 <= racc_sq) {
                     if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth_d2;
-                    mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
+                    if constexpr (NET) mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_net(lst, k);
+                    else mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
                 } else {
                     unsigned slot = atomicAdd(&gp->fail_count, 1u);
                     faillist[slot] = (unsigned)qidx;
@@ -1647,7 +1743,7 @@ struct BrickLaunch {
     unsigned *heavylist;
 };
 
-template <int KCAP, bool MF>
+template <int KCAP, bool MF, bool NET>
 static int launch_bricks(gsx_ctx *ctx, const BrickLaunch &a)
 {
     // Work is assigned STATICALLY to waves, so every launched workgroup must be resident at once:
@@ -1655,16 +1751,16 @@ static int launch_bricks(gsx_ctx *ctx, const BrickLaunch &a)
     // workgroup would run its share only after a resident one has finished all of its own).
     static int occ_brick = 0, occ_extra = 0;
     if (!occ_brick) {
-        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false, MF>, BRICK_THREADS, 0));
-        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true, MF>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_brick, knn_brick_kernel<KCAP, false, MF, NET>, BRICK_THREADS, 0));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_extra, knn_brick_kernel<KCAP, true, MF, NET>, BRICK_THREADS, 0));
         occ_brick = std::max(1, std::min(occ_brick, 8));
         occ_extra = std::max(1, std::min(occ_extra, 8));
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false, MF>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, false, MF, NET>), dim3(ctx->num_cu * occ_brick), dim3(BRICK_THREADS), 0, ctx->stream,
                        a.gp, a.refs, a.rstart, a.qpts, a.qstart, a.k, (int)a.q_begin, a.mean_out, a.faillist, a.extra,
                        a.deferred, a.kth_out);
-    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true, MF>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL((knn_brick_kernel<KCAP, true, MF, NET>), dim3(ctx->num_cu * occ_extra), dim3(BRICK_THREADS), 0, ctx->stream,
                        a.gp, a.refs, a.rstart, a.qpts, a.qstart, a.k, (int)a.q_begin, a.mean_out, a.faillist, a.extra,
                        a.deferred, a.kth_out);
     GSX_HIP(hipGetLastError());
@@ -1721,11 +1817,21 @@ static int dispatch_heavy(gsx_ctx *ctx, KnnWs &w, const BrickLaunch &a, int64_t 
     return launch_heavy<65>(ctx, w, a, n_ref, heavy_count);
 }
 
-// list-capacity buckets; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10)
-static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf)
+// list-capacity buckets.  Sorting-network selection (default): the list holds k neighbours, capacities 8, 16,
+// 32, 64 (template argument = capacity + 1).  Bubble-insert selection (phase2_net = 0, kept for A/B): k + 1
+// entries incl. the query; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10).
+static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net)
 {
     const int kk = a.k + 1;
-#define GSX_BRICKS(K) (mf ? launch_bricks<K, true>(ctx, a) : launch_bricks<K, false>(ctx, a))
+    if (net) {
+#define GSX_BRICKS(K) (mf ? launch_bricks<K, true, true>(ctx, a) : launch_bricks<K, false, true>(ctx, a))
+        if (kk <= 9) return GSX_BRICKS(9);
+        if (kk <= 17) return GSX_BRICKS(17);
+        if (kk <= 33) return GSX_BRICKS(33);
+        return GSX_BRICKS(65);
+#undef GSX_BRICKS
+    }
+#define GSX_BRICKS(K) (mf ? launch_bricks<K, true, false>(ctx, a) : launch_bricks<K, false, false>(ctx, a))
     if (kk <= 9) return GSX_BRICKS(9);
     if (kk <= 17) return GSX_BRICKS(17);
     if (kk <= 26) return GSX_BRICKS(26);
@@ -1847,7 +1953,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
 
     BrickLaunch a{gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, kth_out, w.faillist.as<unsigned>(),
                   w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>()};
-    GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0));
+    GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0, ctx->phase2_net != 0));
 
     const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;
     GridParams hgp;

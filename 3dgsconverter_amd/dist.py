@@ -30,6 +30,10 @@ from dataclasses import dataclass
 from typing import Callable, Optional
 
 
+PARALLELISM = ("index-sharded input; all-gather of xyz rows, per-rank slab of the grid's bricks, sum all-reduce of "
+               "the mean distances (RCCL), statistics evaluated redundantly per rank")
+
+
 @dataclass
 class ShardedSorResult:
     mask_local: "object"        # uint8/bool tensor [n_local]

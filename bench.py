@@ -3,13 +3,15 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n SPLATS_PER_GPU] [--k 16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload kmeans        # BASELINE.json configs[4] (SOG palette K-Means), 1 GPU
 
-One step = one pass of the hot path over one batch of synthetic splats whose xyz is already
-resident in HBM: (all-gather of xyz, N>1) -> grid binning -> exact KNN mean distance
-(knn_brick + knn_ring) -> (all-gather of mean distances, N>1) -> numpy-exact mean/std/
-threshold -> survivor mask.  Workload at N=1: BASELINE.json configs[1] (1M uniform splats,
-L=10, seed 0, k=16, sigma=1.0); each extra GPU adds one more 1M-splat index shard (weak
-scaling).  Prints ONE JSON line (rank 0).
+One SOR step = one pass of the hot path over one batch of synthetic splats whose xyz is already
+resident in HBM: (exchange, N>1) -> grid binning -> exact KNN mean distance (knn_brick + knn_ring)
+-> numpy-exact mean/std/threshold -> survivor mask.  Workload at N=1: the configuration
+BASELINE.json's target is quoted on -- 10M uniform-random splats (L=5, seed 0: SURVEY.md 8(d)
+config 3's cloud), k=16, sigma=1.0; each extra GPU adds one more 10M-splat index shard (weak
+scaling).  The 1M-splat configs[1] cloud is timed in the same run and reported under "secondary".
+Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -34,18 +36,34 @@ def synth_shard(n, extent, seed):
     return np.random.default_rng(seed).random((n, 3), dtype=np.float32) * np.float32(extent)
 
 
+def load_pmc(kernel, n, k):
+    """Static PMC figures of the last committed rocprofv3 --pmc passes (counters cannot be read in-process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f).get(kernel, {}).get("%d:%d" % (n, k))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000, help="splats per GPU")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sor", choices=["sor", "kmeans"])
+    ap.add_argument("--n", type=int, default=10_000_000, help="splats per GPU")
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--sigma", type=float, default=1.0)
-    ap.add_argument("--extent", type=float, default=10.0)
+    ap.add_argument("--extent", type=float, default=5.0)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (grid), 1 brute force, 2 grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-splat configs[1] line")
+    ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
     args = ap.parse_args()
+
+    if args.workload == "kmeans":
+        from importlib import import_module
+        return import_module("tools.bench_kmeans").main(args)
 
     import torch  # first: its bundled HIP runtime (same SONAME) is the one the .so binds to
     import torch.distributed as dist
@@ -62,70 +80,95 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     gsx = importlib.import_module("3dgsconverter_amd")
-    from importlib import import_module
-    gdist = import_module("3dgsconverter_amd.dist")
+    gdist = importlib.import_module("3dgsconverter_amd.dist")
     L = gsx._lib
     compute = gdist.HipCompute(local_rank)
     ctx = compute.ctx
-
-    xyz_host = synth_shard(args.n, args.extent, rank)
-    xyz_local = torch.from_numpy(xyz_host).to(dev)
-    torch.cuda.synchronize()
+    for kv in args.param:
+        name, val = kv.split("=")
+        ctx.set_param(name, float(val))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
+    def run(n, extent, steps, warmup, side=True):
+        """Time `steps` SOR steps on a fresh n-splat shard; returns a dict of raw measurements."""
+        xyz_host = synth_shard(n, extent, rank)
+        xyz_local = torch.from_numpy(xyz_host).to(dev)
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    # HIP events around the dominant kernel only inside the timed region: each event pair costs stream
-    # time (measured: all five slots = +0.04 ms on the 0.38 ms step, profiles/r01_timing_overhead.log)
-    ctx.set_param("timing_mask", 1 << L.T_SOR_KNN)
-    ctx.set_timing(True)
-    ctx.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
-    n_knn, ms_knn = ctx.timing(L.T_SOR_KNN)
+        def step():
+            return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
 
-    # the other kernel groups: a short separate pass with every slot recording (not part of the timed region)
-    ctx.set_param("timing_mask", 0xff)
-    ctx.reset_timing()
-    side_steps = min(args.steps, 10)
-    for _ in range(side_steps):
-        step()
-    barrier()
-    n_bin, ms_bin = ctx.timing(L.T_SOR_BIN)
-    n_fb, ms_fb = ctx.timing(L.T_SOR_FALLBACK)
-    n_st, ms_st = ctx.timing(L.T_SOR_STATS)
-    ctx.set_timing(False)
-    info = ctx.sor_knn(*(lambda t: (t.data_ptr(), t.data_ptr() + 4, t.data_ptr() + 8))(xyz_local), 3,
-                       args.n, 0, args.n, args.k, res.mean_dists_local.data_ptr(), algo=args.algo,
-                       want_info=True) if world == 1 else None
+        for _ in range(warmup):
+            res = step()
+        barrier()
+        # HIP events around the dominant kernel only inside the timed region: each event pair costs stream
+        # time (all five slots = +0.04 ms on a 0.38 ms step, profiles/r01_timing_overhead.log)
+        ctx.set_param("timing_mask", 1 << L.T_SOR_KNN)
+        ctx.set_timing(True)
+        ctx.reset_timing()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dt = float(t_max.item())
+        n_knn, ms_knn = ctx.timing(L.T_SOR_KNN)
+        out = {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "res": res, "xyz_host": xyz_host, "xyz_local": xyz_local}
+        if side:
+            # the other kernel groups: a short separate pass with every slot recording (not in the timed region)
+            ctx.set_param("timing_mask", 0xff)
+            ctx.reset_timing()
+            side_steps = min(steps, 10)
+            for _ in range(side_steps):
+                step()
+            barrier()
+            out["side_steps"] = side_steps
+            out["kernel_ms_per_step"] = {
+                "knn": round(ms_knn / steps, 4),
+                "bin": round(ctx.timing(L.T_SOR_BIN)[1] / side_steps, 4),
+                "fallback": round(ctx.timing(L.T_SOR_FALLBACK)[1] / side_steps, 4),
+                "stats": round(ctx.timing(L.T_SOR_STATS)[1] / side_steps, 4),
+                "note": "knn: HIP events inside the timed region; the others: a separate pass of %d steps" % side_steps}
+        ctx.set_timing(False)
+        return out
+
+    main_run = run(args.n, args.extent, args.steps, args.warmup)
+    res = main_run["res"]
+    info = None
+    if world == 1:
+        t = main_run["xyz_local"]
+        info = ctx.sor_knn(t.data_ptr(), t.data_ptr() + 4, t.data_ptr() + 8, 3, args.n, 0, args.n, args.k,
+                           res.mean_dists_local.data_ptr(), algo=args.algo, want_info=True)
+    secondary = None
+    if world == 1 and not args.no_secondary and args.n != 1_000_000:
+        r2 = run(1_000_000, 10.0, max(args.steps, 50), max(args.warmup, 5), side=False)
+        secondary = {"workload": "BASELINE.json configs[1]: 1000000 uniform-random splats (L=10, seed 0), SOR k=%d sigma=%g" % (args.k, args.sigma),
+                     "value": round(1_000_000 * max(args.steps, 50) / r2["dt"] / 1e6, 2), "unit": "Msplats/s",
+                     "ms_per_step": round(r2["dt"] / max(args.steps, 50) * 1e3, 4), "steps": max(args.steps, 50),
+                     "knn_kernel_ms": round(r2["knn_ms"], 4),
+                     "survivors": int(r2["res"].mask_local.sum().item())}
+        del r2
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    dt = main_run["dt"]
     n_total = world * args.n
     ms_per_step = dt / args.steps * 1e3
     value = n_total * args.steps / dt / 1e6  # Msplats/s, whole job
 
     # ---- roofline of the dominant kernel (knn_brick, or knn_brute with --algo 1)
-    knn_ms = ms_knn / max(n_knn, 1)
+    knn_ms = main_run["knn_ms"]
     if args.algo != 1:
         # algorithmic bytes of ONE knn_brick launch (DESIGN.md section 5): every brick streams its
         # 4x4x4-cell neighbourhood once (16 B/point, = 8x its own 2x2x2 cells on average), every
@@ -138,23 +181,24 @@ def main():
         kernel = "knn_brute_kernel"
     alg_bytes = bytes_per_splat * args.n
     achieved = alg_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
-    traffic, traffic_note = None, None
-    try:  # PMC counters cannot be read from inside the process: the last rocprofv3 --pmc passes are committed
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            pmc = json.load(f).get(kernel, {}).get("%d:%d" % (args.n, args.k))
-        if pmc and world == 1:
-            traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
-            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_latest.json); fetch as "
-                            "counted, x2-corrected upper bound %d B" % (pmc["fetch_x2_upper"] + pmc["write_bytes"]))
-    except Exception:
-        pass
-    roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_note": traffic_note, "algorithmic_bytes": int(alg_bytes),
-                "valu_busy_frac_pmc": 0.82, "valu_source": "profiles/r01_pmc_10m_sq.txt (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8), 10M splats)",
-                "kernel_ms": round(knn_ms, 4), "algorithmic_bytes_per_splat": bytes_per_splat,
-                "note": "kernel is FP32/FP64 VALU-issue bound, not HBM bound (DESIGN.md section 5); "
-                        "PMC HBM traffic per launch is in profiles/"}
+    pmc = load_pmc(kernel, args.n, args.k) if world == 1 else None
+    traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc and "fetch_bytes" in pmc else None
+    valu = None
+    if pmc and "valu_busy_frac" in pmc:
+        valu = {"busy_frac": pmc["valu_busy_frac"], "insts_per_launch": pmc.get("valu_insts"),
+                "kind": "static: rocprofv3 --pmc pass of this build committed under profiles/ (%s), not measured in this run" % pmc.get("source", "pmc_latest.json")}
+    roofline = {
+        # the contract's fields: algorithmic HBM bytes of one launch / its HIP-event duration vs the 8 TB/s peak
+        "bound": "valu", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json "
+                         "(fetch as counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
+        "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_per_splat": bytes_per_splat,
+        "kernel_ms": round(knn_ms, 4),
+        "binding_resource": {"name": "VALU issue (f32 filter assembly + f64 exact distances, selection network, sqrt)",
+                             "valu": valu,
+                             "note": "achieved/peak/frac above are the HBM figures BASELINE.json's metric asks for; the "
+                                     "kernel is limited by VALU issue, not by HBM (DESIGN.md section 5)"}}
 
     out = {
         "metric": "Msplats/sec SOR k=%d" % args.k, "value": round(value, 2), "unit": "Msplats/s",
@@ -165,17 +209,16 @@ def main():
                                "exact KNN, xyz resident in HBM" % (args.n, args.extent, args.k, args.sigma),
                    "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma,
                    "algo": "grid-binned exact KNN" if args.algo != 1 else "LDS-tiled brute force",
-                   "parallelism": "index-sharded queries, all-gather xyz + all-gather mean_dists (RCCL)"
-                   if world > 1 else "single GPU"},
+                   "parallelism": gdist.PARALLELISM if world > 1 else "single GPU"},
         "roofline": roofline,
-        "kernel_ms_per_step": {"knn": round(ms_knn / args.steps, 4), "bin": round(ms_bin / side_steps, 4),
-                               "fallback": round(ms_fb / side_steps, 4), "stats": round(ms_st / side_steps, 4),
-                               "note": "knn: HIP events inside the timed region; the others: a separate pass of %d steps" % side_steps},
+        "kernel_ms_per_step": main_run["kernel_ms_per_step"],
         "survivors_rank0": int(res.mask_local.sum().item()),
         "threshold": float(res.stats[2].item()),
     }
     if info is not None:
         out["grid"] = info
+    if secondary is not None:
+        out["secondary"] = secondary
 
     if world == 1 and not args.no_cpu_baseline:
         # reported baseline, not the target: the reference's CPU path (cKDTree + numpy, restated in
@@ -183,7 +226,7 @@ def main():
         from oracle import sor as osor
         workers = max(1, (os.cpu_count() or 2) - 1)
         t0 = time.perf_counter()
-        ref = osor.sor(xyz_host, args.k, args.sigma, workers=workers)
+        ref = osor.sor(main_run["xyz_host"], args.k, args.sigma, workers=workers)
         cpu_dt = time.perf_counter() - t0
         same = bool(np.array_equal(ref["mask"], res.mask_local.cpu().numpy().astype(bool)))
         out["cpu_baseline"] = {"value": round(args.n / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": workers,

@@ -12,9 +12,15 @@ Parity status (details in DESIGN.md):
     ``DataProcessor.remove_flyers`` CPU path in the build container
     (oracle/make_golden.py), and the restatements here reproduce them bit for bit.
   * voxel-density filter: PINNED the same way (``apply_density_filter``).
-  * K-Means (Taichi Lloyd kernels): PARITY UNPINNED -- Taichi is not installable
-    here and every reference K-Means path is unseeded; the oracle
-    follows the kernel source text with an injected init.
+  * K-Means (Taichi Lloyd kernels): PINNED -- tests/golden/kmeans_ref.* were produced by the
+    reference's own ``k_means_assign`` / ``k_means_update`` / ``_kmeans_taichi`` executed through
+    oracle/taichi_shim.py (a test-only stand-in for the uninstallable ``taichi`` that runs the
+    kernel bodies as Python with Taichi's default f32/i32 types; ``np.random.seed`` pins the
+    unseeded init), by its sklearn front door under ``np.random.seed``, and by its
+    ``SogFormat.write`` (bundle decoded with pillow) -- oracle/make_golden_kmeans.py.  The C
+    restatement with binary32 index-order accumulation reproduces the Lloyd fixtures bit for
+    bit; the GPU is compared within the floating-point tolerance of SURVEY.md 8(c) (the
+    reference itself is order-nondeterministic: f32 atomics, backend-dependent FMA contraction).
 """
 from __future__ import annotations
 
@@ -61,5 +67,7 @@ def clib() -> ctypes.CDLL:
         lib.gsxo_kmeans_update.restype = None
         lib.gsxo_kmeans_update.argtypes = [
             c.c_void_p, c.c_int64, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p]
+        lib.gsxo_kmeans_update_f32seq.restype = None
+        lib.gsxo_kmeans_update_f32seq.argtypes = lib.gsxo_kmeans_update.argtypes
         _lib = lib
     return _lib

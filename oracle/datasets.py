@@ -87,3 +87,46 @@ def make(spec: dict) -> np.ndarray:
     if kind == "centered":
         return centered(spec["n"], spec.get("extent", 10.0), spec.get("seed", 0))
     raise ValueError(kind)
+
+
+# ---- K-Means / SOG inputs (oracle/make_golden_kmeans.py, tests/test_kmeans_*.py) ---------------------
+def km_data(spec: dict) -> np.ndarray:
+    """Synthetic K-Means inputs (SURVEY.md 8(d) config 5 distributions, scaled down)."""
+    rng = np.random.default_rng(spec["seed"])
+    kind = spec["kind"]
+    if kind == "normal":      # f_rest ~ N(0, 0.1^2), scales ~ N(-4, 1), f_dc ~ N(0, 1)
+        return (rng.standard_normal((spec["n"], spec["d"])) * spec.get("sigma", 1.0) + spec.get("mu", 0.0)).astype(np.float32)
+    if kind == "repeated":    # every distinct row appears `rep` times: coinciding initial centroids -> empty clusters
+        base = (rng.standard_normal((spec["n"] // spec["rep"], spec["d"])) * 0.1).astype(np.float32)
+        return np.repeat(base, spec["rep"], axis=0)[rng.permutation(spec["n"] // spec["rep"] * spec["rep"])]
+    if kind == "lattice2d":   # integer lattice: exact distance ties between centroids (lowest index must win)
+        g = np.arange(spec["m"], dtype=np.float32)
+        pts = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+        return np.tile(pts, (spec["rep"], 1))[rng.permutation(len(pts) * spec["rep"])].copy()
+    raise ValueError(kind)
+
+
+def splat_dtype(sh_degree: int = 3):
+    """The reference's standard table layout (structures.py:23-59, no prefix, no RGB): 62 x f4 at degree 3."""
+    n_rest = 3 * ((sh_degree + 1) ** 2 - 1)
+    names = (["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(n_rest)] +
+             ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"])
+    return [(nm, "f4") for nm in names]
+
+
+def sog_scene(n: int, seed: int, sh_degree: int = 3) -> np.ndarray:
+    """A synthetic splat table (structured array) with every column the SOG writer reads."""
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n, dtype=splat_dtype(sh_degree))
+    xyz = (rng.standard_normal((n, 3)) * 3.0).astype(np.float32)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    for i in range(3):
+        a["f_dc_%d" % i] = rng.standard_normal(n).astype(np.float32)
+        a["scale_%d" % i] = (rng.standard_normal(n) - 4.0).astype(np.float32)
+    for i in range(3 * ((sh_degree + 1) ** 2 - 1)):
+        a["f_rest_%d" % i] = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    a["opacity"] = (rng.standard_normal(n) * 2.0).astype(np.float32)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    for i in range(4):
+        a["rot_%d" % i] = q[:, i]
+    return a

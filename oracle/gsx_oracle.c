@@ -237,9 +237,9 @@ void gsxo_voxel_keys(const float *xyz, int64_t n, double voxel_size, int64_t *ke
 
 /* ------------------------------------------------------------------ *
  * Lloyd iteration of the reference's Taichi kernels with an injected init
- * (gpu_ops.py:57-96, 178-191).  PARITY UNPINNED: Taichi cannot run in this
- * environment and the reference is unseeded, so these follow the
- * kernel source text only:
+ * (gpu_ops.py:57-96, 178-191).  PINNED: gsxo_kmeans_assign + gsxo_kmeans_update_f32seq
+ * reproduce, bit for bit, what the reference's own kernels return when executed
+ * through oracle/taichi_shim.py (tests/golden/kmeans_ref.npz):
  *   assign: dist accumulated over dims in f32, strict '<' => lowest index wins,
  *           min_dist starts at 1e20f;
  *   update: centroids zeroed, sum in point order (the reference uses f32
@@ -283,4 +283,29 @@ void gsxo_kmeans_update(const float *data, int64_t n, int d, const int32_t *labe
         }
     }
     free(acc);
+}
+
+/* gpu_ops.py:75-96 (k_means_update) executed in index order with binary32 accumulation: reset,
+ * centroids[l] += data[i] for i = 0..n-1 (one rounding per add), then centroids[c] *= 1/count.
+ * This is the order oracle/taichi_shim.py runs the reference's kernel in -- ONE of the orders its
+ * f32 atomics can take -- so it reproduces tests/golden/kmeans_ref.npz bit for bit. */
+void gsxo_kmeans_update_f32seq(const float *data, int64_t n, int d, const int32_t *labels, int k,
+                               float *cent, int32_t *counts)
+{
+    for (int c = 0; c < k; ++c) {
+        for (int t = 0; t < d; ++t) cent[(int64_t)c * d + t] = 0.0f;
+        counts[c] = 0;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        int l = labels[i];
+        if (l < 0) l += k; /* numpy's negative index: what the shimmed reference does with best_k = -1 */
+        for (int t = 0; t < d; ++t) cent[(int64_t)l * d + t] += data[i * d + t];
+        counts[l] += 1;
+    }
+    for (int c = 0; c < k; ++c) {
+        if (counts[c] > 0) {
+            float inv = 1.0f / (float)counts[c];
+            for (int t = 0; t < d; ++t) cent[(int64_t)c * d + t] *= inv;
+        }
+    }
 }

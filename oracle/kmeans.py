@@ -2,16 +2,17 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-PARITY UNPINNED for the Lloyd loop: the reference's K-Means kernels are Taichi
-(/root/reference/gsconverter/processing/gpu_ops.py:57-96, driver :178-191),
-Taichi is not installable in this environment, and every reference K-Means
-path is unseeded (np.random.choice at gpu_ops.py:182, MiniBatchKMeans at :50;
-SURVEY.md F7).  The Lloyd restatement below follows the kernel SOURCE TEXT with
-an injected initialisation; it cannot be checked against a reference run.
-``quantize_to_codebook`` and ``sog_sh_plan`` are plain numpy in the reference
-(formats/sog.py:408-419, 513-529) and ARE pinned by golden vectors generated
-from restating those lines (the reference defines them as closures inside
-``SogFormat.write`` so they cannot be imported).
+PINNED (round 2): the reference's K-Means kernels are Taichi
+(/root/reference/gsconverter/processing/gpu_ops.py:57-96, driver :178-191) and Taichi is not
+installable here, but their bodies are plain Python: oracle/taichi_shim.py executes them
+with Taichi's default types, ``np.random.seed`` pins the unseeded ``np.random.choice`` of
+gpu_ops.py:182, and oracle/make_golden_kmeans.py stores what the reference's own code
+returned (tests/golden/kmeans_ref.*).  ``lloyd(..., accumulate="f32seq")`` below reproduces
+those fixtures bit for bit (tests/test_kmeans_ref_golden.py); ``accumulate="f64"`` is the
+order-insensitive variant the GPU result is compared with inside SURVEY.md 8(c)'s tolerance.
+``quantize_to_codebook`` and ``sog_sh_plan`` restate closures of ``SogFormat.write``
+(formats/sog.py:408-419, 513-529) and are pinned by decoding the bundle the reference wrote
+and by a spy on its ``gpu_ops.kmeans`` calls (same generator).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import numpy as np
 from . import clib
 
 
-def lloyd(data: np.ndarray, init_centroids: np.ndarray, max_iter: int = 10):
+def lloyd(data: np.ndarray, init_centroids: np.ndarray, max_iter: int = 10, accumulate: str = "f64"):
     """gpu_ops.py:178-191 with ``centroids_np`` injected instead of np.random.choice.
 
     Exactly ``max_iter`` x (assign, update); no convergence test; returns the
@@ -34,10 +35,13 @@ def lloyd(data: np.ndarray, init_centroids: np.ndarray, max_iter: int = 10):
     labels = np.zeros(n, dtype=np.int32)
     counts = np.zeros(k, dtype=np.int32)
     lib = clib()
+    # "f64": sums in double, rounded once (the order-independent centre of what the reference's f32
+    # atomics can produce); "f32seq": binary32 accumulation in index order -- what the reference's kernel
+    # computes when its parallel loop runs sequentially (oracle/taichi_shim.py), bit for bit.
+    update = {"f64": lib.gsxo_kmeans_update, "f32seq": lib.gsxo_kmeans_update_f32seq}[accumulate]
     for _ in range(max_iter):
         lib.gsxo_kmeans_assign(data.ctypes.data, n, d, cent.ctypes.data, k, labels.ctypes.data)
-        lib.gsxo_kmeans_update(data.ctypes.data, n, d, labels.ctypes.data, k, cent.ctypes.data,
-                               counts.ctypes.data)
+        update(data.ctypes.data, n, d, labels.ctypes.data, k, cent.ctypes.data, counts.ctypes.data)
     return cent, labels, counts
 
 

@@ -4,9 +4,10 @@
 
 TEST INFRASTRUCTURE ONLY.  SOR vectors come from the reference's
 ``DataProcessor.remove_flyers`` CPU branch (locals captured from its frame, see
-oracle/refload.py), density vectors from its ``apply_density_filter``.  K-Means
-has no runnable reference (Taichi absent, unseeded): its vectors come from the
-oracle's own restatement and are regression pins only ("parity unpinned").
+oracle/refload.py), density vectors from its ``apply_density_filter``.  The K-Means
+entries written HERE are regression pins of the oracle's own restatement; the
+reference-generated K-Means / SOG fixtures are made by oracle/make_golden_kmeans.py,
+the full-size (10M-splat) hashes by oracle/make_golden_large.py.
 Scalars are stored as hex of their IEEE bytes so comparisons are exact.
 """
 from __future__ import annotations
@@ -137,7 +138,7 @@ def main():
     arrays["kmeans_lloyd__cent"] = cent
     arrays["kmeans_lloyd__labels"] = lab
     cases["kmeans"]["lloyd_4000x9_k64_it10"] = {
-        "pinned": "PARITY UNPINNED: oracle restatement of gpu_ops.py:57-96,178-191 with injected init",
+        "pinned": "oracle restatement (f64 sums) with injected init; reference-generated fixtures: kmeans_ref.json",
         "inertia": okm.inertia(data, cent, lab)}
 
     import numpy, scipy

@@ -97,3 +97,27 @@ def reference_density(xyz, voxel_size=1.0, threshold_percentage=0.32, sensitivit
     mask = np.zeros(len(xyz), dtype=bool)
     mask[out["orig_index"]] = True
     return {"mask": mask, "messages": msgs}
+
+
+def load_gpu_ops_with_taichi_shim():
+    """A SECOND copy of the reference's gpu_ops.py imported with oracle/taichi_shim.py standing in for
+    ``taichi`` -> ``HAS_TAICHI`` is True and ``_kmeans_taichi`` / ``k_means_assign`` / ``k_means_update``
+    (gpu_ops.py:57-96,178-191) run as plain Python on numpy arrays.  The regular import (``load()``)
+    is left untouched."""
+    import importlib.util
+    from . import taichi_shim
+    load()  # puts the stubbed package in sys.modules (parent of the module created below)
+    name = "gsconverter.processing._gpu_ops_taichi_shimmed"
+    if name in sys.modules:
+        return sys.modules[name]
+    taichi_shim.install()
+    try:
+        spec = importlib.util.spec_from_file_location(
+            name, os.path.join(REFERENCE_ROOT, "gsconverter", "processing", "gpu_ops.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        taichi_shim.uninstall()
+    assert mod.HAS_TAICHI, "the shim did not take"
+    return mod

@@ -39,6 +39,13 @@ def golden_cases():
 
 
 @pytest.fixture(scope="session")
+def large_cases():
+    """hash-only fixtures at BASELINE.json's full sizes (oracle/make_golden_large.py, run against the reference)"""
+    with open(os.path.join(GOLDEN_DIR, "large_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def golden_arrays():
     return np.load(os.path.join(GOLDEN_DIR, "arrays.npz"))
 
