@@ -46,6 +46,8 @@ LLOYD_CASES = [
     ("lloyd_empty_clusters", {"kind": "repeated", "n": 1200, "d": 3, "rep": 3, "seed": 5}, 300, 6, 15),
     ("lloyd_ties_lattice", {"kind": "lattice2d", "m": 4, "rep": 20, "seed": 6}, 6, 8, 16),
     ("lloyd_3d_k1024", {"kind": "normal", "n": 4000, "d": 3, "sigma": 1.0, "seed": 7}, 1024, 4, 17),
+    # the SOG scalar-codebook shape (sog.py:396-403) scaled down: 1-D, K=256, 20 iterations, Gaussian tails
+    ("lloyd_1d_k256_tails", {"kind": "normal", "n": 8000, "d": 1, "mu": -4.0, "sigma": 1.0, "seed": 8}, 256, 20, 18),
 ]
 
 SKLEARN_CASES = [
@@ -118,6 +120,14 @@ def main():
                                 "zero_centroids": int((np.abs(cent).sum(1) == 0).sum()),
                                 "source": "reference gpu_ops._kmeans_taichi via oracle/taichi_shim.py"}
         print(name, cases["lloyd"][name])
+
+    # the reference's two paths differ in quality: its GPU path is random-sample init + plain Lloyd, its CPU
+    # path MiniBatchKMeans with k-means++ init -- record both on the same 1-D data
+    _, gpu_ops_cpu, _ = refload.load()
+    spec = cases["lloyd"]["lloyd_1d_k256_tails"]
+    np.random.seed(28)
+    c_sk, l_sk = gpu_ops_cpu.kmeans(km_data(spec["data"]), spec["k"], max_iter=spec["max_iter"], use_gpu=False)
+    spec["inertia_of_the_reference_sklearn_path_on_the_same_data"] = okm.inertia(km_data(spec["data"]), c_sk, l_sk)
 
     # front door: k >= N shortcut (gpu_ops.py:30-31) and the Taichi branch of kmeans() itself
     small = km_data({"kind": "normal", "n": 10, "d": 3, "sigma": 1.0, "seed": 9})

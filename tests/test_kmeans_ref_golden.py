@@ -18,7 +18,7 @@ def kref():
 
 
 LLOYD = ["lloyd_1d_k32", "lloyd_9d_k48", "lloyd_24d_k32", "lloyd_45d_k64", "lloyd_empty_clusters",
-         "lloyd_ties_lattice", "lloyd_3d_k1024"]
+         "lloyd_ties_lattice", "lloyd_3d_k1024", "lloyd_1d_k256_tails"]
 
 
 @pytest.mark.parametrize("name", LLOYD)
