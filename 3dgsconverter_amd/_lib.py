@@ -45,6 +45,7 @@ SIGNATURES = {
     "gsx_ctx_destroy": (None, [_P]),
     "gsx_ctx_set_stream": (_I, [_P, _P]),
     "gsx_ctx_synchronize": (_I, [_P]),
+    "gsx_ctx_check": (_I, [_P]),
     "gsx_ctx_set_timing": (_I, [_P, _I]),
     "gsx_ctx_reset_timing": (_I, [_P]),
     "gsx_ctx_get_timing": (_I, [_P, _I, C.POINTER(C.c_uint64), C.POINTER(_D)]),
@@ -308,6 +309,10 @@ class Context:
 
     def synchronize(self):
         check(self.lib.gsx_ctx_synchronize(self.handle), "gsx_ctx_synchronize")
+
+    def check(self):
+        """synchronise + raise GsxError if a _dev call met non-finite coordinates since the last check"""
+        check(self.lib.gsx_ctx_check(self.handle), "gsx_ctx_check")
 
     def set_param(self, name: str, value: float):
         check(self.lib.gsx_ctx_set_param(self.handle, name.encode(), float(value)), "gsx_ctx_set_param")

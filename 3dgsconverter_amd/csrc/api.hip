@@ -78,7 +78,7 @@ static int timing_resolve(gsx_ctx *ctx, int slot)
 }
 
 // kernels implemented in the other translation units
-int launch_pack_points(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, float4 *);
+int launch_pack_points(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, float4 *);  // flags non-finite input in ctx->devflags
 int launch_knn_brute(gsx_ctx *, const float4 *, int64_t, int64_t, int64_t, const unsigned *, const unsigned *,
                      int64_t, int, float *);
 int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int,
@@ -128,7 +128,26 @@ int gsx_ctx_create(int device, gsx_ctx **out)
         GSX_FAIL("gsx_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                  prop.gcnArchName);
     }
+    if (c->devflags.reserve(64) != 0 || hipMemset(c->devflags.p, 0, 64) != hipSuccess) {
+        delete c;
+        GSX_FAIL("gsx_ctx_create: cannot allocate the device error word");
+    }
     *out = c;
+    return 0;
+}
+
+int gsx_ctx_check(gsx_ctx *c)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipSetDevice(c->device));
+    unsigned flags = 0;
+    GSX_HIP(hipMemcpyAsync(&flags, c->devflags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    if (flags) {
+        GSX_HIP(hipMemsetAsync(c->devflags.p, 0, 64, c->stream));
+        if (flags & 1u) GSX_FAIL("sor: coordinates are not finite (NaN/inf): results were set to NaN");
+        GSX_FAIL("device-side error flags 0x%x", flags);
+    }
     return 0;
 }
 
@@ -140,7 +159,7 @@ void gsx_ctx_destroy(gsx_ctx *c)
     for (auto &s : c->slots)
         for (auto e : s.ev) (void)hipEventDestroy(e);
     for (auto &w : c->ws) w.release_all();
-    gsx::DevBuf *bufs[] = {&c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
+    gsx::DevBuf *bufs[] = {&c->devflags, &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
     delete c;
 }
@@ -386,13 +405,8 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     GSX_HIP(hipMemcpyAsync(mask_out, dmask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (mean_out) GSX_HIP(hipMemcpyAsync(mean_out, dmd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
-    GSX_HIP(hipStreamSynchronize(c->stream));
+    GSX_CHECK(gsx_ctx_check(c));  // synchronises; non-finite coordinates (either algorithm) are an error, like cKDTree's
     const int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
-    if (used == GSX_KNN_GRID) {
-        GridParams hgp;
-        GSX_HIP(hipMemcpy(&hgp, c->ws[0].gridparams.p, sizeof(hgp), hipMemcpyDeviceToHost));
-        if (hgp.bad_input) GSX_FAIL("gsx_sor_filter: coordinates are not finite (NaN/inf)");
-    }
     if (info) {
         // re-query diagnostics without recomputing: only the grid path has device-side counters
         memset(info, 0, sizeof(*info));

@@ -112,6 +112,7 @@ struct gsx_ctx {
 
     // SOR workspace: one KnnWs per refinement level of the KNN grid (level 0 = the whole cloud)
     gsx::KnnWs ws[gsx::KNN_MAX_LEVELS];
+    gsx::DevBuf devflags;    // u32[16]: device-side error word (bit 0: non-finite coordinates), read by gsx_ctx_check
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging
     gsx::DevBuf scratch2;

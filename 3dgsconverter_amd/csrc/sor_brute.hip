@@ -21,25 +21,28 @@ constexpr int BRUTE_THREADS = 256;
 
 __global__ void pack_points_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                    const float *__restrict__ z, int64_t stride, int64_t n,
-                                   float4 *__restrict__ out)
+                                   float4 *__restrict__ out, unsigned *__restrict__ devflags)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
     for (; i < n; i += step) {
         float4 p;
         p.x = x[i * stride];
         p.y = y[i * stride];
         p.z = z[i * stride];
         p.w = __uint_as_float((unsigned)i);
+        bad |= !(fabsf(p.x) < __builtin_inff() && fabsf(p.y) < __builtin_inff() && fabsf(p.z) < __builtin_inff());
         out[i] = p;
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(devflags, 1u);  // NaN/inf: knn_brute writes NaN, gsx_ctx_check reports
 }
 
 template <int KCAP, int Q>
 __global__ __launch_bounds__(BRUTE_THREADS) void knn_brute_kernel(
     const float4 *__restrict__ pts, int n_ref, int q_begin, int q_count,
     const unsigned *__restrict__ qlist, const unsigned *__restrict__ qlist_count, int k,
-    float *__restrict__ mean_out)
+    float *__restrict__ mean_out, const unsigned *__restrict__ devflags)
 {
     // SoA tile: one ds_read_b128 returns the same coordinate of 4 consecutive candidates
     // (3 LDS cycles per candidate per wave instead of 8 for a 12-byte AoS read).
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(BRUTE_THREADS) void knn_brute_kernel(
 
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        if (qorig[q] >= 0) mean_out[qorig[q] - q_begin] = mean_from_list<KCAP>(lst[q], k);
+        // non-finite input (flagged by pack_points): every distance involving it is meaningless -> NaN, loudly
+        if (qorig[q] >= 0) mean_out[qorig[q] - q_begin] = (*devflags & 1u) ? __builtin_nanf("") : mean_from_list<KCAP>(lst[q], k);
     }
 }
 
@@ -154,7 +158,7 @@ static int launch_brute_t(gsx_ctx *ctx, const float4 *pts, int64_t n_ref, int64_
     if (nq_max <= 0) return 0;
     int blocks = div_up(nq_max, BRUTE_THREADS * Q);
     hipLaunchKernelGGL((knn_brute_kernel<KCAP, Q>), dim3(blocks), dim3(BRUTE_THREADS), 0, ctx->stream, pts,
-                       (int)n_ref, (int)q_begin, (int)q_count, qlist, qlist_count, k, mean_out);
+                       (int)n_ref, (int)q_begin, (int)q_count, qlist, qlist_count, k, mean_out, ctx->devflags.as<unsigned>());
     GSX_HIP(hipGetLastError());
     return 0;
 }
@@ -178,7 +182,8 @@ int launch_pack_points(gsx_ctx *ctx, const float *x, const float *y, const float
 {
     if (n <= 0) return 0;
     int blocks = (int)std::min<int64_t>(div_up(n, 256), 8192);
-    hipLaunchKernelGGL(pack_points_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, y, z, stride, n, out);
+    hipLaunchKernelGGL(pack_points_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, y, z, stride, n, out,
+                       ctx->devflags.as<unsigned>());
     GSX_HIP(hipGetLastError());
     return 0;
 }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
 __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
                                                          double pts_per_cell, int cell_cap, int debug_skip,
                                                          int share, int nshares, int defer_words, float parent_h,
-                                                         GridParams *__restrict__ gp)
+                                                         GridParams *__restrict__ gp, unsigned *__restrict__ devflags)
 {
     const int lane = threadIdx.x;
     // all 7 x ceil(nparts/64) loads are independent: issue them together (reducing one value at a time
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     gp->part_lo = (int)(((long long)gp->nbricks * share) / nshares);
     gp->part_hi = (int)(((long long)gp->nbricks * (share + 1)) / nshares);
     gp->bad_input = bad ? 1u : 0u;
+    if (bad) atomicOr(devflags, 1u);  // reported by gsx_ctx_check; knn_ring fills the output with NaN
     gp->debug_skip = debug_skip;
     // r_safe: |p-q| <= H*h'*(1-1e-3) implies the cell coordinates differ by <= H per axis: the
     // f32 cell index floor(fl(fl(x-o)*inv_h)) is monotone and off by < dim*2^-22 <= 2.5e-4 cells.
@@ -1246,7 +1247,7 @@ template <int KCAP>
 __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, int k, int q_begin,
-    float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ heavylist)
+    float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ heavylist, int out_count)
 {
     __shared__ double s_out[BRICK_THREADS / 64][KCAP];
     __shared__ int s_rs[BRICK_THREADS / 64][RING_ROWS];       // first point of each row
@@ -1256,6 +1257,11 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     double *out = s_out[wv];
     int *rs = s_rs[wv], *ro = s_ro[wv];
     const GridParams g = *gp;
+    if (g.bad_input) {  // non-finite coordinates: no kernel searched anything -- the whole output becomes NaN
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < out_count; i += gridDim.x * blockDim.x)
+            mean_out[i] = __builtin_nanf("");
+        return;
+    }
     const int nfail = (int)g.fail_count;
     const int kk = k + 1;
 
@@ -1741,6 +1747,7 @@ struct BrickLaunch {
     uint2 *extra;
     unsigned *deferred;
     unsigned *heavylist;
+    int64_t out_count;  // entries of mean_out (poisoned with NaN when the input is not finite)
 };
 
 template <int KCAP, bool MF, bool NET>
@@ -1778,7 +1785,7 @@ static int launch_ring(gsx_ctx *ctx, const BrickLaunch &a)
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
     hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * occ_ring), dim3(BRICK_THREADS), 0, ctx->stream, a.gp, a.refs,
-                       a.rstart, a.qpts, a.faillist, a.k, (int)a.q_begin, a.mean_out, a.kth_out, a.heavylist);
+                       a.rstart, a.qpts, a.faillist, a.k, (int)a.q_begin, a.mean_out, a.kth_out, a.heavylist, (int)a.out_count);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
     return 0;
@@ -1937,7 +1944,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                        w.bboxpart.as<float>());
     hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, w.bboxpart.as<float>(), bbox_blocks,
                        (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0,
-                       parent_h, gp);
+                       parent_h, gp, ctx->devflags.as<unsigned>());
     GSX_HIP(hipGetLastError());
     if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr));
@@ -1952,7 +1959,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
     BrickLaunch a{gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, kth_out, w.faillist.as<unsigned>(),
-                  w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>()};
+                  w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>(), q_count};
     GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0, ctx->phase2_net != 0));
 
     const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;
@@ -2125,7 +2132,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         GridParams h2;
         GSX_HIP(hipMemcpyAsync(&h2, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
-        if (h2.bad_input) GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
+        if (h2.bad_input) return gsx_ctx_check(ctx);  // reports (and clears) the device flag
         info->algo = GSX_KNN_GRID;
         info->grid_dim[0] = h2.nx; info->grid_dim[1] = h2.ny; info->grid_dim[2] = h2.nz;
         info->cell_size = h2.h;
@@ -2136,7 +2143,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         info->n_deferred_bricks = h2.deferred_count;
         info->n_refined = (int64_t)w.refined_total;
     } else if (have_hgp && hgp.bad_input && level == 0) {
-        GSX_FAIL("sor: coordinates are not finite (NaN/inf): no KNN grid can be built");
+        return gsx_ctx_check(ctx);
     }
     return 0;
 }

@@ -53,6 +53,11 @@ class HipCompute:
         self.ctx = _lib.Context(device_index)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    def check(self):
+        """synchronise and raise GsxError if the asynchronous KNN calls met non-finite coordinates (their outputs were
+        set to NaN, so the statistics are NaN and the mask all-false)"""
+        self.ctx.check()
+
     def knn(self, xyz_all, q_begin: int, q_count: int, k: int, algo: int = 0):
         t = self.torch
         assert xyz_all.is_contiguous() and xyz_all.dtype == t.float32 and xyz_all.shape[1] == 3

@@ -77,6 +77,11 @@ void gsx_ctx_destroy(gsx_ctx *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = legacy default stream */
 int  gsx_ctx_set_stream(gsx_ctx *ctx, void *hip_stream);
 int  gsx_ctx_synchronize(gsx_ctx *ctx);
+/* synchronises, then reports (and clears) errors the asynchronous _dev calls detected ON THE DEVICE since the
+ * last check: non-finite coordinates given to gsx_sor_knn_dev / gsx_sor_knn_share_dev (their mean_out was
+ * filled with NaN, so statistics and masks derived from it are NaN / all-false, never garbage).  The host
+ * entry points call it themselves -- the reference's cKDTree raises on such input (data_processor.py:160). */
+int  gsx_ctx_check(gsx_ctx *ctx);
 int  gsx_ctx_set_timing(gsx_ctx *ctx, int enable);
 int  gsx_ctx_reset_timing(gsx_ctx *ctx);
 /* synchronises, then returns the number of recorded launches and their summed duration */
