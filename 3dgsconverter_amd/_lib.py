@@ -60,6 +60,20 @@ SIGNATURES = {
     "gsx_sor_knn_share_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
     "gsx_sor_mask_dev": (_I, [_P, _P, _I64, _P, _P]),
+    "gsx_comm_unique_id": (_I, [_P]),
+    "gsx_comm_init": (_I, [_P, _I, _I, _P]),
+    "gsx_comm_destroy": (_I, [_P]),
+    "gsx_comm_all_reduce": (_I, [_P, _P, _I64, _I]),
+    "gsx_comm_all_gather": (_I, [_P, _P, _P, _I64]),
+    "gsx_comm_all_to_all_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _I]),
+    "gsx_slab_bbox_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "gsx_slab_hist_dev": (_I, [_P, _P, _I64, _I64, C.c_float, C.c_float, _P]),
+    "gsx_slab_partition_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, C.c_float, C.c_float, _P, C.c_float, _I, _P, _P, _P, _P, _P]),
+    "gsx_sor_knn_slab_dev": (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
+    "gsx_slab_certify_dev": (_I, [_P, _P, _I64, _I64, _P, C.c_float, C.c_float, _P]),
+    "gsx_slab_unpermute_dev": (_I, [_P, _P, _P, _I64, _P]),
+    "gsx_sor_piece_sums_dev": (_I, [_P, _P, _I64, _P, _P]),
+    "gsx_sor_stats_from_pieces_dev": (_I, [_P, _P, _I64, _I64, _I, _D, _P]),
     "gsx_sor_filter": (_I, [_P, _P, _P, _I64, _I64, _I, _D, _I, _P, _P, _P, C.POINTER(SorInfo)]),
     "gsx_density_voxels": (_I, [_P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask": (_I, [_P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),

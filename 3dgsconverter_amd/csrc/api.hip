@@ -151,10 +151,13 @@ int gsx_ctx_check(gsx_ctx *c)
     return 0;
 }
 
+int gsx_comm_destroy(gsx_ctx *c);
+
 void gsx_ctx_destroy(gsx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)gsx_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->slots)
         for (auto e : s.ev) (void)hipEventDestroy(e);

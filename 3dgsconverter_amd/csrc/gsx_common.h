@@ -100,6 +100,7 @@ struct gsx_ctx {
     unsigned timing_mask = 0xffffffffu;  // slots that record events when timing is on (an event pair costs ~8 us of stream time)
     gsx::TimingSlot slots[GSX_T_SLOTS];
     int num_cu = 256;
+    void *comm = nullptr;  // gsx_comm (RCCL communicator, dist_slab.hip) or null
 
     // tunables
     double grid_points_per_cell = 0.0;  // 0 = auto: 0.47 * (k + 1), see launch_knn_grid

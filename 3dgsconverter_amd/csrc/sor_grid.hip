@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void bucket_scan_kernel(const GridParams *__re
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, int64_t stride, int first, int n,
                                                              const GridParams *__restrict__ gp,
-                                                             unsigned *__restrict__ bk_cursor, float4 *__restrict__ out)
+                                                             unsigned *__restrict__ bk_cursor, float4 *__restrict__ out,
+                                                             int ref_only_from)
 {
     __shared__ unsigned hist[MAX_BUCKETS];   // per-bucket count of this tile, then the running rank
     __shared__ unsigned base[MAX_BUCKETS];   // start of this tile's run inside the bucket's region
@@ -524,7 +525,10 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const float *__rest
                 if (i < hi) {
                     const int b = bucket_of(g, cell_coord(py[u], g.oy, g.inv_h, g.ny), cell_coord(pz[u], g.oz, g.inv_h, g.nz));
                     const unsigned r = atomicAdd(&hist[b], 1u);
-                    out[base[b] + r] = make_float4(px[u], py[u], pz[u], __uint_as_float((unsigned)(first + i)));
+                    // points from ref_only_from on are REFERENCE-ONLY (the halo of a multi-GPU slab): bit 31 of
+                    // the index word keeps their lanes dead in knn_brick
+                    out[base[b] + r] = make_float4(px[u], py[u], pz[u],
+                                                   __uint_as_float((unsigned)(first + i) | (i >= ref_only_from ? 0x80000000u : 0u)));
                 }
             }
         }
@@ -852,7 +856,9 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
             }
             const float4 qp = qpts[live ? qidx : 0];
             const float qx = qp.x, qy = qp.y, qz = qp.z;
-            float tau = live ? tau1 : -1.0f;
+            const bool is_query = live && !(__float_as_uint(qp.w) >> 31);  // reference-only points (slab halo) are never queries
+            if (!__any(is_query)) continue;  // a batch of halo points only
+            float tau = is_query ? tau1 : -1.0f;
             double racc_sq = r1sq;  // this lane's acceptance radius^2 (== the exact value its filter bound comes from)
             // Queries next to the cloud's bounding box see only part of their neighbourhood ball, so
             // their (k+1)-th neighbour is farther than one cell and they would all go to knn_ring.  But
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                     }
                     float rq = r1 * cbrtf(1.0f / fmaxf(frac, 0.125f));
                     rq = fminf(rq, rsafe);
-                    if (rq > r1 && live) {
+                    if (rq > r1 && is_query) {
                         racc_sq = (double)rq * (double)rq;
                         tau = bound_from(racc_sq);
                     }
@@ -902,8 +908,8 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                                    cell_coord(qz, g_oz, g_inv_h, nz)};
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    lo[a] = live ? c3[a] : 0x7fffffff;
-                    hi[a] = live ? c3[a] : -1;
+                    lo[a] = is_query ? c3[a] : 0x7fffffff;
+                    hi[a] = is_query ? c3[a] : -1;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) {
                         lo[a] = min(lo[a], __shfl_xor(lo[a], off));
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
             drain();
 
             // ---- exact iff the (k+1)-th distance lies inside the searched cells
-            if (live) {
+            if (is_query) {
                 const double kth_d2 = lst.kth(kq);
                 if (dbg & 8) {
                     if (kth_d2 == 12345.0) mean_out[0] = 1.0f;  // keeps the list live, writes nothing
@@ -1859,11 +1865,17 @@ static int dispatch_ring(gsx_ctx *ctx, const BrickLaunch &a)
     return launch_ring<65>(ctx, a);
 }
 
+// Multi-GPU slab: points [0, n_own) are queries, [n_own, n_own + n_halo) reference-only; kth_out (nullable) receives
+// every query's (k+1)-th squared distance so that the caller can certify it against the slab's open faces.
+int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
+                    int64_t n_halo, int k, float *mean_out, double *kth_out);
+
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
 // Sort (x,y,z)[first, first+n) by cell of the grid in gp: `sorted` and `start` (cell_start) are outputs.
 static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
-                      int64_t n, GridParams *gp, unsigned *start, float4 *sorted, int64_t cell_cap = 0, unsigned *cursor = nullptr)
+                      int64_t n, GridParams *gp, unsigned *start, float4 *sorted, int64_t cell_cap = 0, unsigned *cursor = nullptr,
+                      int64_t ref_only_from = INT32_MAX)
 {
     const bool big_path = cursor != nullptr;  // adaptive mode: oversized buckets are sorted by all workgroups
     unsigned *bk_cnt = w.bkcnt.as<unsigned>();
@@ -1875,7 +1887,7 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
                        bk_cnt);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, gp, bk_cnt, bk_start, bk_cursor);
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n,
-                       gp, bk_cursor, tmp);
+                       gp, bk_cursor, tmp, (int)std::min<int64_t>(ref_only_from, INT32_MAX));
     if (big_path) GSX_HIP(hipMemsetAsync(start, 0, sizeof(unsigned) * (size_t)(cell_cap + 1), ctx->stream));  // counts of big buckets
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(MAX_BUCKETS), dim3(256), 0, ctx->stream, gp, bk_start, tmp, sorted, start,
                        big_path ? BIG_BUCKET : 0xffffffffu);
@@ -1895,15 +1907,18 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
 
 static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *y, const float *z, int64_t stride,
                           int64_t n_ref, int64_t q_begin, int64_t q_count, int k, float *mean_out, double *kth_out,
-                          gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h)
+                          gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h,
+                          int64_t ref_only_from = INT32_MAX)
 {
     KnnWs &w = ctx->ws[level];
     w.refined_total = 0;
     const int kk = k + 1;
     if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
     const int64_t cap = grid_cell_cap(n_ref);
-    const bool all = (q_begin == 0 && q_count == n_ref);
-    adaptive = adaptive && all && nshares == 1 && level + 1 < KNN_MAX_LEVELS;
+    // slab mode (multi-GPU): every point is binned once, the halo [ref_only_from, n_ref) is flagged reference-only
+    const bool slab = ref_only_from < n_ref;
+    const bool all = (q_begin == 0 && q_count == n_ref) || slab;
+    adaptive = adaptive && all && !slab && nshares == 1 && level + 1 < KNN_MAX_LEVELS;
     const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
     // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts
@@ -1926,7 +1941,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     GSX_CHECK(w.gridparams.reserve(sizeof(GridParams)));
     GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
-    GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(q_count / 64 + 64)));
+    GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(std::max(q_count, slab ? n_ref : q_count) / 64 + 64)));
     if (adaptive) {
         GSX_CHECK(w.deferred.reserve(sizeof(unsigned) * (size_t)(cap + 64)));  // nbricks <= ncells <= cap
         GSX_CHECK(w.heavylist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
@@ -1947,7 +1962,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                        parent_h, gp, ctx->devflags.as<unsigned>());
     GSX_HIP(hipGetLastError());
     if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
-    GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr));
+    GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr,
+                         slab ? ref_only_from : INT32_MAX));
     const float4 *qpts = refs;
     const unsigned *qstart = rstart;
     if (!all) {
@@ -2153,6 +2169,13 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
 {
     return knn_grid_level(ctx, 0, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, share, nshares,
                           ctx->adaptive != 0, 0.0f);
+}
+
+int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
+                    int64_t n_halo, int k, float *mean_out, double *kth_out)
+{
+    return knn_grid_level(ctx, 0, x, y, z, stride, n_own + n_halo, 0, n_own, k, mean_out, kth_out, nullptr, 0, 1, false, 0.0f,
+                          n_own);
 }
 
 }  // namespace gsx

@@ -186,11 +186,10 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
 // mode 0: stats[0] = mean.  mode 1: stats[1] = std, stats[2] = threshold.
 // One wave: numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial; the
 // wave loads 64 piece sums per step (coalesced) and folds them in order through v_readlane.
-__global__ __launch_bounds__(64) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n,
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n, int64_t nchunks,
                                                             int mode, float factor, float *__restrict__ stats)
 {
     const int lane = threadIdx.x;
-    const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
     float acc = 0.0f;
     for (int64_t base = 0; base < nchunks; base += 64) {
         const int m = (int)((nchunks - base) < 64 ? (nchunks - base) : 64);
@@ -240,9 +239,31 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
     const int blocks = (int)nchunks;
     const float tf = (float)factor;  // python float is a weak scalar: rounded to f32 first
     hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, 0, tf, stats_dev);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, nchunks, 0, tf, stats_dev);
     hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, 1, tf, stats_dev);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, nchunks, 1, tf, stats_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+// Multi-GPU (dist_slab.hip): numpy's reduction is "pairwise inside an 8192-element piece, pieces added sequentially",
+// so the piece sums can be computed wherever the elements live and combined anywhere, bit-exactly.
+int launch_sor_piece_sums(gsx_ctx *ctx, const float *a, int64_t n, const float *mean_dev, float *piece_out)
+{
+    const int blocks = (int)((n + NP_BUF - 1) / NP_BUF);
+    if (mean_dev)
+        hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out);
+    else
+        hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_sor_stats_from_pieces(gsx_ctx *ctx, const float *pieces, int64_t npieces, int64_t n_total, int mode, double factor,
+                                 float *stats_dev)
+{
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, pieces, n_total, npieces, mode, (float)factor,
+                       stats_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,379 @@
+"""Multi-GPU SOR by spatial slabs: one process per GPU, RCCL over xGMI called from the C library.
+
+The reference is single-process; its SOR treats queries as independent units over one reference
+set (data_processor.py:160-173) and thresholds on numpy's f32 mean/std of the whole mean-distance
+array (:176-180).  Rank r holds an INDEX shard of the cloud (as a loader hands it out) and gets the
+survivor mask of that shard back -- bit-identical to the single-GPU / reference result.
+
+One step (``slab_sor``); the device pieces are C-ABI entry points (include/gsx_hip.h,
+csrc/dist_slab.hip), this module only moves sizes and offsets around:
+
+  1. global bounding box: ``gsx_slab_bbox_dev`` + ONE float32 max all-reduce of 7 words;
+  2. equal-count slabs along the longest axis: 4096-bin histogram + int64 sum all-reduce (32 KB);
+  3. ``gsx_slab_partition_dev``: every point is sent to the rank owning its slab and, as a
+     reference-only copy, to every rank whose slab lies within W of it (W = ``halo_cells`` x the KNN
+     cell edge of the GLOBAL density).  Grouped ncclSend/ncclRecv, 12 B per point -- no rank ever
+     holds or bins the whole cloud (an all-gather of xyz costs 12 (G-1) N_local B per rank and G-fold
+     redundant binning: measured dead end of round 1);
+  4. ``gsx_sor_knn_slab_dev``: the single-GPU exact-KNN pipeline on (own + halo) rows, halo lanes dead;
+  5. certificate ``gsx_slab_certify_dev``: a result is globally exact iff the query's k-th neighbour is
+     nearer than the edge of what this rank received.  Sum all-reduce of the number of uncertified
+     queries; if it is not zero (far floaters, slabs thinner than the neighbour distance) the step
+     raises ``SlabUncertain`` and ``dist.sharded_sor`` falls back to the replicated exchange, which is
+     exact for any cloud -- results are identical either way;
+  6. mean distances travel back to the index owners (4 B per point) and are un-permuted;
+  7. statistics: numpy's float32 reduction is "pairwise inside 8192-element pieces, pieces added
+     sequentially", so each rank sums the pieces it holds (after handing the < 8192 leading
+     elements that belong to its left neighbour's last piece over) and the piece sums (KBs) are
+     all-gathered: bit-identical mean / std / threshold without gathering the array;
+  8. mask of the local index range.
+
+``Comm`` / backend are injectable: ``RcclComm`` + ``HipSlabBackend`` is the product; tests/ run the
+same choreography on CPU with gloo and a numpy backend built on the oracle (never the product).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+KIND_F32_MAX, KIND_F32_SUM, KIND_I64_SUM = 0, 1, 2
+NP_PIECE = 8192   # numpy's reduction buffer (elements): see csrc/sor_stats.hip
+BINS = 4096
+
+PARALLELISM = ("index-sharded input; spatial slabs: all-to-all of xyz rows to the slab owners (+ reference-only halo), "
+               "exact KNN per slab, all-to-all of the mean distances back, all-gather of numpy-exact 8192-piece "
+               "sums (RCCL from libgsx_hip.so, no collective inside kernels)")
+
+
+class SlabUncertain(RuntimeError):
+    """some query's k-th neighbour may lie outside what its slab rank received (not an error of the data:
+    the caller re-runs the step with the replicated exchange)"""
+
+
+# ------------------------------------------------------------------------------------------ communicators
+class RcclComm:
+    """RCCL through the C ABI (gsx_comm_*), on the backend context's stream.  Buffers: anything with ``.ptr``."""
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+        from . import _lib
+        self._lib, self.ctx, self.rank, self.world = _lib, ctx, int(rank), int(world)
+        buf = C.create_string_buffer(unique_id, 128)
+        _lib.check(ctx.lib.gsx_comm_init(ctx.handle, self.rank, self.world, buf), "gsx_comm_init")
+        import atexit
+        atexit.register(self.close)   # before the interpreter tears the HIP / RCCL libraries down
+
+    def close(self):
+        """ncclCommDestroy (idempotent)"""
+        if self.ctx is not None and getattr(self.ctx, "handle", None):
+            self.ctx.lib.gsx_comm_destroy(self.ctx.handle)
+        self.ctx = None
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().gsx_comm_unique_id(buf), "gsx_comm_unique_id")
+        return buf.raw
+
+    def all_reduce(self, buf, count: int, kind: int):
+        self._lib.check(self.ctx.lib.gsx_comm_all_reduce(self.ctx.handle, buf.ptr, int(count), int(kind)), "gsx_comm_all_reduce")
+
+    def all_gather(self, send, recv, nbytes: int):
+        self._lib.check(self.ctx.lib.gsx_comm_all_gather(self.ctx.handle, send.ptr, recv.ptr, int(nbytes)), "gsx_comm_all_gather")
+
+    def all_to_all_v(self, send, send_off, send_cnt, recv, recv_off, recv_cnt, elem_bytes: int):
+        arr = lambda v: (C.c_int64 * self.world)(*[int(x) for x in v])
+        self._lib.check(self.ctx.lib.gsx_comm_all_to_all_v(self.ctx.handle, send.ptr, arr(send_off), arr(send_cnt), recv.ptr,
+                                                          arr(recv_off), arr(recv_cnt), int(elem_bytes)), "gsx_comm_all_to_all_v")
+
+
+class TorchHostComm:
+    """torch.distributed (gloo) on host memory: CPU tests of the choreography, and 2-process runs on a one-GPU box
+    (device buffers are staged through the host).  Never used by bench.py."""
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.be = dist, group, backend
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce(self, buf, count, kind):
+        import torch
+        dt = np.int64 if kind == KIND_I64_SUM else np.float32
+        a = self.be.to_host(buf, dt, count)
+        t = torch.from_numpy(a)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if kind == KIND_F32_MAX else self.dist.ReduceOp.SUM, group=self.group)
+        self.be.from_host(buf, t.numpy())
+
+    def all_gather(self, send, recv, nbytes):
+        import torch
+        a = torch.from_numpy(self.be.to_host(send, np.uint8, nbytes))
+        out = torch.empty(self.world * nbytes, dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(out, a, group=self.group)
+        self.be.from_host(recv, out.numpy())
+
+    def all_to_all_v(self, send, send_off, send_cnt, recv, recv_off, recv_cnt, elem_bytes):
+        import torch
+        total_s = max(int(o + c) for o, c in zip(send_off, send_cnt))
+        total_r = max(int(o + c) for o, c in zip(recv_off, recv_cnt))
+        s = self.be.to_host(send, np.uint8, total_s * elem_bytes)
+        r = self.be.to_host(recv, np.uint8, total_r * elem_bytes) if total_r else np.zeros(0, np.uint8)
+        reqs, bufs = [], []
+        for p in range(self.world):
+            so, sc, ro, rc = int(send_off[p]), int(send_cnt[p]), int(recv_off[p]), int(recv_cnt[p])
+            if p == self.rank:
+                r[ro * elem_bytes:(ro + rc) * elem_bytes] = s[so * elem_bytes:(so + sc) * elem_bytes]
+                continue
+            if sc:
+                reqs.append(self.dist.isend(torch.from_numpy(s[so * elem_bytes:(so + sc) * elem_bytes].copy()), p, group=self.group))
+            if rc:
+                t = torch.empty(rc * elem_bytes, dtype=torch.uint8)
+                bufs.append((ro, rc, t))
+                reqs.append(self.dist.irecv(t, p, group=self.group))
+        for q in reqs:
+            q.wait()
+        for ro, rc, t in bufs:
+            r[ro * elem_bytes:(ro + rc) * elem_bytes] = t.numpy()
+        if total_r:
+            self.be.from_host(recv, r)
+
+
+# ------------------------------------------------------------------------------------------ device backend
+class _View:
+    """a device pointer inside a DeviceArray"""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+
+class HipSlabBackend:
+    """The C ABI on one GPU (libgsx_hip.so); buffers are grow-only DeviceArrays owned here."""
+
+    def __init__(self, device: int = 0, stream: int | None = None, ctx=None):
+        from . import _lib
+        self._lib = _lib
+        self.ctx = ctx if ctx is not None else _lib.Context(device, stream)
+        self.lib = self.ctx.lib
+        self._bufs = {}
+
+    def buf(self, name: str, nbytes: int):
+        cur = self._bufs.get(name)
+        if cur is None or cur.nbytes < nbytes:
+            if cur is not None:
+                cur.free()
+            cur = self.ctx.alloc(int(nbytes * 1.125) + 256)
+            self._bufs[name] = cur
+        return cur
+
+    @staticmethod
+    def at(buf, byte_off: int):
+        return _View(buf.ptr + int(byte_off))
+
+    def to_host(self, buf, dtype, count):
+        out = np.empty(int(count), dtype=dtype)
+        if out.nbytes:
+            self._lib.check(self.lib.gsx_dev_download(self.ctx.handle, out.ctypes.data, buf.ptr, out.nbytes), "gsx_dev_download")
+        return out
+
+    def from_host(self, buf, arr):
+        a = np.ascontiguousarray(arr)
+        if a.nbytes:
+            self._lib.check(self.lib.gsx_dev_upload(self.ctx.handle, buf.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload")
+
+    def zero(self, buf, nbytes):
+        self.from_host(buf, np.zeros(int(nbytes), np.uint8))
+
+    def _chk(self, rc, what):
+        self._lib.check(rc, what)
+
+    # rows: device pointer to (n,3) float32
+    def bbox(self, rows, n, out7):
+        p = rows.ptr
+        self._chk(self.lib.gsx_slab_bbox_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), out7.ptr), "gsx_slab_bbox_dev")
+
+    def hist(self, rows, n, axis, lo, hi, hist):
+        self._chk(self.lib.gsx_slab_hist_dev(self.ctx.handle, rows.ptr + 4 * axis, 3, int(n), float(lo), float(hi), hist.ptr),
+                  "gsx_slab_hist_dev")
+
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_w, mode, counts, cursor, send, send_src):
+        p = rows.ptr
+        cuts = (C.c_int32 * (world + 1))(*[int(c) for c in cut])
+        planes = (C.c_float * (2 * world))()
+        self._chk(self.lib.gsx_slab_partition_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), int(world), int(axis), float(lo),
+                                                  float(hi), cuts, float(halo_w), int(mode),
+                                                  counts.ptr if counts is not None else None,
+                                                  cursor.ptr if cursor is not None else None,
+                                                  send.ptr if send is not None else None,
+                                                  send_src.ptr if send_src is not None else None, planes), "gsx_slab_partition_dev")
+        return np.array(planes[:], dtype=np.float32).reshape(world, 2)
+
+    def knn_slab(self, rows, n_own, n_halo, k, mean_out, kth_out):
+        self._chk(self.lib.gsx_sor_knn_slab_dev(self.ctx.handle, rows.ptr, int(n_own), int(n_halo), int(k), mean_out.ptr, kth_out.ptr),
+                  "gsx_sor_knn_slab_dev")
+
+    def certify(self, rows, axis, n_own, kth, open_lo, open_hi, n_uncertain):
+        self._chk(self.lib.gsx_slab_certify_dev(self.ctx.handle, rows.ptr + 4 * axis, 3, int(n_own), kth.ptr, float(open_lo),
+                                                float(open_hi), n_uncertain.ptr), "gsx_slab_certify_dev")
+
+    def unpermute(self, recv, send_src, n, out):
+        self._chk(self.lib.gsx_slab_unpermute_dev(self.ctx.handle, recv.ptr, send_src.ptr, int(n), out.ptr), "gsx_slab_unpermute_dev")
+
+    def piece_sums(self, a, n, mean, out):
+        self._chk(self.lib.gsx_sor_piece_sums_dev(self.ctx.handle, a.ptr, int(n), mean.ptr if mean is not None else None, out.ptr),
+                  "gsx_sor_piece_sums_dev")
+
+    def stats_from_pieces(self, pieces, npieces, n_total, mode, factor, stats):
+        self._chk(self.lib.gsx_sor_stats_from_pieces_dev(self.ctx.handle, pieces.ptr, int(npieces), int(n_total), int(mode),
+                                                         float(factor), stats.ptr), "gsx_sor_stats_from_pieces_dev")
+
+    def mask(self, md, n, stats, out):
+        self.ctx.sor_mask(md.ptr, int(n), stats.ptr + 8, out.ptr)
+
+    def check(self):
+        self.ctx.check()
+
+
+# ------------------------------------------------------------------------------------------ the step
+def pts_per_cell(k: int) -> float:
+    """the KNN grid's cell population (csrc/sor_grid.hip: knn_grid_level)"""
+    m = max(2.0, 0.47 * (k + 1))
+    for cells in (8, 4, 2, 1):
+        if 58.0 < m * cells <= 66.0:
+            m = 58.0 / cells
+    return m
+
+
+def plan_slabs(hist: np.ndarray, world: int):
+    """equal-count cuts of the global 4096-bin histogram: slab s owns bins [cut[s], cut[s+1])"""
+    cum = np.concatenate([[0], np.cumsum(hist.astype(np.int64))])
+    total = int(cum[-1])
+    cut = [0]
+    for s in range(1, world):
+        b = int(np.searchsorted(cum, (total * s) // world, side="left"))
+        cut.append(min(max(b, cut[-1]), BINS))
+    cut.append(BINS)
+    return cut, total
+
+
+def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 2.5, want_host: bool = False):
+    """rows: backend buffer holding this rank's (n_local,3) float32 index shard (same n_local on every rank).
+    -> dict(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info)."""
+    G, r = comm.world, comm.rank
+    n_local = int(n_local)
+    # ---- 1. bounding box
+    b7 = be.buf("bbox", 32)
+    be.bbox(rows, n_local, b7)
+    if G > 1:
+        comm.all_reduce(b7, 7, KIND_F32_MAX)
+    hb = be.to_host(b7, np.float32, 7)
+    if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
+        raise ValueError("sor: coordinates are not finite (NaN/inf)")
+    lo3, hi3 = -hb[:3].astype(np.float64), hb[3:6].astype(np.float64)
+    ext = hi3 - lo3
+    axis = int(np.argmax(ext))
+    lo, hi = np.float32(lo3[axis]), np.float32(hi3[axis])
+    # ---- 2. equal-count slabs
+    hist = be.buf("hist", 8 * BINS)
+    be.hist(rows, n_local, axis, lo, hi, hist)
+    if G > 1:
+        comm.all_reduce(hist, BINS, KIND_I64_SUM)
+    cut, n_total = plan_slabs(be.to_host(hist, np.int64, BINS), G)
+    if n_total != G * n_local:
+        raise ValueError("slab_sor needs equally sized index shards (%d points in total, %d x %d expected)" % (n_total, G, n_local))
+    nd = int((ext > 0).sum())
+    vol = float(np.prod(ext[ext > 0])) if nd else 0.0
+    per = vol * pts_per_cell(k) / max(n_total, 1)
+    h_est = per ** (1.0 / nd) if nd else 0.0
+    halo_w = np.float32(halo_cells * h_est)
+    # ---- 3. partition: count, exchange the counts, scatter, exchange the rows
+    cnt = be.buf("cnt", 4 * 2 * G)
+    be.zero(cnt, 4 * 2 * G)
+    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_w, 0, cnt, None, None, None)
+    allcnt_buf = be.buf("allcnt", 4 * 2 * G * G)
+    if G > 1:
+        comm.all_gather(cnt, allcnt_buf, 4 * 2 * G)
+        allcnt = be.to_host(allcnt_buf, np.uint32, 2 * G * G).reshape(G, 2 * G).astype(np.int64)
+    else:
+        allcnt = be.to_host(cnt, np.uint32, 2 * G).reshape(1, 2 * G).astype(np.int64)
+    mine = allcnt[r]
+    own_cnt, halo_cnt = mine[0::2], mine[1::2]
+    assert int(own_cnt.sum()) == n_local
+    own_off = np.concatenate([[0], np.cumsum(own_cnt)[:-1]])
+    halo_off = n_local + np.concatenate([[0], np.cumsum(halo_cnt)[:-1]])
+    n_send = n_local + int(halo_cnt.sum())
+    cursor = be.buf("cursor", 4 * 2 * G)
+    cur = np.empty(2 * G, np.uint32)
+    cur[0::2], cur[1::2] = own_off, halo_off
+    be.from_host(cursor, cur)
+    send = be.buf("send", 12 * n_send)
+    send_src = be.buf("send_src", 4 * max(n_local, 1))
+    be.partition(rows, n_local, G, axis, lo, hi, cut, halo_w, 1, None, cursor, send, send_src)
+    in_own, in_halo = allcnt[:, 2 * r], allcnt[:, 2 * r + 1]      # rows every source sends me
+    n_own, n_halo = int(in_own.sum()), int(in_halo.sum())
+    r_own_off = np.concatenate([[0], np.cumsum(in_own)[:-1]])
+    r_halo_off = n_own + np.concatenate([[0], np.cumsum(in_halo)[:-1]])
+    slab = be.buf("slab", 12 * max(n_own + n_halo, 1))
+    comm.all_to_all_v(send, own_off, own_cnt, slab, r_own_off, in_own, 12)
+    comm.all_to_all_v(send, halo_off, halo_cnt, slab, r_halo_off, in_halo, 12)
+    # ---- 4./5. exact KNN on the slab, certificate
+    md_slab = be.buf("md_slab", 4 * max(n_own, 1))
+    kth = be.buf("kth", 8 * max(n_own, 1))
+    if n_own:
+        be.knn_slab(slab, n_own, n_halo, k, md_slab, kth)
+    unc = be.buf("unc", 8)
+    be.zero(unc, 8)
+    if n_own:
+        be.certify(slab, axis, n_own, kth, planes[r, 0], planes[r, 1], unc)
+    if G > 1:
+        comm.all_reduce(unc, 1, KIND_I64_SUM)
+    n_unc = int(be.to_host(unc, np.int64, 1)[0])
+    if n_unc:
+        raise SlabUncertain("%d queries could not be certified inside their slab (halo %.4g)" % (n_unc, float(halo_w)))
+    # ---- 6. mean distances back to the index owners, original order
+    ret = be.buf("ret", 4 * max(n_local, 1))
+    comm.all_to_all_v(md_slab, r_own_off, in_own, ret, own_off, own_cnt, 4)
+    md = be.buf("md", 4 * (n_local + NP_PIECE + 4))
+    be.unpermute(ret, send_src, n_local, md)
+    # ---- 7. numpy-exact statistics from 8192-element piece sums
+    stats = be.buf("stats", 16)
+    start = r * n_local
+    head = (-start) % NP_PIECE                          # my leading elements complete my left neighbour's last piece
+    nxt_head = (-(start + n_local)) % NP_PIECE if r + 1 < G else 0
+    if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):
+        raise ValueError("slab_sor: index shards must hold a multiple of 4 and at least 8192 points (got %d)" % n_local)
+    if G > 1:
+        s_off, s_cnt, r_off, r_cnt = [0] * G, [0] * G, [0] * G, [0] * G
+        if r > 0:
+            s_cnt[r - 1] = head
+        if r + 1 < G:
+            r_off[r + 1], r_cnt[r + 1] = n_local, nxt_head
+        comm.all_to_all_v(md, s_off, s_cnt, md, r_off, r_cnt, 4)
+    n_mine = n_local - head + nxt_head
+    my_pieces = -(-n_mine // NP_PIECE) if n_mine > 0 else 0
+    max_pieces = n_local // NP_PIECE + 2
+    pieces = be.buf("pieces", 4 * max_pieces)
+    allp = be.buf("allpieces", 4 * max_pieces * G)
+    packed = be.buf("packed", 4 * max_pieces * G)
+    counts = [(-(-(n_local - ((-(q * n_local)) % NP_PIECE) + ((-((q + 1) * n_local)) % NP_PIECE if q + 1 < G else 0)) // NP_PIECE))
+              for q in range(G)]
+    for mode in (0, 1):
+        if my_pieces:
+            be.piece_sums(be.at(md, 4 * head), n_mine, stats if mode else None, pieces)
+        if G > 1:
+            comm.all_gather(pieces, allp, 4 * max_pieces)
+            ap = be.to_host(allp, np.float32, max_pieces * G).reshape(G, max_pieces)
+            flat = np.concatenate([ap[q, :counts[q]] for q in range(G)])
+            be.from_host(packed, flat)
+            be.stats_from_pieces(packed, len(flat), n_total, mode, threshold_factor, stats)
+        else:
+            be.stats_from_pieces(pieces, my_pieces, n_total, mode, threshold_factor, stats)
+    # ---- 8. mask of the local index range
+    mask = be.buf("mask", n_local + 4)
+    be.mask(md, n_local, stats, mask)
+    out = {"mask": mask, "mean_dists": md, "stats": stats, "n_total": n_total, "n_own": n_own, "n_halo": n_halo,
+           "info": {"axis": axis, "halo_w": float(halo_w), "cut": cut}}
+    if want_host:
+        out["mask_host"] = be.to_host(mask, np.uint8, n_local).view(np.bool_)
+        out["mean_dists_host"] = be.to_host(md, np.float32, n_local)
+        out["stats_host"] = be.to_host(stats, np.float32, 3)
+    return out

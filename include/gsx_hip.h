@@ -151,6 +151,58 @@ int gsx_sor_stats_dev(gsx_ctx *ctx, const float *mean_dists_dev, int64_t n, doub
 int gsx_sor_mask_dev(gsx_ctx *ctx, const float *mean_dists_dev, int64_t n, const float *threshold_dev,
                      uint8_t *mask_out_dev);
 
+/* ---- multi-GPU SOR on one node: RCCL + the slab exchange ----
+ * The reference has no distributed path: its queries are independent units over one reference set
+ * (data_processor.py:167-173, 50 000-query chunks of one cKDTree) and its threshold is numpy's f32
+ * mean/std over the whole mean-distance array (:176-178).  One process per GPU, splats sharded by index; the
+ * host (3dgsconverter_amd/dist.py: slab_sor) drives these entry points; DESIGN.md section 7 has the protocol.
+ *
+ * gsx_comm_*: RCCL collectives on the context's stream (librccl is dlopen'ed at gsx_comm_init).  The unique id
+ * is created on rank 0 (gsx_comm_unique_id) and handed to the other ranks by the launcher (128 bytes). */
+int gsx_comm_unique_id(void *out128);
+int gsx_comm_init(gsx_ctx *ctx, int rank, int world, const void *id128);
+int gsx_comm_destroy(gsx_ctx *ctx);
+/* in place on device memory; kind 0 = float32 max, 1 = float32 sum, 2 = int64 sum */
+int gsx_comm_all_reduce(gsx_ctx *ctx, void *buf_dev, int64_t count, int kind);
+int gsx_comm_all_gather(gsx_ctx *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
+/* grouped ncclSend/ncclRecv: offsets and counts (host arrays, one entry per peer) in elements of elem_bytes
+ * (1, 4, 8 or 12 = a row of three floats) */
+int gsx_comm_all_to_all_v(gsx_ctx *ctx, const void *send_dev, const int64_t *send_off, const int64_t *send_cnt,
+                          void *recv_dev, const int64_t *recv_off, const int64_t *recv_cnt, int elem_bytes);
+
+/* out7_dev = max over the points of (-x,-y,-z,x,y,z) and a non-finite flag: ONE float32 max all-reduce gives the
+ * global bounding box (the per-rank half of gpu_ops.py:203-206) */
+int gsx_slab_bbox_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                      float *out7_dev);
+/* 4096-bin histogram (int64) of one coordinate over [lo, hi]: summed over the ranks it yields equal-count slabs */
+int gsx_slab_hist_dev(gsx_ctx *ctx, const float *coord, int64_t stride, int64_t n, float lo, float hi,
+                      int64_t *hist4096_dev);
+/* Slab s owns the histogram bins [cut[s], cut[s+1]); a point is also a REFERENCE-ONLY copy for every other slab it
+ * lies within halo_w of.  mode 0: counts_dev[2*world] += rows per destination (own, halo).  mode 1: rows (3 floats)
+ * are written to send_dev at the row cursors cursor_dev[2*world] (advanced), send_src_dev[row] = local index of each
+ * own row.  planes_out (host, 2*world floats, nullable): the [lo, hi] coordinate range every slab receives. */
+int gsx_slab_partition_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                           int world, int axis, float lo, float hi, const int32_t *cut, float halo_w, int mode,
+                           uint32_t *counts_dev, uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev,
+                           float *planes_out);
+/* exact KNN mean distance of the first n_own rows against all n_own + n_halo rows (the halo rows are never
+ * queries); kth_d2_dev[i] = squared distance of query i's (k+1)-th neighbour INCLUDING itself, i.e. its k-th other */
+int gsx_sor_knn_slab_dev(gsx_ctx *ctx, const float *rows_dev, int64_t n_own, int64_t n_halo, int k,
+                         float *mean_out_dev, double *kth_d2_dev);
+/* *n_uncertain_dev = number of queries whose k-th neighbour is not provably among the rows this rank holds:
+ * kth_d2 > min(coord - open_lo, open_hi - coord)^2 (open_* = the slab's planes_out entries, +-inf at the cloud's ends) */
+int gsx_slab_certify_dev(gsx_ctx *ctx, const float *coord, int64_t stride, int64_t n_own, const double *kth_d2_dev,
+                         float open_lo, float open_hi, uint32_t *n_uncertain_dev);
+/* out_dev[send_src_dev[p]] = recv_dev[p]: mean distances come back in the order the rows were sent */
+int gsx_slab_unpermute_dev(gsx_ctx *ctx, const float *recv_dev, const uint32_t *send_src_dev, int64_t n, float *out_dev);
+/* numpy's float32 reduction (data_processor.py:176-177) is "pairwise inside 8192-element pieces, pieces added
+ * sequentially": piece sums of a piece-aligned sub-range can be computed where the data lives ... */
+int gsx_sor_piece_sums_dev(gsx_ctx *ctx, const float *a_dev, int64_t n, const float *mean_dev /* NULL: plain sum,
+                           else sum of (a - *mean)^2 */, float *piece_out_dev);
+/* ... and combined anywhere: mode 0: stats[0] = mean; mode 1: stats[1] = std, stats[2] = mean + factor * std */
+int gsx_sor_stats_from_pieces_dev(gsx_ctx *ctx, const float *pieces_dev, int64_t npieces, int64_t n_total, int mode,
+                                  double threshold_factor, float *stats_dev);
+
 /* host buffers, one GPU: the whole of filter_sor_gpu (gpu_ops.py:193-263).
  * mean_out (n floats) and stats_out (3 floats) may be NULL. */
 int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t stride, int64_t n,

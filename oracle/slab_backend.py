@@ -1,0 +1,177 @@
+"""numpy stand-in for 3dgsconverter_amd.dist_slab.HipSlabBackend: the same method names on host arrays.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  It lets tests/test_dist_cpu.py run the multi-GPU slab
+choreography (3dgsconverter_amd/dist_slab.py: slab_sor) with torch.distributed's gloo backend on CPU, world 2
+and 3; the arithmetic is the oracle's (cKDTree exactly as data_processor.py:156-173, numpy's own float32
+reductions for :176-178).  The binning formulas restate csrc/dist_slab.hip so that both sides cut identical slabs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import sor as osor
+
+BINS = 4096
+NP_PIECE = 8192
+
+
+class _Buf:
+    def __init__(self, nbytes):
+        self.a = np.zeros(int(nbytes), dtype=np.uint8)
+        self.nbytes = int(nbytes)
+
+    def view(self, dtype, count, byte_off=0):
+        return self.a[byte_off:byte_off + int(count) * np.dtype(dtype).itemsize].view(dtype)
+
+
+class _At:
+    def __init__(self, buf, off):
+        self.buf, self.off = buf, int(off)
+
+    def view(self, dtype, count, byte_off=0):
+        return self.buf.view(dtype, count, self.off + byte_off)
+
+
+class NumpySlabBackend:
+    def __init__(self):
+        self._bufs = {}
+
+    def buf(self, name, nbytes):
+        cur = self._bufs.get(name)
+        if cur is None or cur.nbytes < nbytes:
+            cur = _Buf(int(nbytes) + 64)
+            self._bufs[name] = cur
+        return cur
+
+    @staticmethod
+    def at(buf, byte_off):
+        return _At(buf, byte_off)
+
+    @staticmethod
+    def rows_buffer(xyz):
+        b = _Buf(xyz.nbytes)
+        b.view(np.float32, xyz.size)[:] = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1)
+        return b
+
+    def to_host(self, buf, dtype, count):
+        return buf.view(dtype, count).copy()
+
+    def from_host(self, buf, arr):
+        a = np.ascontiguousarray(arr)
+        buf.view(np.uint8, a.nbytes)[:] = a.view(np.uint8).reshape(-1)
+
+    def zero(self, buf, nbytes):
+        buf.view(np.uint8, nbytes)[:] = 0
+
+    # ---- the device entry points, restated
+    def bbox(self, rows, n, out7):
+        x = rows.view(np.float32, 3 * n).reshape(n, 3)
+        o = out7.view(np.float32, 7)
+        o[:6] = -np.inf
+        o[6] = 0.0
+        if n:
+            o[:3] = (-x).max(0)
+            o[3:6] = x.max(0)
+            o[6] = 0.0 if np.isfinite(x).all() else 1.0
+
+    @staticmethod
+    def _bin(c, lo, hi):
+        inv_w = np.float32(BINS) / (np.float32(hi) - np.float32(lo)) if hi > lo else np.float32(0)
+        return np.clip(((c - np.float32(lo)) * inv_w).astype(np.int32), 0, BINS - 1)
+
+    def hist(self, rows, n, axis, lo, hi, hist):
+        c = rows.view(np.float32, 3 * n).reshape(n, 3)[:, axis]
+        hist.view(np.int64, BINS)[:] = np.bincount(self._bin(c, lo, hi), minlength=BINS)
+
+    def _planes(self, world, lo, hi, cut, halo_w):
+        lo, hi, halo_w = np.float32(lo), np.float32(hi), np.float32(halo_w)
+        bw = (hi - lo) / np.float32(BINS) if hi > lo else np.float32(0)
+        pl = np.empty((world, 2), np.float32)
+        for s in range(world):
+            s_lo = lo + bw * np.float32(cut[s] - 1)
+            s_hi = lo + bw * np.float32(cut[s + 1] + 1)
+            pl[s, 0] = -np.inf if s == 0 else s_lo - halo_w
+            pl[s, 1] = np.inf if s == world - 1 else s_hi + halo_w
+        return pl
+
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_w, mode, counts, cursor, send, send_src):
+        x = rows.view(np.float32, 3 * n).reshape(n, 3)
+        c = x[:, axis]
+        owner = np.searchsorted(np.asarray(cut[1:world], dtype=np.int64), self._bin(c, lo, hi), side="right")
+        pl = self._planes(world, lo, hi, cut, halo_w)
+        if mode == 0:
+            cnt = counts.view(np.uint32, 2 * world)
+            for s in range(world):
+                cnt[2 * s] += np.uint32((owner == s).sum())
+                cnt[2 * s + 1] += np.uint32(((owner != s) & (c >= pl[s, 0]) & (c <= pl[s, 1])).sum())
+            return pl
+        cur = cursor.view(np.uint32, 2 * world)
+        n_send = int(cur.max()) + n  # upper bound of the rows this call can write
+        out = send.view(np.float32, 3 * (send.nbytes // 12)).reshape(-1, 3)
+        src = send_src.view(np.uint32, n)
+        for s in range(world):
+            idx = np.nonzero(owner == s)[0]
+            o = int(cur[2 * s])
+            out[o:o + len(idx)] = x[idx]
+            src[o:o + len(idx)] = idx
+            cur[2 * s] += len(idx)
+            hidx = np.nonzero((owner != s) & (c >= pl[s, 0]) & (c <= pl[s, 1]))[0]
+            o = int(cur[2 * s + 1])
+            out[o:o + len(hidx)] = x[hidx]
+            cur[2 * s + 1] += len(hidx)
+        del n_send
+        return pl
+
+    def knn_slab(self, rows, n_own, n_halo, k, mean_out, kth_out):
+        from scipy.spatial import cKDTree
+        pts = rows.view(np.float32, 3 * (n_own + n_halo)).reshape(-1, 3)
+        tree = cKDTree(pts)
+        d, _ = tree.query(pts[:n_own], k=k + 1)   # data_processor.py:160-173
+        d = np.asarray(d).reshape(n_own, -1)
+        mean_out.view(np.float32, n_own)[:] = np.mean(d[:, 1:], axis=1).astype(np.float32)
+        kth_out.view(np.float64, n_own)[:] = d[:, -1] ** 2 if d.shape[1] == k + 1 else np.inf
+
+    def certify(self, rows, axis, n_own, kth, open_lo, open_hi, n_uncertain):
+        c = rows.view(np.float32, 3 * n_own).reshape(-1, 3)[:, axis].astype(np.float64)
+        d = np.minimum(c - np.float64(open_lo), np.float64(open_hi) - c) * (1.0 - 1e-6)
+        # d**2 of a sqrt-ed cKDTree distance is not the exact squared distance: 1e-12 relative slack keeps this
+        # stand-in from flagging what the device (which has the exact value) certifies
+        bad = ~(kth.view(np.float64, n_own) * (1.0 - 1e-12) <= d * d)
+        n_uncertain.view(np.uint32, 1)[0] = np.uint32(bad.sum())
+
+    def unpermute(self, recv, send_src, n, out):
+        out.view(np.float32, n)[send_src.view(np.uint32, n)] = recv.view(np.float32, n)
+
+    def piece_sums(self, a, n, mean, out):
+        v = a.view(np.float32, n)
+        if mean is not None:
+            m = mean.view(np.float32, 1)[0]
+            v = (v - m) * (v - m)    # float32, as np.std's x - mean, then squared
+        npieces = -(-n // NP_PIECE)
+        o = out.view(np.float32, npieces)
+        for p in range(npieces):
+            o[p] = np.add.reduce(v[p * NP_PIECE:(p + 1) * NP_PIECE])   # <= 8192 elements: one pairwise sum
+        return npieces
+
+    def stats_from_pieces(self, pieces, npieces, n_total, mode, factor, stats):
+        acc = np.float32(0.0)
+        for v in pieces.view(np.float32, npieces):
+            acc = np.float32(acc + v)
+        q = np.float32(np.float64(acc) / np.float64(n_total))
+        st = stats.view(np.float32, 3)
+        if mode == 0:
+            st[0] = q
+        else:
+            st[1] = np.sqrt(q)
+            st[2] = st[0] + np.float32(factor) * st[1]
+
+    def mask(self, md, n, stats, out):
+        out.view(np.uint8, n)[:] = md.view(np.float32, n) < stats.view(np.float32, 3)[2]
+
+    def check(self):
+        pass
+
+
+def reference_result(xyz_all, k, threshold_factor):
+    """what the whole (un-sharded) cloud gives: oracle/sor.py (cKDTree + numpy, data_processor.py:156-180)"""
+    return osor.sor(np.ascontiguousarray(xyz_all, dtype=np.float32), k, threshold_factor)
