@@ -6,8 +6,10 @@
     python bench.py --workload kmeans        # BASELINE.json configs[4] (SOG palette K-Means), 1 GPU
 
 One SOR step = one pass of the hot path over one batch of synthetic splats whose xyz is already
-resident in HBM: (exchange, N>1) -> grid binning -> exact KNN mean distance (knn_brick + knn_ring)
--> numpy-exact mean/std/threshold -> survivor mask.  Workload at N=1: the configuration
+resident in HBM: grid binning -> exact KNN mean distance (knn_brick + knn_ring) -> numpy-exact
+mean/std/threshold -> survivor mask; with N > 1 the splats are sharded by index and the step is the slab
+exchange of 3dgsconverter_amd/dist_slab.py (RCCL all-to-all of xyz rows + halo, slab KNN, all-to-all of
+the mean distances back, all-gather of numpy's 8192-piece sums).  Workload at N=1: the configuration
 BASELINE.json's target is quoted on -- 10M uniform-random splats (L=5, seed 0: SURVEY.md 8(d)
 config 3's cloud), k=16, sigma=1.0; each extra GPU adds one more 10M-splat index shard (weak
 scaling).  The 1M-splat configs[1] cloud is timed in the same run and reported under "secondary".
@@ -59,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-splat configs[1] line")
     ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
+                    help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
+                         "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
     args = ap.parse_args()
 
     if args.workload == "kmeans":
@@ -81,12 +86,26 @@ def main():
 
     gsx = importlib.import_module("3dgsconverter_amd")
     gdist = importlib.import_module("3dgsconverter_amd.dist")
+    gslab = importlib.import_module("3dgsconverter_amd.dist_slab")
     L = gsx._lib
     compute = gdist.HipCompute(local_rank)
     ctx = compute.ctx
     for kv in args.param:
         name, val = kv.split("=")
         ctx.set_param(name, float(val))
+    # N > 1: spatial slabs, every collective of the data path is RCCL called from libgsx_hip.so on the library's
+    # stream (3dgsconverter_amd/dist_slab.py); torch.distributed only hands the 128-byte unique id out and times
+    slab_be = slab_comm = None
+    exchange = {"path": "single GPU"}
+    if (world > 1 and args.exchange != "replicated") or args.exchange == "slab":
+        uid = [gslab.RcclComm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        slab_be = gslab.HipSlabBackend(ctx=ctx)
+        slab_comm = gslab.RcclComm(ctx, rank, world, uid[0])
+        exchange["path"] = "slab"
+    elif world > 1:
+        exchange["path"] = "replicated (requested)"
 
     def barrier():
         if world > 1:
@@ -99,7 +118,24 @@ def main():
         xyz_local = torch.from_numpy(xyz_host).to(dev)
         torch.cuda.synchronize()
 
+        class SlabResult:   # the fields the report below reads, from the slab path's device buffers
+            def __init__(self, r):
+                self.r = r
+
+            @property
+            def mask_local(self):
+                return torch.from_numpy(slab_be.to_host(self.r["mask"], np.uint8, n))
+
+            @property
+            def stats(self):
+                return torch.from_numpy(slab_be.to_host(self.r["stats"], np.float32, 3))
+
         def step():
+            if exchange["path"] == "slab":
+                try:
+                    return SlabResult(gslab.slab_sor(slab_be, slab_comm, gslab._View(xyz_local.data_ptr()), n, args.k, args.sigma))
+                except gslab.SlabUncertain as e:   # raised on every rank together (the count is all-reduced)
+                    exchange["path"] = "replicated (slab certificate failed: %s)" % e
             return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
 
         for _ in range(warmup):
@@ -143,12 +179,12 @@ def main():
     main_run = run(args.n, args.extent, args.steps, args.warmup)
     res = main_run["res"]
     info = None
-    if world == 1:
+    if world == 1 and slab_comm is None:
         t = main_run["xyz_local"]
         info = ctx.sor_knn(t.data_ptr(), t.data_ptr() + 4, t.data_ptr() + 8, 3, args.n, 0, args.n, args.k,
                            res.mean_dists_local.data_ptr(), algo=args.algo, want_info=True)
     secondary = None
-    if world == 1 and not args.no_secondary and args.n != 1_000_000:
+    if world == 1 and slab_comm is None and not args.no_secondary and args.n != 1_000_000:
         r2 = run(1_000_000, 10.0, max(args.steps, 50), max(args.warmup, 5), side=False)
         secondary = {"workload": "BASELINE.json configs[1]: 1000000 uniform-random splats (L=10, seed 0), SOR k=%d sigma=%g" % (args.k, args.sigma),
                      "value": round(1_000_000 * max(args.steps, 50) / r2["dt"] / 1e6, 2), "unit": "Msplats/s",
@@ -157,6 +193,9 @@ def main():
                      "survivors": int(r2["res"].mask_local.sum().item())}
         del r2
 
+    if slab_comm is not None:
+        ctx.check()
+        slab_comm.close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -209,7 +248,8 @@ def main():
                                "exact KNN, xyz resident in HBM" % (args.n, args.extent, args.k, args.sigma),
                    "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma,
                    "algo": "grid-binned exact KNN" if args.algo != 1 else "LDS-tiled brute force",
-                   "parallelism": gdist.PARALLELISM if world > 1 else "single GPU"},
+                   "parallelism": ((gslab.PARALLELISM if exchange["path"] == "slab" else gdist.PARALLELISM + " -- " + exchange["path"])
+                                   if (world > 1 or slab_comm is not None) else "single GPU")},
         "roofline": roofline,
         "kernel_ms_per_step": main_run["kernel_ms_per_step"],
         "survivors_rank0": int(res.mask_local.sum().item()),

@@ -184,3 +184,50 @@ def test_slab_plan_is_equal_count_and_monotone():
         own = [hist[a:b].sum() for a, b in zip(cut, cut[1:])]
         assert max(own) <= total / world + 5000 + 50
     assert slab.pts_per_cell(16) == pytest.approx(7.25) and slab.pts_per_cell(32) == pytest.approx(14.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SOG SH-palette K-Means: the reference's independent chunks (sog.py:527-552) dealt out to the ranks
+def _oracle_kmeans(data, k, it, init):
+    from oracle import kmeans as okm
+    if k >= len(data):
+        return data.copy(), np.arange(len(data), dtype=np.int32)
+    c, l, _ = okm.lloyd(data, init, it)
+    return c, l
+
+
+def _palette_worker(rank, world, port, n, d, level, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    pal = importlib.import_module("3dgsconverter_amd.dist_palette")
+    from oracle.slab_backend import NumpySlabBackend
+    be = NumpySlabBackend()
+    sh = (np.random.default_rng(5).standard_normal((n, d)) * 0.1).astype(np.float32)
+    np.random.seed(77)
+    cen, lab = pal.palette_kmeans(sh, level, 4, kmeans=_oracle_kmeans, comm=slab.TorchHostComm(be), be=be)
+    np.save(os.path.join(out_dir, "cen_%d.npy" % rank), cen)
+    np.save(os.path.join(out_dir, "lab_%d.npy" % rank), lab)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_palette_chunks_across_ranks_equal_the_single_process_loop(world, tmp_path):
+    import importlib
+    import torch.multiprocessing as mp
+    pal = importlib.import_module("3dgsconverter_amd.dist_palette")
+    n, d, level = 7000, 9, 8   # 6 chunks of 1167 rows, k_per_chunk 683
+    mp.spawn(_palette_worker, args=(world, _free_port(), n, d, level, str(tmp_path)), nprocs=world, join=True)
+    sh = (np.random.default_rng(5).standard_normal((n, d)) * 0.1).astype(np.float32)
+    np.random.seed(77)
+    cen, lab = pal.palette_kmeans(sh, level, 4, kmeans=_oracle_kmeans)
+    plan = pal.palette_plan(n, level)
+    assert plan == {"target_k": 4096, "num_chunks": 6, "chunk_size": 1167, "k_per_chunk": 683}
+    assert cen.shape == (6 * 683, d) and lab.shape == (n,) and lab.max() < len(cen)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / ("cen_%d.npy" % r)), cen)
+        np.testing.assert_array_equal(np.load(tmp_path / ("lab_%d.npy" % r)), lab)

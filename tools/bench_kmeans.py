@@ -1,0 +1,142 @@
+"""bench.py --workload kmeans: BASELINE.json configs[4] -- the SOG SH-palette K-Means of a 10M-splat scene
+(compression_level 2: 64 chunks x (156 250 x 45 f32), K = 1024 per chunk, 10 Lloyd iterations; formats/sog.py:513-552
+calling gpu_ops.kmeans, reference kernels gpu_ops.py:57-96).
+
+One step = all chunks of the scene, SH rows already resident in HBM (the reference re-uploads every chunk twice per
+iteration); initial centroids are random rows (gpu_ops.py:182) restored before every step.  With N GPUs
+the chunks are dealt out round robin (no collective): strong scaling, value = splats of the whole
+scene / step time.  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector FP32 (FMA = 2 flops)
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    gsx = importlib.import_module("3dgsconverter_amd")
+    pal = importlib.import_module("3dgsconverter_amd.dist_palette")
+    L = gsx._lib
+    ctx = L.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+
+    n_scene = args.n if args.n != 10_000_000 or True else args.n
+    d, iters, level = 45, 10, 2
+    plan = pal.palette_plan(n_scene, level)
+    nch, cs, k = plan["num_chunks"], plan["chunk_size"], plan["k_per_chunk"]
+    mine = [i for i in range(nch) if i % world == rank]
+    steps = args.steps if args.steps != 30 else 5
+    warmup = min(args.warmup, 2)
+
+    # synthetic SH rows of this rank's chunks (f_rest ~ N(0, 0.1^2)), generated on the device
+    g = torch.Generator(device=dev)
+    chunks, inits = [], []
+    for i in mine:
+        rows = min(cs, n_scene - i * cs)
+        g.manual_seed(1000 + i)
+        x = torch.randn((rows, d), generator=g, device=dev, dtype=torch.float32) * 0.1
+        chunks.append(x)
+        inits.append(x[torch.randperm(rows, generator=g, device=dev)[:k]].contiguous())
+    cents = [t.clone() for t in inits]
+    labels = [torch.empty(c.shape[0], dtype=torch.int32, device=dev) for c in chunks]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        for j in range(len(mine)):
+            cents[j].copy_(inits[j])
+            L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j].data_ptr(), chunks[j].shape[0], d, k, iters,
+                                                 cents[j].data_ptr(), labels[j].data_ptr()), "gsx_kmeans_lloyd_dev")
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    ctx.set_param("timing_mask", (1 << L.T_KMEANS_ASSIGN) | (1 << L.T_KMEANS_UPDATE))
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    n_as, ms_as = ctx.timing(L.T_KMEANS_ASSIGN)
+    n_up, ms_up = ctx.timing(L.T_KMEANS_UPDATE)
+    ctx.set_timing(False)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = dt / steps * 1e3
+    value = n_scene * steps / dt / 1e6
+    assign_ms = ms_as / max(n_as, 1)            # one launch = one Lloyd iteration of one chunk (assign + fused accumulate)
+    rows0 = chunks[0].shape[0]
+    flops = 3.0 * rows0 * k * d                 # per (point, centroid, dim): 1 subtract + 1 fused multiply-add
+    achieved = flops / (assign_ms * 1e-3) / 1e12 if assign_ms > 0 else 0.0
+    alg_bytes = rows0 * (4 * d + 4)             # read the rows once, write one label
+    out = {
+        "metric": "Msplats/sec SOG SH-palette K-Means (64 chunks x K=1024 x 10 iterations)", "value": round(value, 2),
+        "unit": "Msplats/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (f64 cluster sums)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[4]: %d splats, degree-3 SH rows (45 f32), compression_level %d -> %d chunks "
+                               "of %d rows, K=%d per chunk, %d Lloyd iterations, rows resident in HBM" % (n_scene, level, nch, cs, k, iters),
+                   "splats": n_scene, "chunks": nch, "k_per_chunk": k, "iterations": iters,
+                   "parallelism": "chunks dealt out round robin, no collective" if world > 1 else "single GPU"},
+        "roofline": {"bound": "valu", "kernel": "kmeans_assign_kernel<45,16,false>", "achieved": round(achieved, 2),
+                     "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                     "traffic": None, "kernel_ms": round(assign_ms, 4), "flops_per_launch": flops,
+                     "algorithmic_bytes": alg_bytes,
+                     "hbm_frac_of_8TBs": round(alg_bytes / (assign_ms * 1e-3) / 8e12, 5) if assign_ms > 0 else None,
+                     "note": "vector FP32 (not MFMA): the argmin needs every distance in the reference's f32 accumulation order; "
+                             "3 flops per (point, centroid, dim) as 1 v_pk_add + 1 v_pk_fma on two points per lane"},
+        "kernel_ms_per_step": {"assign+accumulate": round(ms_as / steps, 3), "finalize": round(ms_up / steps, 3)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's CPU path for the same call (gpu_ops.py:48-52: MiniBatchKMeans, batch 16384, n_init auto), ONE chunk
+        from sklearn.cluster import MiniBatchKMeans
+        x = chunks[0].cpu().numpy()
+        t0 = time.perf_counter()
+        km = MiniBatchKMeans(n_clusters=k, max_iter=iters, batch_size=min(4096 * 4, len(x)), n_init="auto", compute_labels=True)
+        km.fit(x)
+        cpu_dt = time.perf_counter() - t0
+        from oracle import kmeans as okm
+        i_cpu = okm.inertia(x, km.cluster_centers_, km.labels_)
+        i_gpu = okm.inertia(x, cents[0].cpu().numpy(), labels[0].cpu().numpy())
+        out["cpu_baseline"] = {"value": round(rows0 / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "one of the %d chunks (%d x %d, K=%d, max_iter=%d), once (%.2f s): sklearn MiniBatchKMeans "
+                                         "called as the reference's _kmeans_sklearn does" % (nch, rows0, d, k, iters, cpu_dt),
+                               "inertia_cpu": round(i_cpu, 2), "inertia_gpu_same_chunk": round(i_gpu, 2)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
