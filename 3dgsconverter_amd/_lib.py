@@ -54,6 +54,7 @@ SIGNATURES = {
     "gsx_dev_free": (_I, [_P, _P]),
     "gsx_dev_upload": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_dev_copy": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
@@ -67,8 +68,8 @@ SIGNATURES = {
     "gsx_comm_all_gather": (_I, [_P, _P, _P, _I64]),
     "gsx_comm_all_to_all_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _I]),
     "gsx_slab_bbox_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
-    "gsx_slab_hist_dev": (_I, [_P, _P, _I64, _I64, C.c_float, C.c_float, _P]),
-    "gsx_slab_partition_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, C.c_float, C.c_float, _P, C.c_float, _I, _P, _P, _P, _P, _P]),
+    "gsx_slab_hist_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "gsx_slab_partition_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _P]),
     "gsx_sor_knn_slab_dev": (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     "gsx_slab_certify_dev": (_I, [_P, _P, _I64, _I64, _P, C.c_float, C.c_float, _P]),
     "gsx_slab_unpermute_dev": (_I, [_P, _P, _P, _I64, _P]),

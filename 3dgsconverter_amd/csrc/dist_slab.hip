@@ -131,17 +131,36 @@ __device__ __forceinline__ int slab_bin(float v, float lo, float inv_w)
     return min(max(b, 0), SLAB_BINS - 1);
 }
 
-__global__ __launch_bounds__(256) void slab_hist_kernel(const float *__restrict__ c, int64_t stride, int64_t n, float lo,
-                                                        float inv_w, unsigned long long *__restrict__ hist)
+// axis / range of the partition coordinate from the (all-reduced) bbox words: the longest edge, first one on ties
+__device__ __forceinline__ void slab_axis(const float *__restrict__ b7, int &axis, float &lo, float &hi)
+{
+    const float e0 = b7[3] + b7[0], e1 = b7[4] + b7[1], e2 = b7[5] + b7[2];  // max - min = max + max(-x)
+    axis = 0;
+    if (e1 > e0) axis = 1;
+    if (e2 > (e1 > e0 ? e1 : e0)) axis = 2;
+    lo = -b7[axis];
+    hi = b7[3 + axis];
+}
+
+// local histogram of the partition coordinate; range and axis are read from the device-resident global bbox, so no
+// host round trip separates the bbox all-reduce from this pass
+__global__ __launch_bounds__(256) void slab_hist_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ z, int64_t stride, int64_t n,
+                                                        const float *__restrict__ b7, unsigned *__restrict__ hist)
 {
     __shared__ unsigned h[SLAB_BINS];
+    int axis;
+    float lo, hi;
+    slab_axis(b7, axis, lo, hi);
+    const float inv_w = hi > lo ? (float)SLAB_BINS / (hi - lo) : 0.0f;
+    const float *__restrict__ c = axis == 0 ? x : (axis == 1 ? y : z);
     for (int i = threadIdx.x; i < SLAB_BINS; i += 256) h[i] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         atomicAdd(&h[slab_bin(c[i * stride], lo, inv_w)], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < SLAB_BINS; i += 256)
-        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+        if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
 constexpr int SLAB_MAX_RANKS = 16;
@@ -149,29 +168,18 @@ struct SlabPlan {
     int world;
     int axis;                        // 0/1/2: the partition axis (the longest edge of the global box)
     float lo, inv_w;                 // histogram binning of that axis
-    int cut[SLAB_MAX_RANKS + 1];     // slab s owns bins [cut[s], cut[s+1])
-    float halo_lo[SLAB_MAX_RANKS];   // a point with coordinate c is a reference for slab s iff halo_lo[s] <= c <= halo_hi[s]
-    float halo_hi[SLAB_MAX_RANKS];
+    int cut[SLAB_MAX_RANKS + 1];     // slab s OWNS bins [cut[s], cut[s+1])
+    int halo_bins;                   // ... and RECEIVES (reference-only) bins [cut[s] - halo_bins, cut[s+1] + halo_bins):
+                                     // membership by bin index, so every count follows from the histograms alone
 };
 
-__device__ __forceinline__ int slab_owner(const SlabPlan &p, float c)
-{
-    const int b = slab_bin(c, p.lo, p.inv_w);
-    int s = 0;
-#pragma unroll 1
-    while (s + 1 < p.world && b >= p.cut[s + 1]) ++s;
-    return s;
-}
-
 // Per 2048-point tile (points stay in registers): count the rows per slot (slot 2s = owned by slab s, 2s+1 =
-// reference-only copy for slab s) in LDS, reserve the tile's runs with one global atomic per non-empty slot, then
-// (SCATTER) rank the rows inside their runs with a second LDS pass and write them.  A point may be a halo copy for
-// any number of slabs (slabs thinner than W).
-template <bool SCATTER>
+// reference-only copy for slab s) in LDS, reserve the tile's runs with one global atomic per non-empty slot, rank the
+// rows inside their runs with a second LDS pass and write them.  A point may be a halo copy for any number of
+// slabs (slabs thinner than the halo).
 __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, int64_t stride, int64_t n,
-                                                             SlabPlan plan, unsigned *__restrict__ counts /* [2*world], !SCATTER */,
-                                                             unsigned *__restrict__ cursor /* [2*world], SCATTER */,
+                                                             SlabPlan plan, unsigned *__restrict__ cursor /* [2*world] */,
                                                              float *__restrict__ send /* rows of 3 floats */,
                                                              unsigned *__restrict__ send_src /* local index of each OWN row */)
 {
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
     if (tile0 >= n) return;
     if (threadIdx.x < nslot) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    float px[8], py[8], pz[8], pc[8];
-    int owner[8];
+    float px[8], py[8], pz[8];
+    int bin[8], owner[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int64_t i = tile0 + u * 256 + threadIdx.x;
@@ -192,21 +200,24 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
             px[u] = x[i * stride];
             py[u] = y[i * stride];
             pz[u] = z[i * stride];
-            pc[u] = plan.axis == 0 ? px[u] : (plan.axis == 1 ? py[u] : pz[u]);
-            owner[u] = slab_owner(plan, pc[u]);
-            atomicAdd(&s_cnt[2 * owner[u]], 1u);
-            for (int s = 0; s < plan.world; ++s)
-                if (s != owner[u] && pc[u] >= plan.halo_lo[s] && pc[u] <= plan.halo_hi[s]) atomicAdd(&s_cnt[2 * s + 1], 1u);
+            bin[u] = slab_bin(plan.axis == 0 ? px[u] : (plan.axis == 1 ? py[u] : pz[u]), plan.lo, plan.inv_w);
+            int s = 0;
+#pragma unroll 1
+            while (s + 1 < plan.world && bin[u] >= plan.cut[s + 1]) ++s;
+            owner[u] = s;
+            atomicAdd(&s_cnt[2 * s], 1u);
+            for (int t = 0; t < plan.world; ++t)
+                if (t != s && bin[u] >= plan.cut[t] - plan.halo_bins && bin[u] < plan.cut[t + 1] + plan.halo_bins)
+                    atomicAdd(&s_cnt[2 * t + 1], 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x < nslot) {
         const unsigned c = s_cnt[threadIdx.x];
-        s_base[threadIdx.x] = c ? atomicAdd(SCATTER ? &cursor[threadIdx.x] : &counts[threadIdx.x], c) : 0u;
+        s_base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
         s_cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (!SCATTER) return;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         if (owner[u] < 0) continue;
@@ -218,9 +229,9 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
             send[3 * at + 2] = pz[u];
             send_src[at] = (unsigned)i;
         }
-        for (int s = 0; s < plan.world; ++s)
-            if (s != owner[u] && pc[u] >= plan.halo_lo[s] && pc[u] <= plan.halo_hi[s]) {
-                const size_t at = (size_t)s_base[2 * s + 1] + atomicAdd(&s_cnt[2 * s + 1], 1u);
+        for (int t = 0; t < plan.world; ++t)
+            if (t != owner[u] && bin[u] >= plan.cut[t] - plan.halo_bins && bin[u] < plan.cut[t + 1] + plan.halo_bins) {
+                const size_t at = (size_t)s_base[2 * t + 1] + atomicAdd(&s_cnt[2 * t + 1], 1u);
                 send[3 * at + 0] = px[u];
                 send[3 * at + 1] = py[u];
                 send[3 * at + 2] = pz[u];
@@ -385,30 +396,30 @@ int gsx_slab_bbox_dev(gsx_ctx *c, const float *x, const float *y, const float *z
     return 0;
 }
 
-int gsx_slab_hist_dev(gsx_ctx *c, const float *coord, int64_t stride, int64_t n, float lo, float hi, int64_t *hist4096_dev)
+int gsx_slab_hist_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, const float *bbox7_dev,
+                      uint32_t *hist4096_dev)
 {
-    if (!c || !coord || !hist4096_dev || n < 0) GSX_FAIL("gsx_slab_hist_dev: bad arguments");
+    if (!c || !x || !y || !z || !bbox7_dev || !hist4096_dev || n < 0) GSX_FAIL("gsx_slab_hist_dev: bad arguments");
     GSX_HIP(hipSetDevice(c->device));
-    GSX_HIP(hipMemsetAsync(hist4096_dev, 0, sizeof(int64_t) * SLAB_BINS, c->stream));
+    GSX_HIP(hipMemsetAsync(hist4096_dev, 0, sizeof(uint32_t) * SLAB_BINS, c->stream));
     if (n == 0) return 0;
-    const float inv_w = hi > lo ? (float)SLAB_BINS / (hi - lo) : 0.0f;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4096), (int64_t)c->num_cu * 4));
-    hipLaunchKernelGGL(slab_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, coord, stride, n, lo, inv_w,
-                       reinterpret_cast<unsigned long long *>(hist4096_dev));
+    hipLaunchKernelGGL(slab_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, bbox7_dev, hist4096_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }
 
 /*
- * plan (host): world, axis, lo, hi of the histogram, cut[world+1] (bin index where each slab starts; cut[world] = 4096),
- * halo width W.  mode 0: counts_dev[2*world] += (own, halo) per destination.  mode 1: rows are written to send_dev at the
- * cursors in cursor_dev[2*world] (start offsets in rows, advanced), send_src_dev gets the local index of every OWN row.
+ * plan (host): world, axis, [lo, hi] = the binned range (the all-reduced bbox words of that axis), cut[world+1], halo_bins.
+ * Rows (3 floats) are written to send_dev at the row cursors cursor_dev[2*world] (start offsets, advanced): slot 2s = rows
+ * owned by slab s, slot 2s+1 = reference-only copies for slab s; send_src_dev[row] = local index of every own row.
+ * planes_out (host, 2*world floats, nullable): coordinates between which slab s is guaranteed to hold EVERY point.
  */
 int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, int world,
-                           int axis, float lo, float hi, const int32_t *cut, float halo_w, int mode, uint32_t *counts_dev,
-                           uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev, float *planes_out)
+                           int axis, float lo, float hi, const int32_t *cut, int halo_bins, uint32_t *cursor_dev,
+                           float *send_dev, uint32_t *send_src_dev, float *planes_out)
 {
-    if (!c || !x || !y || !z || !cut || world < 1 || world > SLAB_MAX_RANKS || axis < 0 || axis > 2)
+    if (!c || !x || !y || !z || !cut || world < 1 || world > SLAB_MAX_RANKS || axis < 0 || axis > 2 || halo_bins < 0)
         GSX_FAIL("gsx_slab_partition_dev: bad arguments");
     GSX_HIP(hipSetDevice(c->device));
     SlabPlan p;
@@ -416,29 +427,30 @@ int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const flo
     p.axis = axis;
     p.lo = lo;
     p.inv_w = hi > lo ? (float)SLAB_BINS / (hi - lo) : 0.0f;
-    const float bw = hi > lo ? (hi - lo) / (float)SLAB_BINS : 0.0f;
+    p.halo_bins = halo_bins;
     for (int s = 0; s <= world; ++s) p.cut[s] = cut[s];
-    for (int s = 0; s < world; ++s) {
-        // conservative f32 planes of slab s (bin edges are recomputed, not trusted to round-trip): one extra bin of slack
-        // on both sides only ever ADDS halo points
-        const float s_lo = lo + bw * (float)(cut[s] - 1), s_hi = lo + bw * (float)(cut[s + 1] + 1);
-        p.halo_lo[s] = s == 0 ? -INFINITY : s_lo - halo_w;
-        p.halo_hi[s] = s == world - 1 ? INFINITY : s_hi + halo_w;
-    }
-    if (planes_out)  // (halo_lo, halo_hi) of every slab: what gsx_slab_certify_dev must be given as its open faces
-        for (int s2 = 0; s2 < world; ++s2) {
-            planes_out[2 * s2] = p.halo_lo[s2];
-            planes_out[2 * s2 + 1] = p.halo_hi[s2];
+    if (planes_out) {
+        // slab s holds every point whose bin is in [cut[s] - halo_bins, cut[s+1] + halo_bins).  bin(c) is a monotone f32
+        // function of c whose steps sit within ~1e-3 of a bin of lo + b * bw: half a bin inside is safely inside.
+        const double bw = hi > lo ? ((double)hi - (double)lo) / SLAB_BINS : 0.0;
+        for (int s = 0; s < world; ++s) {
+            const int b0 = cut[s] - halo_bins, b1 = cut[s + 1] + halo_bins;
+            planes_out[2 * s] = (s == 0 || b0 <= 0) ? -INFINITY : (float)((double)lo + ((double)b0 + 0.5) * bw);
+            planes_out[2 * s + 1] = (s == world - 1 || b1 >= SLAB_BINS) ? INFINITY : (float)((double)lo + ((double)b1 - 0.5) * bw);
         }
+    }
     if (n <= 0) return 0;
-    const int blocks = div_up(n, 2048);
-    if (mode == 0)
-        hipLaunchKernelGGL((slab_partition_kernel<false>), dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, p, counts_dev,
-                           cursor_dev, send_dev, send_src_dev);
-    else
-        hipLaunchKernelGGL((slab_partition_kernel<true>), dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, p, counts_dev,
-                           cursor_dev, send_dev, send_src_dev);
+    if (!cursor_dev || !send_dev || !send_src_dev) GSX_FAIL("gsx_slab_partition_dev: null buffer");
+    hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n, 2048)), dim3(256), 0, c->stream, x, y, z, stride, n, p, cursor_dev,
+                       send_dev, send_src_dev);
     GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int gsx_dev_copy(gsx_ctx *c, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    if (!c) GSX_FAIL("null ctx");
+    if (bytes) GSX_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 

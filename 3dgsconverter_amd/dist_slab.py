@@ -8,19 +8,21 @@ survivor mask of that shard back -- bit-identical to the single-GPU / reference 
 One step (``slab_sor``); the device pieces are C-ABI entry points (include/gsx_hip.h,
 csrc/dist_slab.hip), this module only moves sizes and offsets around:
 
-  1. global bounding box: ``gsx_slab_bbox_dev`` + ONE float32 max all-reduce of 7 words;
-  2. equal-count slabs along the longest axis: 4096-bin histogram + int64 sum all-reduce (32 KB);
+  1. global bounding box: ``gsx_slab_bbox_dev`` + ONE float32 max all-reduce of 7 words (stays on the device);
+  2. 4096-bin histogram of the longest axis, all-gathered (16 KB per rank): equal-count slab cuts AND -- because
+     slab membership is decided by bin index -- every (source, destination) row count.  This is the step's only
+     host synchronisation;
   3. ``gsx_slab_partition_dev``: every point is sent to the rank owning its slab and, as a
-     reference-only copy, to every rank whose slab lies within W of it (W = ``halo_cells`` x the KNN
-     cell edge of the GLOBAL density).  Grouped ncclSend/ncclRecv, 12 B per point -- no rank ever
-     holds or bins the whole cloud (an all-gather of xyz costs 12 (G-1) N_local B per rank and G-fold
-     redundant binning: measured dead end of round 1, DESIGN.md section 7);
+     reference-only copy, to every rank whose slab lies within ``halo_cells`` KNN cell edges (of the
+     GLOBAL density, rounded up to whole bins) of it.  Grouped ncclSend/ncclRecv, 12 B per point -- no
+     rank ever holds or bins the whole cloud (an all-gather of xyz costs 12 (G-1) N_local B per rank and
+     G-fold redundant binning: measured dead end of round 1, DESIGN.md section 7);
   4. ``gsx_sor_knn_slab_dev``: the single-GPU exact-KNN pipeline on (own + halo) rows, halo lanes dead;
   5. certificate ``gsx_slab_certify_dev``: a result is globally exact iff the query's k-th neighbour is
      nearer than the edge of what this rank received.  Sum all-reduce of the number of uncertified
-     queries; if it is not zero (far floaters, slabs thinner than the neighbour distance) the step
-     raises ``SlabUncertain`` and ``dist.sharded_sor`` falls back to the replicated exchange, which is
-     exact for any cloud -- results are identical either way;
+     queries, read back lazily (``SlabResult.check``); if it is not zero (far floaters, slabs thinner
+     than the neighbour distance) ``SlabUncertain`` is raised and the caller re-runs the step with the
+     replicated exchange of dist.py, which is exact for any cloud -- results are identical either way;
   6. mean distances travel back to the index owners (4 B per point) and are un-permuted;
   7. statistics: numpy's float32 reduction is "pairwise inside 8192-element pieces, pieces added
      sequentially", so each rank sums the pieces it holds (after handing the < 8192 leading
@@ -191,21 +193,21 @@ class HipSlabBackend:
         p = rows.ptr
         self._chk(self.lib.gsx_slab_bbox_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), out7.ptr), "gsx_slab_bbox_dev")
 
-    def hist(self, rows, n, axis, lo, hi, hist):
-        self._chk(self.lib.gsx_slab_hist_dev(self.ctx.handle, rows.ptr + 4 * axis, 3, int(n), float(lo), float(hi), hist.ptr),
-                  "gsx_slab_hist_dev")
+    def hist(self, rows, n, bbox7, hist):
+        p = rows.ptr
+        self._chk(self.lib.gsx_slab_hist_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), bbox7.ptr, hist.ptr), "gsx_slab_hist_dev")
 
-    def partition(self, rows, n, world, axis, lo, hi, cut, halo_w, mode, counts, cursor, send, send_src):
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, cursor, send, send_src):
         p = rows.ptr
         cuts = (C.c_int32 * (world + 1))(*[int(c) for c in cut])
         planes = (C.c_float * (2 * world))()
         self._chk(self.lib.gsx_slab_partition_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), int(world), int(axis), float(lo),
-                                                  float(hi), cuts, float(halo_w), int(mode),
-                                                  counts.ptr if counts is not None else None,
-                                                  cursor.ptr if cursor is not None else None,
-                                                  send.ptr if send is not None else None,
-                                                  send_src.ptr if send_src is not None else None, planes), "gsx_slab_partition_dev")
+                                                  float(hi), cuts, int(halo_bins), cursor.ptr, send.ptr, send_src.ptr, planes),
+                  "gsx_slab_partition_dev")
         return np.array(planes[:], dtype=np.float32).reshape(world, 2)
+
+    def copy(self, dst, src, nbytes):
+        self._chk(self.lib.gsx_dev_copy(self.ctx.handle, dst.ptr, src.ptr, int(nbytes)), "gsx_dev_copy")
 
     def knn_slab(self, rows, n_own, n_halo, k, mean_out, kth_out):
         self._chk(self.lib.gsx_sor_knn_slab_dev(self.ctx.handle, rows.ptr, int(n_own), int(n_halo), int(k), mean_out.ptr, kth_out.ptr),
@@ -255,48 +257,76 @@ def plan_slabs(hist: np.ndarray, world: int):
     return cut, total
 
 
+def slab_counts(allhist: np.ndarray, cut, halo_bins: int):
+    """rows every source sends every slab, from the per-rank histograms alone: own[src, s], halo[src, s]"""
+    world = allhist.shape[0]
+    cum = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(allhist.astype(np.int64), axis=1)], axis=1)
+    own = np.empty((world, world), np.int64)
+    halo = np.empty((world, world), np.int64)
+    for s in range(world):
+        a, b = cut[s], cut[s + 1]
+        ha, hb = max(a - halo_bins, 0), min(b + halo_bins, BINS)
+        own[:, s] = cum[:, b] - cum[:, a]
+        halo[:, s] = (cum[:, hb] - cum[:, ha]) - own[:, s]
+    return own, halo
+
+
+class SlabResult(dict):
+    """buffers of one step.  The certificate is evaluated on the device and read back lazily: call ``check()`` (one
+    synchronisation) before trusting the buffers; it raises SlabUncertain when the slabs could not certify every query."""
+
+    def check(self):
+        be = self["_be"]
+        n_unc = int(be.to_host(self["uncertain"], np.int64, 1)[0])
+        be.check()
+        if n_unc:
+            raise SlabUncertain("%d queries could not be certified inside their slab (halo of %d bins)" % (n_unc, self["info"]["halo_bins"]))
+        return self
+
+
 def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 2.5, want_host: bool = False):
     """rows: backend buffer holding this rank's (n_local,3) float32 index shard (same n_local on every rank).
-    -> dict(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info)."""
+    -> SlabResult(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info).
+    ONE host synchronisation inside the step (the histograms, from which every size follows)."""
     G, r = comm.world, comm.rank
     n_local = int(n_local)
-    # ---- 1. bounding box
+    if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):
+        raise ValueError("slab_sor: index shards must hold a multiple of 4 and at least 8192 points (got %d)" % n_local)
+    # ---- 1. bounding box (device-resident), 2. histogram of the longest axis; all-gathered: cuts AND every row count
     b7 = be.buf("bbox", 32)
     be.bbox(rows, n_local, b7)
     if G > 1:
         comm.all_reduce(b7, 7, KIND_F32_MAX)
-    hb = be.to_host(b7, np.float32, 7)
+    hist = be.buf("hist", 4 * BINS)
+    be.hist(rows, n_local, b7, hist)
+    allhist_buf = be.buf("allhist", 4 * BINS * G)
+    if G > 1:
+        comm.all_gather(hist, allhist_buf, 4 * BINS)
+    else:
+        allhist_buf = hist
+    hb = be.to_host(b7, np.float32, 7)                                         # <- the step's host synchronisation
+    allhist = be.to_host(allhist_buf, np.uint32, BINS * G).reshape(G, BINS)
     if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
         raise ValueError("sor: coordinates are not finite (NaN/inf)")
-    lo3, hi3 = -hb[:3].astype(np.float64), hb[3:6].astype(np.float64)
-    ext = hi3 - lo3
-    axis = int(np.argmax(ext))
-    lo, hi = np.float32(lo3[axis]), np.float32(hi3[axis])
-    # ---- 2. equal-count slabs
-    hist = be.buf("hist", 8 * BINS)
-    be.hist(rows, n_local, axis, lo, hi, hist)
-    if G > 1:
-        comm.all_reduce(hist, BINS, KIND_I64_SUM)
-    cut, n_total = plan_slabs(be.to_host(hist, np.int64, BINS), G)
+    ext = hb[3:6] + hb[:3]                                                     # float32, like the device (slab_axis)
+    axis = 0
+    if ext[1] > ext[0]:
+        axis = 1
+    if ext[2] > max(ext[0], ext[1]):
+        axis = 2
+    lo, hi = np.float32(-hb[axis]), np.float32(hb[3 + axis])
+    cut, n_total = plan_slabs(allhist.sum(0), G)
     if n_total != G * n_local:
         raise ValueError("slab_sor needs equally sized index shards (%d points in total, %d x %d expected)" % (n_total, G, n_local))
-    nd = int((ext > 0).sum())
-    vol = float(np.prod(ext[ext > 0])) if nd else 0.0
-    per = vol * pts_per_cell(k) / max(n_total, 1)
+    ext64 = ext.astype(np.float64)
+    nd = int((ext64 > 0).sum())
+    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k) / max(n_total, 1) if nd else 0.0
     h_est = per ** (1.0 / nd) if nd else 0.0
-    halo_w = np.float32(halo_cells * h_est)
-    # ---- 3. partition: count, exchange the counts, scatter, exchange the rows
-    cnt = be.buf("cnt", 4 * 2 * G)
-    be.zero(cnt, 4 * 2 * G)
-    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_w, 0, cnt, None, None, None)
-    allcnt_buf = be.buf("allcnt", 4 * 2 * G * G)
-    if G > 1:
-        comm.all_gather(cnt, allcnt_buf, 4 * 2 * G)
-        allcnt = be.to_host(allcnt_buf, np.uint32, 2 * G * G).reshape(G, 2 * G).astype(np.int64)
-    else:
-        allcnt = be.to_host(cnt, np.uint32, 2 * G).reshape(1, 2 * G).astype(np.int64)
-    mine = allcnt[r]
-    own_cnt, halo_cnt = mine[0::2], mine[1::2]
+    bw = (float(hi) - float(lo)) / BINS if hi > lo else 0.0
+    halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS
+    # ---- 3. scatter into the send buffer, exchange the rows (sizes from the histograms: no counting pass)
+    own, halo = slab_counts(allhist, cut, halo_bins)
+    own_cnt, halo_cnt = own[r], halo[r]
     assert int(own_cnt.sum()) == n_local
     own_off = np.concatenate([[0], np.cumsum(own_cnt)[:-1]])
     halo_off = n_local + np.concatenate([[0], np.cumsum(halo_cnt)[:-1]])
@@ -305,17 +335,17 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     cur = np.empty(2 * G, np.uint32)
     cur[0::2], cur[1::2] = own_off, halo_off
     be.from_host(cursor, cur)
-    send = be.buf("send", 12 * n_send)
+    send = be.buf("send", 12 * max(n_send, 1))
     send_src = be.buf("send_src", 4 * max(n_local, 1))
-    be.partition(rows, n_local, G, axis, lo, hi, cut, halo_w, 1, None, cursor, send, send_src)
-    in_own, in_halo = allcnt[:, 2 * r], allcnt[:, 2 * r + 1]      # rows every source sends me
+    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_bins, cursor, send, send_src)
+    in_own, in_halo = own[:, r], halo[:, r]                                    # rows every source sends me
     n_own, n_halo = int(in_own.sum()), int(in_halo.sum())
     r_own_off = np.concatenate([[0], np.cumsum(in_own)[:-1]])
     r_halo_off = n_own + np.concatenate([[0], np.cumsum(in_halo)[:-1]])
     slab = be.buf("slab", 12 * max(n_own + n_halo, 1))
     comm.all_to_all_v(send, own_off, own_cnt, slab, r_own_off, in_own, 12)
     comm.all_to_all_v(send, halo_off, halo_cnt, slab, r_halo_off, in_halo, 12)
-    # ---- 4./5. exact KNN on the slab, certificate
+    # ---- 4./5. exact KNN on the slab; certificate (device-side count, summed over the ranks, read by check())
     md_slab = be.buf("md_slab", 4 * max(n_own, 1))
     kth = be.buf("kth", 8 * max(n_own, 1))
     if n_own:
@@ -326,9 +356,6 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
         be.certify(slab, axis, n_own, kth, planes[r, 0], planes[r, 1], unc)
     if G > 1:
         comm.all_reduce(unc, 1, KIND_I64_SUM)
-    n_unc = int(be.to_host(unc, np.int64, 1)[0])
-    if n_unc:
-        raise SlabUncertain("%d queries could not be certified inside their slab (halo %.4g)" % (n_unc, float(halo_w)))
     # ---- 6. mean distances back to the index owners, original order
     ret = be.buf("ret", 4 * max(n_local, 1))
     comm.all_to_all_v(md_slab, r_own_off, in_own, ret, own_off, own_cnt, 4)
@@ -336,11 +363,8 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     be.unpermute(ret, send_src, n_local, md)
     # ---- 7. numpy-exact statistics from 8192-element piece sums
     stats = be.buf("stats", 16)
-    start = r * n_local
-    head = (-start) % NP_PIECE                          # my leading elements complete my left neighbour's last piece
-    nxt_head = (-(start + n_local)) % NP_PIECE if r + 1 < G else 0
-    if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):
-        raise ValueError("slab_sor: index shards must hold a multiple of 4 and at least 8192 points (got %d)" % n_local)
+    heads = [(-(q * n_local)) % NP_PIECE for q in range(G)] + [0]              # leading elements owed to the left neighbour
+    head, nxt_head = heads[r], heads[r + 1]
     if G > 1:
         s_off, s_cnt, r_off, r_cnt = [0] * G, [0] * G, [0] * G, [0] * G
         if r > 0:
@@ -349,30 +373,29 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
             r_off[r + 1], r_cnt[r + 1] = n_local, nxt_head
         comm.all_to_all_v(md, s_off, s_cnt, md, r_off, r_cnt, 4)
     n_mine = n_local - head + nxt_head
-    my_pieces = -(-n_mine // NP_PIECE) if n_mine > 0 else 0
-    max_pieces = n_local // NP_PIECE + 2
+    counts = [-(-(n_local - heads[q] + heads[q + 1]) // NP_PIECE) for q in range(G)]
+    max_pieces = max(counts)
     pieces = be.buf("pieces", 4 * max_pieces)
     allp = be.buf("allpieces", 4 * max_pieces * G)
     packed = be.buf("packed", 4 * max_pieces * G)
-    counts = [(-(-(n_local - ((-(q * n_local)) % NP_PIECE) + ((-((q + 1) * n_local)) % NP_PIECE if q + 1 < G else 0)) // NP_PIECE))
-              for q in range(G)]
     for mode in (0, 1):
-        if my_pieces:
-            be.piece_sums(be.at(md, 4 * head), n_mine, stats if mode else None, pieces)
+        be.piece_sums(be.at(md, 4 * head), n_mine, stats if mode else None, pieces)
         if G > 1:
             comm.all_gather(pieces, allp, 4 * max_pieces)
-            ap = be.to_host(allp, np.float32, max_pieces * G).reshape(G, max_pieces)
-            flat = np.concatenate([ap[q, :counts[q]] for q in range(G)])
-            be.from_host(packed, flat)
-            be.stats_from_pieces(packed, len(flat), n_total, mode, threshold_factor, stats)
+            o = 0
+            for q in range(G):   # drop the padding: a handful of small device-to-device copies
+                be.copy(be.at(packed, 4 * o), be.at(allp, 4 * max_pieces * q), 4 * counts[q])
+                o += counts[q]
+            be.stats_from_pieces(packed, o, n_total, mode, threshold_factor, stats)
         else:
-            be.stats_from_pieces(pieces, my_pieces, n_total, mode, threshold_factor, stats)
+            be.stats_from_pieces(pieces, counts[0], n_total, mode, threshold_factor, stats)
     # ---- 8. mask of the local index range
     mask = be.buf("mask", n_local + 4)
     be.mask(md, n_local, stats, mask)
-    out = {"mask": mask, "mean_dists": md, "stats": stats, "n_total": n_total, "n_own": n_own, "n_halo": n_halo,
-           "info": {"axis": axis, "halo_w": float(halo_w), "cut": cut}}
+    out = SlabResult({"mask": mask, "mean_dists": md, "stats": stats, "uncertain": unc, "_be": be, "n_total": n_total,
+                      "n_own": n_own, "n_halo": n_halo, "info": {"axis": axis, "halo_bins": halo_bins, "cut": cut}})
     if want_host:
+        out.check()
         out["mask_host"] = be.to_host(mask, np.uint8, n_local).view(np.bool_)
         out["mean_dists_host"] = be.to_host(md, np.float32, n_local)
         out["stats_host"] = be.to_host(stats, np.float32, 3)

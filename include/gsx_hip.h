@@ -100,6 +100,7 @@ int gsx_dev_malloc(gsx_ctx *ctx, size_t bytes, void **dptr);
 int gsx_dev_free(gsx_ctx *ctx, void *dptr);
 int gsx_dev_upload(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int gsx_dev_copy(gsx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* device to device, asynchronous */
 
 /* ---- Host-side row operations around every filter -- */
 /*
@@ -174,17 +175,18 @@ int gsx_comm_all_to_all_v(gsx_ctx *ctx, const void *send_dev, const int64_t *sen
  * global bounding box (the per-rank half of gpu_ops.py:203-206) */
 int gsx_slab_bbox_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
                       float *out7_dev);
-/* 4096-bin histogram (int64) of one coordinate over [lo, hi]: summed over the ranks it yields equal-count slabs */
-int gsx_slab_hist_dev(gsx_ctx *ctx, const float *coord, int64_t stride, int64_t n, float lo, float hi,
-                      int64_t *hist4096_dev);
-/* Slab s owns the histogram bins [cut[s], cut[s+1]); a point is also a REFERENCE-ONLY copy for every other slab it
- * lies within halo_w of.  mode 0: counts_dev[2*world] += rows per destination (own, halo).  mode 1: rows (3 floats)
- * are written to send_dev at the row cursors cursor_dev[2*world] (advanced), send_src_dev[row] = local index of each
- * own row.  planes_out (host, 2*world floats, nullable): the [lo, hi] coordinate range every slab receives. */
+/* 4096-bin histogram (uint32) of the partition coordinate = the longest axis of the box in bbox7_dev (read ON THE DEVICE:
+ * no host round trip after the bbox all-reduce).  All-gathered, the histograms give every rank the equal-count slab
+ * cuts AND every (source, destination) row count, since slab membership is decided by bin index. */
+int gsx_slab_hist_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                      const float *bbox7_dev, uint32_t *hist4096_dev);
+/* Slab s OWNS the bins [cut[s], cut[s+1]) of the axis range [lo, hi] and also receives, as REFERENCE-ONLY rows, the
+ * bins within halo_bins of them.  Rows (3 floats) are written to send_dev at the row cursors cursor_dev[2*world]
+ * (slot 2s: owned by slab s, slot 2s+1: halo copies for slab s; advanced), send_src_dev[row] = local index of each own
+ * row.  planes_out (host, 2*world floats, nullable): coordinates between which slab s holds EVERY point of the cloud. */
 int gsx_slab_partition_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
-                           int world, int axis, float lo, float hi, const int32_t *cut, float halo_w, int mode,
-                           uint32_t *counts_dev, uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev,
-                           float *planes_out);
+                           int world, int axis, float lo, float hi, const int32_t *cut, int halo_bins,
+                           uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev, float *planes_out);
 /* exact KNN mean distance of the first n_own rows against all n_own + n_halo rows (the halo rows are never
  * queries); kth_d2_dev[i] = squared distance of query i's (k+1)-th neighbour INCLUDING itself, i.e. its k-th other */
 int gsx_sor_knn_slab_dev(gsx_ctx *ctx, const float *rows_dev, int64_t n_own, int64_t n_halo, int k,

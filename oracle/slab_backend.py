@@ -79,48 +79,48 @@ class NumpySlabBackend:
         inv_w = np.float32(BINS) / (np.float32(hi) - np.float32(lo)) if hi > lo else np.float32(0)
         return np.clip(((c - np.float32(lo)) * inv_w).astype(np.int32), 0, BINS - 1)
 
-    def hist(self, rows, n, axis, lo, hi, hist):
+    @staticmethod
+    def _axis(b7):
+        e = b7[3:6] + b7[:3]    # float32, as csrc/dist_slab.hip: slab_axis
+        axis = 0
+        if e[1] > e[0]:
+            axis = 1
+        if e[2] > max(e[0], e[1]):
+            axis = 2
+        return axis, np.float32(-b7[axis]), np.float32(b7[3 + axis])
+
+    def hist(self, rows, n, bbox7, hist):
+        axis, lo, hi = self._axis(bbox7.view(np.float32, 7))
         c = rows.view(np.float32, 3 * n).reshape(n, 3)[:, axis]
-        hist.view(np.int64, BINS)[:] = np.bincount(self._bin(c, lo, hi), minlength=BINS)
+        hist.view(np.uint32, BINS)[:] = np.bincount(self._bin(c, lo, hi), minlength=BINS)
 
-    def _planes(self, world, lo, hi, cut, halo_w):
-        lo, hi, halo_w = np.float32(lo), np.float32(hi), np.float32(halo_w)
-        bw = (hi - lo) / np.float32(BINS) if hi > lo else np.float32(0)
-        pl = np.empty((world, 2), np.float32)
-        for s in range(world):
-            s_lo = lo + bw * np.float32(cut[s] - 1)
-            s_hi = lo + bw * np.float32(cut[s + 1] + 1)
-            pl[s, 0] = -np.inf if s == 0 else s_lo - halo_w
-            pl[s, 1] = np.inf if s == world - 1 else s_hi + halo_w
-        return pl
-
-    def partition(self, rows, n, world, axis, lo, hi, cut, halo_w, mode, counts, cursor, send, send_src):
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, cursor, send, send_src):
         x = rows.view(np.float32, 3 * n).reshape(n, 3)
-        c = x[:, axis]
-        owner = np.searchsorted(np.asarray(cut[1:world], dtype=np.int64), self._bin(c, lo, hi), side="right")
-        pl = self._planes(world, lo, hi, cut, halo_w)
-        if mode == 0:
-            cnt = counts.view(np.uint32, 2 * world)
-            for s in range(world):
-                cnt[2 * s] += np.uint32((owner == s).sum())
-                cnt[2 * s + 1] += np.uint32(((owner != s) & (c >= pl[s, 0]) & (c <= pl[s, 1])).sum())
-            return pl
+        b = self._bin(x[:, axis], lo, hi)
+        owner = np.searchsorted(np.asarray(cut[1:world], dtype=np.int64), b, side="right")
+        lo64, hi64 = np.float64(np.float32(lo)), np.float64(np.float32(hi))
+        bw = (hi64 - lo64) / BINS if hi > lo else 0.0
+        pl = np.empty((world, 2), np.float32)
         cur = cursor.view(np.uint32, 2 * world)
-        n_send = int(cur.max()) + n  # upper bound of the rows this call can write
         out = send.view(np.float32, 3 * (send.nbytes // 12)).reshape(-1, 3)
         src = send_src.view(np.uint32, n)
         for s in range(world):
+            b0, b1 = cut[s] - halo_bins, cut[s + 1] + halo_bins
+            pl[s, 0] = -np.inf if (s == 0 or b0 <= 0) else np.float32(lo64 + (b0 + 0.5) * bw)
+            pl[s, 1] = np.inf if (s == world - 1 or b1 >= BINS) else np.float32(lo64 + (b1 - 0.5) * bw)
             idx = np.nonzero(owner == s)[0]
             o = int(cur[2 * s])
             out[o:o + len(idx)] = x[idx]
             src[o:o + len(idx)] = idx
             cur[2 * s] += len(idx)
-            hidx = np.nonzero((owner != s) & (c >= pl[s, 0]) & (c <= pl[s, 1]))[0]
+            hidx = np.nonzero((owner != s) & (b >= b0) & (b < b1))[0]
             o = int(cur[2 * s + 1])
             out[o:o + len(hidx)] = x[hidx]
             cur[2 * s + 1] += len(hidx)
-        del n_send
         return pl
+
+    def copy(self, dst, src, nbytes):
+        dst.view(np.uint8, nbytes)[:] = src.view(np.uint8, nbytes)
 
     def knn_slab(self, rows, n_own, n_halo, k, mean_out, kth_out):
         from scipy.spatial import cKDTree

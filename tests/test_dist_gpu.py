@@ -58,8 +58,24 @@ def test_slab_path_world1_through_rccl_matches_the_golden_1m(gsx, golden_cases):
     comm.close()
 
 
+def _spawn(target, world, args):
+    """world processes through the standard library's spawn context.  NOT torch.multiprocessing: importing torch into
+    this (pytest) process after libgsx_hip.so has bound ROCm's own libamdhip64 / librccl puts two HIP runtimes into
+    one process, which corrupts the heap at exit (torch must be imported FIRST where both are used --
+    the workers do that)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=target, args=(r, world) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert [p.exitcode for p in procs] == [0] * world, [p.exitcode for p in procs]
+
+
 def _worker(rank, world, port, n_local, k, sigma, kind, out_dir):
     sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (first: see _spawn)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -96,8 +112,7 @@ def _cloud(kind, n):
 @pytest.mark.parametrize("world,kind,n_local,k", [(2, "uniform", 300000, 16), (3, "uniform", 100000, 32), (2, "gradient", 150000, 16),
                                                   (3, "gradient", 70000, 8)])
 def test_slab_path_on_shared_gpu_equals_the_unsharded_result(world, kind, n_local, k, tmp_path):
-    import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _free_port(), n_local, k, 1.0, kind, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, world, (_free_port(), n_local, k, 1.0, kind, str(tmp_path)))
     assert not list(tmp_path.glob("uncertain_*"))
     full = _cloud(kind, world * n_local)
     ref = osor.sor(full, k, 1.0)
@@ -116,6 +131,5 @@ def test_slab_path_on_shared_gpu_equals_the_unsharded_result(world, kind, n_loca
 
 
 def test_slab_path_refuses_floaters_on_every_rank(tmp_path):
-    import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), 40000, 16, 1.0, "floaters", str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, 2, (_free_port(), 40000, 16, 1.0, "floaters", str(tmp_path)))
     assert len(list(tmp_path.glob("uncertain_*"))) == 2 and not list(tmp_path.glob("mask_*"))
