@@ -22,6 +22,8 @@ FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector FP32 (FMA = 2 flop
 
 
 def main(args):
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"   # keep RCCL's banner off stdout (one JSON line is expected there)
     import torch
     import torch.distributed as dist
 
