@@ -66,12 +66,16 @@ def main():
                          "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: RCCL (banner, warnings) and other libraries print to the C stdout, so
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a private copy of the real one
+    sys.stdout.flush()
+    args.json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if args.workload == "kmeans":
         from importlib import import_module
         return import_module("tools.bench_kmeans").main(args)
 
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"   # RCCL's version banner goes to STDOUT, where exactly one JSON line is expected
     import torch  # first: its bundled HIP runtime (same SONAME) is the one the .so binds to
     import torch.distributed as dist
 
@@ -282,7 +286,7 @@ def main():
                                "kind": "port", "sample": "the full %d-splat workload, once (%.2f s): "
                                "scipy cKDTree query workers=%d + numpy stats" % (args.n, cpu_dt, workers),
                                "mask_identical_to_gpu": same}
-    print(json.dumps(out))
+    os.write(args.json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

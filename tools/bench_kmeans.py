@@ -22,8 +22,6 @@ FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector FP32 (FMA = 2 flop
 
 
 def main(args):
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"   # keep RCCL's banner off stdout (one JSON line is expected there)
     import torch
     import torch.distributed as dist
 
@@ -139,6 +137,6 @@ def main(args):
                                "sample": "one of the %d chunks (%d x %d, K=%d, max_iter=%d), once (%.2f s): sklearn MiniBatchKMeans "
                                          "called as the reference's _kmeans_sklearn does" % (nch, rows0, d, k, iters, cpu_dt),
                                "inertia_cpu": round(i_cpu, 2), "inertia_gpu_same_chunk": round(i_gpu, 2)}
-    print(json.dumps(out))
+    os.write(args.json_fd, (json.dumps(out) + "\n").encode())   # bench.py pointed fd 1 at stderr; this is the real stdout
     if world > 1:
         dist.destroy_process_group()
