@@ -55,6 +55,8 @@ SIGNATURES = {
     "gsx_dev_upload": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_copy": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),

@@ -99,14 +99,24 @@ __global__ __launch_bounds__(256) void slab_bbox_kernel(const float *__restrict_
     float m[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) m[a] = a < 6 ? -__builtin_inff() : 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v[3] = {x[i * stride], y[i * stride], z[i * stride]};
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {   // 12 loads in flight per lane
+        float v[4][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            m[a] = fmaxf(m[a], -v[a]);
-            m[3 + a] = fmaxf(m[3 + a], v[a]);
-            m[6] = (fabsf(v[a]) < __builtin_inff()) ? m[6] : 1.0f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * step < n ? i0 + u * step : i0;
+            v[u][0] = x[i * stride];
+            v[u][1] = y[i * stride];
+            v[u][2] = z[i * stride];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                m[a] = fmaxf(m[a], -v[u][a]);
+                m[3 + a] = fmaxf(m[3 + a], v[u][a]);
+                m[6] = (fabsf(v[u][a]) < __builtin_inff()) ? m[6] : 1.0f;
+            }
     }
 #pragma unroll
     for (int a = 0; a < 7; ++a)
@@ -389,7 +399,8 @@ int gsx_slab_bbox_dev(gsx_ctx *c, const float *x, const float *y, const float *z
     const float init[7] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0f};
     GSX_HIP(hipMemcpyAsync(out7_dev, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 8));
+        // one result per workgroup goes through 7 same-address atomics: keep the grid at two workgroups per CU
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 2));
         hipLaunchKernelGGL(slab_bbox_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, out7_dev);
         GSX_HIP(hipGetLastError());
     }
@@ -444,6 +455,21 @@ int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const flo
     hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n, 2048)), dim3(256), 0, c->stream, x, y, z, stride, n, p, cursor_dev,
                        send_dev, send_src_dev);
     GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+/* enqueue only: hipMemcpyAsync from pageable memory has consumed the host buffer when it returns */
+int gsx_dev_upload_async(gsx_ctx *c, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (!c) GSX_FAIL("null ctx");
+    if (bytes) GSX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int gsx_dev_memset(gsx_ctx *c, void *dst_dev, int value, size_t bytes)
+{
+    if (!c) GSX_FAIL("null ctx");
+    if (bytes) GSX_HIP(hipMemsetAsync(dst_dev, value, bytes, c->stream));
     return 0;
 }
 

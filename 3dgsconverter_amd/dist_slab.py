@@ -179,11 +179,14 @@ class HipSlabBackend:
 
     def from_host(self, buf, arr):
         a = np.ascontiguousarray(arr)
-        if a.nbytes:
+        if a.nbytes > (1 << 16):
             self._lib.check(self.lib.gsx_dev_upload(self.ctx.handle, buf.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload")
+        elif a.nbytes:   # small control data: enqueue only, no stream synchronisation (the runtime stages pageable
+            # memory before returning, so the temporary may die)
+            self._lib.check(self.lib.gsx_dev_upload_async(self.ctx.handle, buf.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload_async")
 
     def zero(self, buf, nbytes):
-        self.from_host(buf, np.zeros(int(nbytes), np.uint8))
+        self._lib.check(self.lib.gsx_dev_memset(self.ctx.handle, buf.ptr, 0, int(nbytes)), "gsx_dev_memset")
 
     def _chk(self, rc, what):
         self._lib.check(rc, what)
@@ -284,10 +287,12 @@ class SlabResult(dict):
         return self
 
 
-def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 2.5, want_host: bool = False):
+def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 1.5, want_host: bool = False):
     """rows: backend buffer holding this rank's (n_local,3) float32 index shard (same n_local on every rank).
     -> SlabResult(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info).
-    ONE host synchronisation inside the step (the histograms, from which every size follows)."""
+    ONE host synchronisation inside the step (the histograms, from which every size follows).
+    halo_cells: halo width in KNN cell edges h of the global density.  On uniform data a query's k-th neighbour is at
+    ~0.82 h and beyond 1.3 h with probability < 1e-13; the certificate catches whatever the halo does not cover."""
     G, r = comm.world, comm.rank
     n_local = int(n_local)
     if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):

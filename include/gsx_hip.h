@@ -101,6 +101,8 @@ int gsx_dev_free(gsx_ctx *ctx, void *dptr);
 int gsx_dev_upload(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int gsx_dev_copy(gsx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* device to device, asynchronous */
+int gsx_dev_upload_async(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);  /* enqueue only */
+int gsx_dev_memset(gsx_ctx *ctx, void *dst_dev, int value, size_t bytes);                    /* enqueue only */
 
 /* ---- Host-side row operations around every filter -- */
 /*
