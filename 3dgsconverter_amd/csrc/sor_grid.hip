@@ -49,7 +49,10 @@ constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index roun
 constexpr int MAX_BUCKETS = 4096;         // LDS histogram bins of the coarse pass
 constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 KiB)
 constexpr int BUCKET_POINTS = 4096;       // target points per bucket
-constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass
+#ifndef GSX_BIN_TILE
+#define GSX_BIN_TILE 8192
+#endif
+constexpr int BIN_TILE = GSX_BIN_TILE;    // points per workgroup tile in the coarse pass
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
 constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of knn_heavy_scan covers (512 per lane: the
@@ -728,6 +731,9 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #ifndef GSX_NET_BF
 #define GSX_NET_BF 1
 #endif
+#ifndef GSX_NET_DU
+#define GSX_NET_DU 0   // measured: 2.15 vs 2.07 ms at 10M -- the branch also skips finished lanes' work
+#endif
 constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
@@ -1025,7 +1031,12 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                             }
 #pragma unroll
                             for (int j = 0; j < HB; ++j) {
-                                const double d = dist2_f64(qxd, qyd, qzd, pt[j].x, pt[j].y, pt[j].z);
+                                double d = dist2_f64(qxd, qyd, qzd, pt[j].x, pt[j].y, pt[j].z);
+#if GSX_NET_DU
+                                // keep the distance UNCONDITIONAL: without the barrier the compiler sinks its 11 ops into
+                                // an `if (ok)` block, i.e. a divergent branch (exec save/restore + s_cbranch) per candidate
+                                asm volatile("" : "+v"(d));
+#endif
                                 blk[h0 + j] = (ok[j] && __float_as_uint(pt[j].w) != self_w) ? d : __builtin_inf();
                             }
                         }
