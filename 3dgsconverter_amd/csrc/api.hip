@@ -225,6 +225,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
 #else
         if (value != 0.0) GSX_FAIL("debug_skip needs a profiling build of the library (-DGSX_ABLATE); this one computes exact results only");
 #endif
+    } else if (!strcmp(name, "kmeans_mfma")) {
+        c->kmeans_mfma = value != 0.0;
     } else if (!strcmp(name, "phase2_net")) {
         c->phase2_net = value != 0.0;
     } else if (!strcmp(name, "timing_mask")) {

@@ -143,6 +143,484 @@ __global__ __launch_bounds__(64 * NW) void kmeans_assign_kernel(const float *__r
     }
 }
 
+// ---- matrix-core assign (D = 9, 24, 45; K >= 64) -------------------------------------------------------------------
+// argmin_c |x - c|^2 = argmin_c (|c|^2 - 2 x.c): the K x N inner products are a GEMM.  It runs on
+// v_mfma_f32_32x32x16_bf16 as a FILTER, the same way knn_brick's phase 1 does (sor_grid.hip): every f32 value is split
+// into two bf16 pieces (v = vh + vl, |v - vh - vl| <= 2^-18 |v|), x.c ~ xh.ch + xh.cl + xl.ch (three MFMAs per 16
+// dimensions), |c|^2 rides in the padding slots of the K dimension as three bf16 pieces against 1.0.  Per point the THREE
+// smallest approximate values are tracked with their indices.  If the two smallest are further apart than twice the
+// error bound E below, the smallest IS the centroid the exact f32 kernel would pick.  Else, if the third is further
+// than 2E from the first, only the first two can win and the reference's own arithmetic (gpu_ops.py:57-73: f32, dims
+// in order, strict '<' = first minimum) is evaluated on those two rows in place.  Else (three-way near tie, duplicate
+// centroids, NaN rows) the point goes to kmeans_assign_exact_list_kernel, which scans all K centroids that way.
+// Labels are therefore IDENTICAL to kmeans_assign_kernel's.  Error budget of the approximate value against the exact-kernel's f32 distance minus |x|^2,
+// with nx = |x|, nc = max_c |c|:
+//   dropped xl.cl and split residuals      <= 2 * 3 * 2^-18 nx nc          = 2.3e-5 nx nc
+//   f32 accumulation of <= 144 products    <= 144 * 2^-24 (2 nx nc + nc^2) = 8.6e-6 (2 nx nc + nc^2)
+//   |c|^2 in f32 and its three bf16 pieces <= 2.8e-6 nc^2
+//   the exact kernel's own fmaf chain      <= 47 * 2^-24 (nx + nc)^2       = 2.8e-6 (nx + nc)^2
+//   index bits in the 4 low mantissa bits  <= 15 * 2^-24 (2 nx nc + nc^2)  = 9e-7 (2 nx nc + nc^2)
+//   E := 2^-14 (nx nc + nc^2) + 2^-18 nx^2 covers the sum.
+typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+typedef float kf32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned ku32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned km_cvt_pk_bf16(float lo, float hi)  // RNE, lo -> bits 0..15
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float km_bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float km_bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// eight f32 values -> their bf16 high pieces and the bf16 of the remainders, packed in MFMA operand order
+__device__ __forceinline__ void km_split8(const float (&v)[8], ku32x4 &hi, ku32x4 &lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = km_cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = km_cvt_pk_bf16(v[2 * i] - km_bf_lo(h), v[2 * i + 1] - km_bf_hi(h));
+    }
+}
+
+// raw min / max: fminf / fmaxf make LLVM add a canonicalising v_max per operand (see knn_common.h); NaN operands are
+// ignored by the hardware ops, which is what the tracking wants
+__device__ __forceinline__ float km_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float km_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float km_min3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+constexpr int km_dp(int d) { return (d + 3 + 15) / 16 * 16; }  // K-dimension incl. the three |c|^2 slots: 16, 32, 48
+
+// Centroid operands for the whole iteration: for tile t (32 centroids), 16-dimension slice j, variant v (0 = high pieces
+// + |c|^2 slots, 1 = low pieces) one 16-byte word per lane at ((t * NS + j) * 2 + v) * 64 + lane, lane l = row l & 31,
+// k = 16 j + 8 (l >> 5) ... + 7.  Also *cmax2 = max |c|^2.
+template <int D>
+__global__ __launch_bounds__(64) void kmeans_centroid_operands_kernel(const float *__restrict__ cent, int k,
+                                                                      ku32x4 *__restrict__ opnd, float *__restrict__ cmax2)
+{
+    constexpr int DP = km_dp(D), NS = DP / 16;
+    const int t = blockIdx.x / NS, j = blockIdx.x % NS;
+    const int lane = threadIdx.x;
+    const int c = 32 * t + (lane & 31), k0 = 16 * j + 8 * (lane >> 5);
+    float v[8];
+    float n2 = 0.0f;
+    if (c < k) {
+        for (int d = 0; d < D; ++d) n2 = __builtin_fmaf(cent[(int64_t)c * D + d], cent[(int64_t)c * D + d], n2);
+        if (j == 0 && lane < 32) atomicMax(reinterpret_cast<int *>(cmax2), __float_as_int(n2));  // n2 >= 0: int order = float order
+    } else {
+        n2 = 1.0e30f;  // padding rows never win
+    }
+    // three bf16 pieces of |c|^2
+    const unsigned p1 = km_cvt_pk_bf16(n2, n2);
+    const float r1 = n2 - km_bf_lo(p1);
+    const unsigned p2 = km_cvt_pk_bf16(r1, r1);
+    const float r2 = r1 - km_bf_lo(p2);
+    bool norm_slot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int d = k0 + i;
+        norm_slot[i] = d >= D && d < D + 3;
+        v[i] = (c < k && d < D) ? -2.0f * cent[(int64_t)c * D + d] : 0.0f;
+    }
+    ku32x4 hi, lo;
+    km_split8(v, hi, lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (norm_slot[i]) {
+            const int piece = k0 + i - D;
+            const float val = piece == 0 ? km_bf_lo(p1) : (piece == 1 ? km_bf_lo(p2) : r2);
+            const unsigned bits = km_cvt_pk_bf16(val, val) & 0xffffu;
+            const int w = i >> 1, sh = (i & 1) * 16;
+            hi[w] = (hi[w] & ~(0xffffu << sh)) | (bits << sh);
+            lo[w] = lo[w] & ~(0xffffu << sh);
+        }
+    opnd[((size_t)(t * NS + j) * 2 + 0) * 64 + lane] = hi;
+    opnd[((size_t)(t * NS + j) * 2 + 1) * 64 + lane] = lo;
+}
+
+#ifndef GSX_KM_WAVES
+#define GSX_KM_WAVES 4
+#endif
+#ifndef GSX_KM_PT
+#define GSX_KM_PT 1   // measured on a SOG chunk (156 250 x 45, K = 1024): 53 us with 1 tile per wave, 59 with 2, 61 with 3
+#endif
+constexpr int KM_MF_WAVES = GSX_KM_WAVES;
+constexpr int KM_MF_PT = GSX_KM_PT;                  // 32-point tiles per wave
+constexpr int KM_MF_TILE = KM_MF_WAVES * KM_MF_PT * 32;  // points per workgroup
+#ifndef GSX_KM_PF
+#define GSX_KM_PF 2
+#endif
+constexpr int KM_PF = GSX_KM_PF;                     // centroid tiles requested ahead
+#ifndef GSX_KM_LDS_A
+#define GSX_KM_LDS_A 0   // 1: centroid operand tiles staged once per workgroup in LDS -- measured slower (89 vs 62 us per SOG
+                         // chunk: a workgroup barrier per tile); 0: every wave streams them from L2
+#endif
+
+// labels only: the update runs as a sort-by-label segmented reduction (kmeans_update_* below), not as 45 float64
+// atomics per point (7M per SOG chunk iteration: ~85 us of the fused VALU kernel's 340)
+template <int D>
+__global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(const float *__restrict__ data, int64_t n,
+                                                                             const ku32x4 *__restrict__ opnd, int ktiles,
+                                                                             const float *__restrict__ cmax2,
+                                                                             int32_t *__restrict__ labels,
+                                                                             unsigned *__restrict__ unc_list, unsigned *__restrict__ unc_count)
+{
+    constexpr int DP = km_dp(D), NS = DP / 16, LS = DP + 1;   // odd LDS row stride
+    constexpr int AW = NS * 2 * 64;                           // operand words (16 B) of one centroid tile
+    __shared__ float s_tile[KM_MF_TILE * LS];
+    __shared__ ku32x4 s_a[GSX_KM_LDS_A ? 2 : 1][GSX_KM_LDS_A ? AW : 1];   // centroid operands shared by the four waves, double buffered
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float nc2 = *cmax2, nc = __builtin_sqrtf(nc2);
+    const int64_t tiles = (n + KM_MF_TILE - 1) / KM_MF_TILE;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t base = tile * KM_MF_TILE;
+        const int rows = (int)(n - base < KM_MF_TILE ? n - base : KM_MF_TILE);
+        __syncthreads();
+        for (int e = threadIdx.x; e < rows * D; e += 64 * KM_MF_WAVES) {   // contiguous rows: one coalesced copy
+            const int r = e / D;
+            s_tile[r * LS + (e - r * D)] = data[base * D + e];
+        }
+        if (GSX_KM_LDS_A)
+            for (int e = threadIdx.x; e < AW; e += 64 * KM_MF_WAVES) s_a[0][e] = opnd[e];
+        __syncthreads();
+        // this wave's point operands: lane l = point (l & 31) of each of its tiles, dimensions 16 j + 8 (l >> 5) ... + 7
+        ku32x4 bh[KM_MF_PT][NS], bl[KM_MF_PT][NS];
+        float nx2[KM_MF_PT];
+#pragma unroll
+        for (int pt = 0; pt < KM_MF_PT; ++pt) {
+            const int r = (wv * KM_MF_PT + pt) * 32 + (lane & 31);
+            const int rr = r < rows ? r : rows - 1;
+            float acc2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int d = 16 * j + 8 * (lane >> 5) + i;
+                    v[i] = d < D ? s_tile[rr * LS + d] : 0.0f;
+                    acc2 = __builtin_fmaf(v[i], v[i], acc2);
+                }
+                km_split8(v, bh[pt][j], bl[pt][j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {   // 1.0 against the three |c|^2 pieces, in the high operand only
+                    const int d = 16 * j + 8 * (lane >> 5) + i;
+                    if (d >= D && d < D + 3) bh[pt][j][i >> 1] |= 0x3f80u << ((i & 1) * 16);
+                }
+            }
+            nx2[pt] = acc2 + __shfl_xor(acc2, 32);
+        }
+        float best[KM_MF_PT], second[KM_MF_PT];
+        int btile[KM_MF_PT];
+#pragma unroll
+        for (int pt = 0; pt < KM_MF_PT; ++pt) {
+            best[pt] = __builtin_inff();
+            second[pt] = __builtin_inff();
+            btile[pt] = 0;
+        }
+        ku32x4 a[NS][2], a_pf[KM_PF][NS][2];   // a_pf[i]: tile t + 1 + i, requested KM_PF tiles ahead (an L2 round trip is
+                                               // longer than one tile's ~600 cycles of MFMA work)
+        if (!GSX_KM_LDS_A) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) a[j][v] = opnd[(size_t)(j * 2 + v) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i + 1 < KM_PF; ++i) {
+                const int tt = i + 1 < ktiles ? i + 1 : ktiles - 1;
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) a_pf[i][j][v] = opnd[(size_t)tt * AW + (size_t)(j * 2 + v) * 64 + lane];
+            }
+        }
+        for (int t = 0; t < ktiles; ++t) {
+            if (GSX_KM_LDS_A) {   // the workgroup fetches tile t+1 into the other buffer while its waves multiply tile t
+                const int cur = t & 1;
+                if (t + 1 < ktiles)
+                    for (int e = threadIdx.x; e < AW; e += 64 * KM_MF_WAVES) s_a[cur ^ 1][e] = opnd[(size_t)(t + 1) * AW + e];
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) a[j][v] = s_a[cur][(j * 2 + v) * 64 + lane];
+            } else {
+                const int tn = t + KM_PF < ktiles ? t + KM_PF : ktiles - 1;
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) a_pf[KM_PF - 1][j][v] = opnd[(size_t)tn * AW + (size_t)(j * 2 + v) * 64 + lane];
+            }
+#pragma unroll
+            for (int pt = 0; pt < KM_MF_PT; ++pt) {
+                kf32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const kbf16x8 ah = __builtin_bit_cast(kbf16x8, a[j][0]), al = __builtin_bit_cast(kbf16x8, a[j][1]);
+                    const kbf16x8 xh = __builtin_bit_cast(kbf16x8, bh[pt][j]), xl = __builtin_bit_cast(kbf16x8, bl[pt][j]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc, 0, 0, 0);
+                }
+                // lane l: column = its point, accumulator r = centroid row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile.
+                // The two smallest of the 16 values by a tournament on (lo <= hi) pairs -- 37 min/max ops instead of
+                // 16 x (compare + select + 3 min/max); the accumulator number rides in the 4 low mantissa bits
+                // (<= 15 ulp, inside E), the tile number is tracked once per tile.
+                float lo[8], hi[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float a0 = __uint_as_float((__float_as_uint(acc[2 * q]) & ~0xfu) | (unsigned)(2 * q));
+                    const float a1 = __uint_as_float((__float_as_uint(acc[2 * q + 1]) & ~0xfu) | (unsigned)(2 * q + 1));
+                    lo[q] = km_min(a0, a1);
+                    hi[q] = km_max(a0, a1);
+                }
+#pragma unroll
+                for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                    for (int q = 0; q < w; ++q) {   // merge the sorted pairs q and q + w: two smallest of four
+                        const float m = km_max(lo[q], lo[q + w]);
+                        lo[q] = km_min(lo[q], lo[q + w]);
+                        hi[q] = km_min3(m, hi[q], hi[q + w]);
+                    }
+                const float m = km_max(best[pt], lo[0]);
+                btile[pt] = lo[0] < best[pt] ? t : btile[pt];
+                best[pt] = km_min(best[pt], lo[0]);
+                second[pt] = km_min3(m, second[pt], hi[0]);
+            }
+            if (GSX_KM_LDS_A) {
+                __syncthreads();   // tile t+1 is in LDS, tile t's buffer is free
+            } else {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        a[j][v] = a_pf[0][j][v];
+#pragma unroll
+                        for (int i = 0; i + 1 < KM_PF; ++i) a_pf[i][j][v] = a_pf[i + 1][j][v];
+                    }
+            }
+        }
+        // the two half-waves hold the same points (different centroid rows): merge, certify, publish
+#pragma unroll
+        for (int pt = 0; pt < KM_MF_PT; ++pt) {
+            const int rb = (int)(__float_as_uint(best[pt]) & 0xfu);   // accumulator number of this lane's best
+            const int bidx = 32 * btile[pt] + (rb & 3) + 8 * (rb >> 2) + 4 * (lane >> 5);
+            const float b2 = __shfl_xor(best[pt], 32), s2 = __shfl_xor(second[pt], 32);
+            const int i2 = __shfl_xor(bidx, 32);
+            const float mb = fminf(best[pt], b2);
+            const float ms = fminf(fmaxf(best[pt], b2), fminf(second[pt], s2));
+            const int mi = b2 < best[pt] ? i2 : bidx;
+            const float nx = __builtin_sqrtf(nx2[pt]);
+            const float E = 6.1035156e-5f * (nx * nc + nc2) + 3.8146973e-6f * nx2[pt];
+            const bool sure = (ms - mb) > 2.0f * E;   // false for NaN / inf rows and exact ties
+            const int r = (wv * KM_MF_PT + pt) * 32 + (lane & 31);
+            if (lane < 32 && r < rows) {
+                if (sure) labels[base + r] = mi;
+                else unc_list[atomicAdd(unc_count, 1u)] = (unsigned)(base + r);
+            }
+        }
+    }
+}
+
+// the points the matrix-core filter could not certify (near ties: ~0.3 % on SOG data): the reference's arithmetic
+// (gpu_ops.py:57-73) over ALL centroids, one wave per point; lane = centroids lane, lane + 64, ...; the lowest index wins
+// inside a lane by the strict '<' and across lanes by the merge.  D is a compile-time constant so that a lane's 45 loads
+// per centroid are all in flight (a runtime loop was latency-bound: 90 us for a few hundred points).
+template <int D>
+__global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const float *__restrict__ data,
+                                                                       const float *__restrict__ cent, int k,
+                                                                       const unsigned *__restrict__ list,
+                                                                       const unsigned *__restrict__ list_count,
+                                                                       int32_t *__restrict__ labels)
+{
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const unsigned cnt = *list_count;
+    for (unsigned it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < cnt; it += nwaves) {
+        const int64_t i = list[it];
+        float x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = data[i * D + d];
+        float best = 1e20f;  // gpu_ops.py:60
+        int bi = -1;
+        for (int c = lane; c < k; c += 64) {
+            const float *__restrict__ cc = cent + (int64_t)c * D;
+            float cv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) cv[d] = cc[d];
+            float dist = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float diff = x[d] - cv[d];
+                dist = __builtin_fmaf(diff, diff, dist);
+            }
+            if (dist < best) {
+                best = dist;
+                bi = c;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            // the sequential scan keeps the FIRST minimum: smaller value, or equal value and smaller (valid) index
+            const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+            best = take ? ob : best;
+            bi = take ? oi : bi;
+        }
+        if (lane == 0) labels[i] = bi;
+    }
+}
+
+// ---- update as a segmented reduction (k_means_update, gpu_ops.py:75-96) ---------------------------------------------
+// labels -> counts[K] (LDS-aggregated histogram) -> exclusive scan -> point indices grouped by label -> one wave per
+// centroid sums its rows (lanes = dimensions, rows read coalesced) in float64 and divides: no per-element atomics, no
+// sums buffer, no separate finalize.  Points with label -1 (unassignable) belong to no cluster.
+__global__ __launch_bounds__(256) void kmeans_label_hist_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
+                                                                unsigned *__restrict__ counts)
+{
+    extern __shared__ unsigned s_h[];
+    const bool use_lds = k <= 8192;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < k; i += 256) s_h[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int l = labels[i];
+        if (l >= 0) atomicAdd(use_lds ? &s_h[l] : &counts[l], 1u);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += 256)
+            if (s_h[i]) atomicAdd(&counts[i], s_h[i]);
+    }
+}
+
+// starts[c] = exclusive scan of counts; cursor[c] = starts[c] (one workgroup)
+__global__ __launch_bounds__(1024) void kmeans_label_scan_kernel(const unsigned *__restrict__ counts, int k,
+                                                                 unsigned *__restrict__ starts, unsigned *__restrict__ cursor)
+{
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b = 0; b < k; b += 1024) {
+        const int i = b + threadIdx.x;
+        const unsigned v = i < k ? counts[i] : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off);
+            if ((int)(threadIdx.x & 63) >= off) inc += o;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned pre = s_carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s_w[w];
+        if (i < k) {
+            starts[i] = pre + inc - v;
+            cursor[i] = pre + inc - v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = pre + inc;
+        __syncthreads();
+    }
+}
+
+// point indices grouped by label.  Per 2048-point tile: LDS ranks (returning atomics), ONE global atomic per (tile, label)
+// reserves the run -- a global atomic per point serialises on the K cursors (35 us per SOG chunk)
+__global__ __launch_bounds__(256) void kmeans_label_scatter_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
+                                                                   unsigned *__restrict__ cursor, unsigned *__restrict__ perm)
+{
+    extern __shared__ unsigned s_h[];   // [k] counts, then [k] run bases (k <= 8192)
+    unsigned *s_b = s_h + k;
+    const bool use_lds = k <= 8192;
+    const int64_t ntiles = (n + 2047) / 2048;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int lab[8];
+        unsigned rk[8];
+        if (use_lds) {
+            for (int i = threadIdx.x; i < k; i += 256) s_h[i] = 0;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = t * 2048 + u * 256 + threadIdx.x;
+            lab[u] = i < n ? labels[i] : -1;
+            if (lab[u] >= 0) rk[u] = use_lds ? atomicAdd(&s_h[lab[u]], 1u) : atomicAdd(&cursor[lab[u]], 1u);
+        }
+        if (use_lds) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < k; i += 256)
+                if (s_h[i]) s_b[i] = atomicAdd(&cursor[i], s_h[i]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lab[u] >= 0) perm[(use_lds ? s_b[lab[u]] : 0u) + rk[u]] = (unsigned)(t * 2048 + u * 256 + threadIdx.x);
+        __syncthreads();
+    }
+}
+
+// one workgroup per centroid: four waves take every fourth row (lanes = dimensions, rows read coalesced, eight in flight),
+// float64 partial sums meet in LDS; also re-zeroes counts for the next iteration
+__global__ __launch_bounds__(256) void kmeans_centroid_reduce_kernel(const float *__restrict__ data, int D,
+                                                                     const unsigned *__restrict__ perm,
+                                                                     const unsigned *__restrict__ starts,
+                                                                     unsigned *__restrict__ counts, int k, float *__restrict__ cent)
+{
+    __shared__ double s_part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const unsigned cnt = counts[c], s0 = starts[c];
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;   // gpu_ops.py:93
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        double acc = 0.0;   // float64 makes the order immaterial (the reference's f32 atomics are order-dependent)
+        // wave g owns the rows g, g + 4, g + 8, ...: 64 of their indices are fetched at once (one per lane) and
+        // broadcast, so the row loads do not wait on the permutation and 16 of them are in flight
+        for (unsigned jb = g; jb < cnt; jb += 256) {
+            const unsigned jmine = jb + 4u * (unsigned)lane;
+            const unsigned my_row = jmine < cnt ? perm[s0 + jmine] : 0u;
+            const int nrows = (int)min(64u, (cnt - jb + 3u) / 4u);
+            for (int i0 = 0; i0 < nrows; i0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const unsigned row = (unsigned)__shfl((int)my_row, (i0 + u) & 63);
+                    v[u] = (i0 + u < nrows && d < D) ? data[(int64_t)row * D + d] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += (double)v[u];
+            }
+        }
+        s_part[g][lane] = acc;
+        __syncthreads();
+        if (g == 0 && d < D) {
+            const double sum = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+            cent[(int64_t)c * D + d] = cnt > 0 ? (float)sum * inv : 0.0f;   // empty cluster -> 0 (gpu_ops.py:78-96)
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[c] = 0u;
+}
+
 // any D (slow path): coordinates re-read from memory
 __global__ __launch_bounds__(256) void kmeans_assign_generic_kernel(const float *__restrict__ data, int64_t n, int D,
                                                                     const float *__restrict__ cent, int k,
@@ -248,11 +726,51 @@ static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const floa
                            cent, k, labels, sums, counts);
 }
 
+template <int D>
+static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float *cent, int k, int32_t *labels, unsigned *counts)
+{
+    constexpr int NS = km_dp(D) / 16;
+    const int ktiles = (k + 31) / 32;
+    const size_t opnd_bytes = sizeof(ku32x4) * (size_t)ktiles * NS * 2 * 64;
+    // operand words | meta (16 words) | uncertain list / permutation (n words) | starts (k) | cursor (k)
+    GSX_CHECK(c->scratch5.reserve(opnd_bytes + sizeof(unsigned) * (size_t)(16 + n + 2 * (size_t)k + 16)));
+    ku32x4 *opnd = c->scratch5.as<ku32x4>();
+    unsigned *meta = reinterpret_cast<unsigned *>(c->scratch5.as<char>() + opnd_bytes);  // [0] = max |c|^2 (float bits), [1] = list length
+    unsigned *list = meta + 16, *starts = list + n, *cursor = starts + k;
+    GSX_HIP(hipMemsetAsync(meta, 0, sizeof(unsigned) * 16, c->stream));
+    hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
+                       reinterpret_cast<float *>(meta));
+    const int64_t tiles = div_up(n, KM_MF_TILE);
+    const int blocks = (int)std::min<int64_t>(tiles, (int64_t)c->num_cu * 8);
+    hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
+                       reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * 2), dim3(256), 0, c->stream, data, cent, k, list,
+                       meta + 1, labels);
+    // update (the list is dead now: its storage becomes the permutation)
+    const int hb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 4));
+    hipLaunchKernelGGL(kmeans_label_hist_kernel, dim3(hb), dim3(256), k <= 8192 ? sizeof(unsigned) * (size_t)k : 0, c->stream, labels, n,
+                       k, counts);
+    hipLaunchKernelGGL(kmeans_label_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, k, starts, cursor);
+    hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
+                       labels, n, k, cursor, list);
+    hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
 // returns 0 and sets *fused when the templated kernel (assign + accumulate in one launch) ran
-static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, const float *cent, int k, int32_t *labels,
-                         double *sums, unsigned *counts, bool *fused)
+static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, float *cent, int k, int32_t *labels,
+                         double *sums, unsigned *counts, bool *fused, bool *updated)
 {
     *fused = true;
+    *updated = false;
+    if (c->kmeans_mfma && k >= 64 && (d == 9 || d == 24 || d == 45)) {
+        // matrix-core filter + exact certificate (identical labels), update by segmented reduction: the whole iteration
+        *updated = true;
+        if (d == 9) return launch_assign_mfma_t<9>(c, data, n, cent, k, labels, counts);
+        if (d == 24) return launch_assign_mfma_t<24>(c, data, n, cent, k, labels, counts);
+        return launch_assign_mfma_t<45>(c, data, n, cent, k, labels, counts);
+    }
     switch (d) {
         case 1: launch_assign_t<1>(c, data, n, cent, k, labels, sums, counts); break;
         case 2: launch_assign_t<2>(c, data, n, cent, k, labels, sums, counts); break;
@@ -282,10 +800,11 @@ int kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k,
     const int acc_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n * d, 256), (int64_t)c->num_cu * 16));
     GSX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * kd + sizeof(unsigned) * (size_t)k, c->stream));
     for (int it = 0; it < max_iter; ++it) {
-        bool fused = false;
+        bool fused = false, updated = false;
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_ASSIGN));
-        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused));
+        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused, &updated));
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
+        if (updated) continue;   // the matrix-core path ran assign AND update (sort-by-label reduction)
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
         if (!fused)
             hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(acc_blocks), dim3(256), 0, c->stream, data_dev, n, d,
