@@ -24,6 +24,9 @@ from ..utils import debug_print, status_print
 from . import clusters as _clusters
 
 
+MAX_SOR_K = 64  # include/gsx_hip.h: gsx_sor_* accept 1 <= k <= 64
+
+
 def sor_params_from_intensity(intensity):
     """reference :125-134 (intensity 5 -> (27, 12.44), not the (25, 10.5) of its comment)."""
     k = int(10 + (intensity - 1) * (40 / 9))
@@ -74,6 +77,11 @@ class DataProcessor:
         num_points = len(vertices)
         if num_points == 0:
             return self.data
+        if not 1 <= int(k) <= MAX_SOR_K:
+            # the reference's cKDTree path takes any k and its Taichi kernel silently caps K at 50 (gpu_ops.py:244);
+            # the register-resident top-k lists of the HIP kernels stop at 64 -- say so instead of failing deep inside
+            raise ValueError(f"SOR: k={k} is outside the supported range 1..{MAX_SOR_K} of the MI355X path "
+                             f"(--sor_intensity maps to k = 10..50, the CLI default is 25)")
         status_print("[SOR] Determining outliers on GPU (HIP gfx950, exact KNN)...")
         res = _lib.sor_filter(_xyz_rows(vertices), int(k), float(threshold_factor), want_mean=False)
         self.last_sor = {"mean": res["mean"], "std": res["std"], "threshold": res["threshold"]}

@@ -158,3 +158,18 @@ def test_info_struct_layout_matches_the_header(gsx, tmp_path):
     assert int(out["size"]) == C.sizeof(gsx._lib.SorInfo)
     for f in fields:
         assert int(out[f]) == getattr(gsx._lib.SorInfo, f).offset, f
+
+
+def test_sor_k_range_is_checked_at_the_python_boundary(gsx):
+    """k > 64 (the reference's cKDTree path takes any k, its Taichi kernel caps K at 50) is refused with a clear
+    message before anything reaches the device -- not a GsxError from deep inside the library"""
+    arr = np.zeros(100, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4")])
+    arr["x"] = np.arange(100)
+    with pytest.raises(ValueError, match="1..64"):
+        gsx.DataProcessor(arr).remove_flyers(65, 1.0)
+    with pytest.raises(ValueError, match="1..64"):
+        gsx.gpu_ops.filter_sor_gpu(np.zeros((100, 3), np.float32), k=0)
+    # every --sor_intensity maps inside the range (data_processor.py:125-134)
+    from importlib import import_module
+    dp = import_module("3dgsconverter_amd.processing.data_processor")
+    assert [dp.sor_params_from_intensity(i)[0] for i in (1, 5, 10)] == [10, 27, 50]
