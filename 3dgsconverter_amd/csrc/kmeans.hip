@@ -746,6 +746,9 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
                        reinterpret_cast<const float *>(meta), labels, list, meta + 1);
     hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * 2), dim3(256), 0, c->stream, data, cent, k, list,
                        meta + 1, labels);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
+    GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
     // update (the list is dead now: its storage becomes the permutation)
     const int hb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 4));
     hipLaunchKernelGGL(kmeans_label_hist_kernel, dim3(hb), dim3(256), k <= 8192 ? sizeof(unsigned) * (size_t)k : 0, c->stream, labels, n,
@@ -755,6 +758,7 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
                        labels, n, k, cursor, list);
     hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
     GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(c, GSX_T_KMEANS_UPDATE));
     return 0;
 }
 
@@ -803,8 +807,8 @@ int kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k,
         bool fused = false, updated = false;
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_ASSIGN));
         GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused, &updated));
+        if (updated) continue;   // the matrix-core path ran assign AND update (sort-by-label reduction) and closed both timing slots
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
-        if (updated) continue;   // the matrix-core path ran assign AND update (sort-by-label reduction)
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
         if (!fused)
             hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(acc_blocks), dim3(256), 0, c->stream, data_dev, n, d,
