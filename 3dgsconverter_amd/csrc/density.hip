@@ -11,11 +11,14 @@
 // Only counts per voxel and membership reach the mask, never np.unique's order, so the
 // lexicographic sort (the reference's O(N log N) hot spot) is replaced by an open-addressing
 // hash table in HBM keyed by a 63-bit packed voxel key (3 x 21 bits relative to the minimum
-// key).  Points arrive in arbitrary order; when few voxels hold most points the global
+// key); scenes spanning more than 2^21 voxels on an axis (voxel 0.1 on a 10^6-unit scene needs 25
+// bits per axis) take the WIDE layout: a 96-bit key in two words, claimed lock-free in two steps
+// (see table_add).  Points arrive in arbitrary order; when few voxels hold most points the global
 // atomics would pile onto a handful of addresses, so every workgroup first aggregates its
 // 4096-point tile in a 1024-slot LDS table and flushes one global atomic per (tile, voxel).
 // HBM-bound: 12 B read per point per pass (bbox, count, mask) + 1 B written.
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "gsx_common.h"
@@ -25,7 +28,7 @@ namespace gsx {
 struct VoxelFrame {
     int kmin[3];
     int dim[3];   // kmax - kmin + 1
-    int ok;       // 0: key range does not fit 3 x 21 bits (or non-finite coordinates)
+    int ok;       // 0: non-finite / absurd coordinates; 1: keys fit 3 x 21 bits; 2: WIDE (x,y in one 64-bit word, z in a second)
     int pad;
 };
 
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64) void voxel_frame_kernel(const float *__restrict
         if (!(fabsf(lo) < 1.0e9f) || !(fabsf(hi) < 1.0e9f)) { ok = 0; lo = hi = 0.f; }
         int klo = (int)lo, khi = (int)hi;
         long long d = (long long)khi - klo + 1;
-        if (d > (1 << 21) - 1) { ok = 0; d = 1; }
+        if (d > (1 << 21) - 1 && ok) ok = 2;   // |keys| < 1e9 above => d < 2^31: fits the wide layout
         vf->kmin[a] = klo;
         vf->dim[a] = (int)d;
     }
@@ -105,11 +108,26 @@ __global__ __launch_bounds__(64) void voxel_frame_kernel(const float *__restrict
     vf->pad = 0;
 }
 
-__device__ __forceinline__ unsigned long long pack_key(const VoxelFrame &f, int kx, int ky, int kz)
+// a = word compared first (0 = empty slot), b = second word (wide layout only; 0 = not yet written)
+struct VKey {
+    unsigned long long a;
+    unsigned b;
+};
+
+template <bool WIDE>
+__device__ __forceinline__ VKey pack_key(const VoxelFrame &f, int kx, int ky, int kz)
 {
-    // +1 so that 0 can mean "empty slot"
-    return (((unsigned long long)(unsigned)(kx - f.kmin[0]) << 42) | ((unsigned long long)(unsigned)(ky - f.kmin[1]) << 21) |
-            (unsigned long long)(unsigned)(kz - f.kmin[2])) + 1ull;
+    VKey k;
+    if (WIDE) {
+        k.a = (((unsigned long long)(unsigned)(kx - f.kmin[0]) << 32) | (unsigned long long)(unsigned)(ky - f.kmin[1])) + 1ull;
+        k.b = (unsigned)(kz - f.kmin[2]) + 1u;
+    } else {
+        // +1 so that 0 can mean "empty slot"
+        k.a = (((unsigned long long)(unsigned)(kx - f.kmin[0]) << 42) | ((unsigned long long)(unsigned)(ky - f.kmin[1]) << 21) |
+               (unsigned long long)(unsigned)(kz - f.kmin[2])) + 1ull;
+        k.b = 0u;
+    }
+    return k;
 }
 
 __device__ __forceinline__ unsigned hash_key(unsigned long long k)
@@ -121,15 +139,35 @@ __device__ __forceinline__ unsigned hash_key(unsigned long long k)
     k ^= k >> 33;
     return (unsigned)k;
 }
-
-__device__ __forceinline__ void table_add(unsigned long long *__restrict__ tkeys, unsigned *__restrict__ tcnt,
-                                          unsigned mask, unsigned long long key, unsigned c)
+template <bool WIDE>
+__device__ __forceinline__ unsigned hash_vkey(const VKey &k)
 {
-    unsigned h = hash_key(key) & mask;
+    return WIDE ? hash_key(k.a ^ ((unsigned long long)k.b * 0x9e3779b97f4a7c15ull)) : hash_key(k.a);
+}
+
+// Open addressing, linear probing, no locks and no spinning.  WIDE slots are claimed in two steps: CAS the first
+// word from 0, then CAS the second from 0; a thread that finds its own first word in a slot whose second word is
+// still 0 may complete the slot with ITS second word (the first claimer then sees a mismatch and probes on), so a
+// half-written slot never blocks anybody.  Works for tables in HBM and in LDS alike.
+template <bool WIDE>
+__device__ __forceinline__ bool slot_claim(unsigned long long *ka, unsigned *kb, unsigned h, const VKey &key)
+{
+    unsigned long long old = ka[h];
+    if (old == 0ull) old = atomicCAS(&ka[h], 0ull, key.a);
+    if (old != 0ull && old != key.a) return false;
+    if (!WIDE) return true;
+    unsigned ob = kb[h];
+    if (ob == 0u) ob = atomicCAS(&kb[h], 0u, key.b);
+    return ob == 0u || ob == key.b;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void table_add(unsigned long long *__restrict__ tkeys, unsigned *__restrict__ tkb,
+                                          unsigned *__restrict__ tcnt, unsigned mask, const VKey &key, unsigned c)
+{
+    unsigned h = hash_vkey<WIDE>(key) & mask;
     for (;;) {
-        unsigned long long old = tkeys[h];
-        if (old == 0ull) old = atomicCAS(&tkeys[h], 0ull, key);
-        if (old == 0ull || old == key) {
+        if (slot_claim<WIDE>(tkeys, tkb, h, key)) {
             atomicAdd(&tcnt[h], c);
             return;
         }
@@ -140,65 +178,72 @@ __device__ __forceinline__ void table_add(unsigned long long *__restrict__ tkeys
 constexpr int VOX_TILE = 4096;   // points per workgroup tile
 constexpr int VOX_LDS = 1024;    // LDS aggregation slots
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void voxel_count_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ z, int64_t stride, int64_t n,
                                                           float voxel, const VoxelFrame *__restrict__ vfp,
-                                                          unsigned long long *__restrict__ tkeys,
+                                                          unsigned long long *__restrict__ tkeys, unsigned *__restrict__ tkb,
                                                           unsigned *__restrict__ tcnt, unsigned tmask)
 {
     __shared__ unsigned long long lkeys[VOX_LDS];
+    __shared__ unsigned lkb[WIDE ? VOX_LDS : 1];
     __shared__ unsigned lcnt[VOX_LDS];
     const VoxelFrame f = *vfp;
     if (!f.ok) return;
     const int64_t ntiles = (n + VOX_TILE - 1) / VOX_TILE;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        for (int i = threadIdx.x; i < VOX_LDS; i += 256) { lkeys[i] = 0ull; lcnt[i] = 0u; }
+        for (int i = threadIdx.x; i < VOX_LDS; i += 256) {
+            lkeys[i] = 0ull;
+            lcnt[i] = 0u;
+            if (WIDE) lkb[i] = 0u;
+        }
         __syncthreads();
         for (int j = threadIdx.x; j < VOX_TILE; j += 256) {
             int64_t i = t * VOX_TILE + j;
             if (i >= n) break;
-            unsigned long long key = pack_key(f, voxel_key(x[i * stride], voxel), voxel_key(y[i * stride], voxel),
-                                              voxel_key(z[i * stride], voxel));
-            unsigned h = hash_key(key) & (VOX_LDS - 1);
+            const VKey key = pack_key<WIDE>(f, voxel_key(x[i * stride], voxel), voxel_key(y[i * stride], voxel),
+                                            voxel_key(z[i * stride], voxel));
+            unsigned h = hash_vkey<WIDE>(key) & (VOX_LDS - 1);
             bool done = false;
             for (int probe = 0; probe < 8 && !done; ++probe) {
-                unsigned long long old = lkeys[h];
-                if (old == 0ull) old = atomicCAS(&lkeys[h], 0ull, key);
-                if (old == 0ull || old == key) {
+                if (slot_claim<WIDE>(lkeys, lkb, h, key)) {
                     atomicAdd(&lcnt[h], 1u);
                     done = true;
                 } else {
                     h = (h + 1) & (VOX_LDS - 1);
                 }
             }
-            if (!done) table_add(tkeys, tcnt, tmask, key, 1u);  // LDS table crowded: straight to HBM
+            if (!done) table_add<WIDE>(tkeys, tkb, tcnt, tmask, key, 1u);  // LDS table crowded: straight to HBM
         }
         __syncthreads();
         for (int i = threadIdx.x; i < VOX_LDS; i += 256) {
             unsigned c = lcnt[i];
-            if (c) table_add(tkeys, tcnt, tmask, lkeys[i], c);
+            // (a wide slot whose second word was never written cannot have a count)
+            if (c) table_add<WIDE>(tkeys, tkb, tcnt, tmask, VKey{lkeys[i], WIDE ? lkb[i] : 0u}, c);
         }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void voxel_collect_kernel(const unsigned long long *__restrict__ tkeys,
+                                                            const unsigned *__restrict__ tkb /* null: narrow */,
                                                             const unsigned *__restrict__ tcnt, unsigned tsize,
                                                             unsigned min_points, unsigned dense_cap,
                                                             unsigned long long *__restrict__ out_keys,
-                                                            unsigned *__restrict__ out_cnt,
+                                                            unsigned *__restrict__ out_kb, unsigned *__restrict__ out_cnt,
                                                             unsigned *__restrict__ counters /* [0]=unique [1]=dense */)
 {
     unsigned uniq = 0;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) {
         unsigned long long k = tkeys[i];
-        if (k == 0ull) continue;
-        ++uniq;
         unsigned c = tcnt[i];
+        if (k == 0ull || c == 0u) continue;   // c == 0: a wide slot that was claimed but never completed
+        ++uniq;
         if (c >= min_points) {
             unsigned slot = atomicAdd(&counters[1], 1u);
             if (slot < dense_cap) {
                 out_keys[slot] = k;
+                if (tkb) out_kb[slot] = tkb[i];
                 out_cnt[slot] = c;
             }
         }
@@ -210,29 +255,41 @@ __global__ __launch_bounds__(256) void voxel_collect_kernel(const unsigned long 
 
 constexpr int KEPT_LDS = 4096;
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void voxel_mask_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                          const float *__restrict__ z, int64_t stride, int64_t n,
                                                          float voxel, const VoxelFrame *__restrict__ vfp,
-                                                         const unsigned long long *__restrict__ kept, int n_kept,
+                                                         const unsigned long long *__restrict__ kept,
+                                                         const unsigned *__restrict__ kept_b, int n_kept,
                                                          uint8_t *__restrict__ mask)
 {
     __shared__ unsigned long long lk[KEPT_LDS];
+    __shared__ unsigned lkb[WIDE ? KEPT_LDS : 1];
     const VoxelFrame f = *vfp;
     const bool in_lds = n_kept <= KEPT_LDS;
     if (in_lds) {
-        for (int i = threadIdx.x; i < n_kept; i += 256) lk[i] = kept[i];
+        for (int i = threadIdx.x; i < n_kept; i += 256) {
+            lk[i] = kept[i];
+            if (WIDE) lkb[i] = kept_b[i];
+        }
         __syncthreads();
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int kx = voxel_key(x[i * stride], voxel), ky = voxel_key(y[i * stride], voxel), kz = voxel_key(z[i * stride], voxel);
-        unsigned long long key = pack_key(f, kx, ky, kz);
-        int lo = 0, hi = n_kept;  // first index with kept[idx] >= key
+        const VKey key = pack_key<WIDE>(f, kx, ky, kz);
+        int lo = 0, hi = n_kept;  // first index with kept[idx] >= key, keys ordered by (a, b)
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
-            unsigned long long v = in_lds ? lk[mid] : kept[mid];
-            if (v < key) lo = mid + 1; else hi = mid;
+            const unsigned long long va = in_lds ? lk[mid] : kept[mid];
+            const unsigned vb = WIDE ? (in_lds ? lkb[mid] : kept_b[mid]) : 0u;
+            if (va < key.a || (va == key.a && vb < key.b)) lo = mid + 1; else hi = mid;
         }
-        bool hit = lo < n_kept && (in_lds ? lk[lo] : kept[lo]) == key;
+        bool hit = false;
+        if (lo < n_kept) {
+            const unsigned long long va = in_lds ? lk[lo] : kept[lo];
+            const unsigned vb = WIDE ? (in_lds ? lkb[lo] : kept_b[lo]) : 0u;
+            hit = va == key.a && vb == key.b;
+        }
         mask[i] = hit ? 1 : 0;
     }
 }
@@ -256,7 +313,7 @@ static int compute_frame(gsx_ctx *c, const float *x, const float *y, const float
     GSX_HIP(hipMemcpyAsync(host_vf, dev_vf, sizeof(VoxelFrame), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));
     if (!host_vf->ok)
-        GSX_FAIL("density: voxel key range does not fit 3 x 21 bits (extent / voxel_size too large) or coordinates are not finite");
+        GSX_FAIL("density: coordinates are not finite, or extent / voxel_size exceeds 1e9 voxels per axis");
     return 0;
 }
 
@@ -274,32 +331,41 @@ int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *
     GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
 
     // table size: power of two >= 2 x min(n, number of voxels in the frame)
+    const bool wide = hvf.ok == 2;
     double space = (double)hvf.dim[0] * hvf.dim[1] * hvf.dim[2];
     uint64_t need = (uint64_t)std::min<double>((double)n, space);
     uint64_t tsize = 1024;
     while (tsize < 2 * need) tsize <<= 1;
     if (tsize > (1ull << 31)) GSX_FAIL("density: too many points for the voxel table");
     const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
-    // layout in one buffer: keys[tsize] | cnt[tsize] | out_keys[cap] | out_cnt[cap] | counters[2]
+    // layout in one buffer: keys[tsize] | cnt[tsize] | kb[tsize] (wide) | out_keys[cap] | out_cnt[cap] | out_kb[cap] | counters[2]
     size_t off_cnt = sizeof(unsigned long long) * tsize;
-    size_t off_ok = off_cnt + sizeof(unsigned) * tsize;
+    size_t off_kb = off_cnt + sizeof(unsigned) * tsize;
+    size_t off_ok = off_kb + (wide ? sizeof(unsigned) * tsize : 0);
     off_ok = (off_ok + 15) & ~(size_t)15;
     size_t off_oc = off_ok + sizeof(unsigned long long) * cap;
-    size_t off_ctr = (off_oc + sizeof(unsigned) * cap + 15) & ~(size_t)15;
+    size_t off_ob = off_oc + sizeof(unsigned) * cap;
+    size_t off_ctr = (off_ob + sizeof(unsigned) * cap + 15) & ~(size_t)15;
     GSX_CHECK(c->scratch2.reserve(off_ctr + 16));
     char *base = c->scratch2.as<char>();
     unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(base);
     unsigned *tcnt = reinterpret_cast<unsigned *>(base + off_cnt);
+    unsigned *tkb = wide ? reinterpret_cast<unsigned *>(base + off_kb) : nullptr;
     unsigned long long *okeys = reinterpret_cast<unsigned long long *>(base + off_ok);
     unsigned *ocnt = reinterpret_cast<unsigned *>(base + off_oc);
+    unsigned *okb = reinterpret_cast<unsigned *>(base + off_ob);
     unsigned *ctr = reinterpret_cast<unsigned *>(base + off_ctr);
     GSX_HIP(hipMemsetAsync(base, 0, off_ok, c->stream));
     GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
-    hipLaunchKernelGGL(voxel_count_kernel, dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
-                       voxel, dvf, tkeys, tcnt, (unsigned)(tsize - 1));
+    if (wide)
+        hipLaunchKernelGGL((voxel_count_kernel<true>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
+                           voxel, dvf, tkeys, tkb, tcnt, (unsigned)(tsize - 1));
+    else
+        hipLaunchKernelGGL((voxel_count_kernel<false>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
+                           voxel, dvf, tkeys, tkb, tcnt, (unsigned)(tsize - 1));
     unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
-    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)tsize, 1024)), dim3(256), 0, c->stream, tkeys,
-                       tcnt, (unsigned)tsize, mp, (unsigned)cap, okeys, ocnt, ctr);
+    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)tsize, 1024)), dim3(256), 0, c->stream, tkeys, tkb,
+                       tcnt, (unsigned)tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
     GSX_HIP(hipGetLastError());
     unsigned hctr[2];
     GSX_HIP(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, c->stream));
@@ -309,20 +375,27 @@ int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *
         GSX_FAIL("density: %u dense voxels exceed dense_cap=%lld", hctr[1], (long long)dense_cap);
     const size_t m = hctr[1];
     std::vector<unsigned long long> hk(m);
-    std::vector<unsigned> hc(m);
+    std::vector<unsigned> hc(m), hb(m, 0u);
     if (m) {
         GSX_HIP(hipMemcpy(hk.data(), okeys, sizeof(unsigned long long) * m, hipMemcpyDeviceToHost));
         GSX_HIP(hipMemcpy(hc.data(), ocnt, sizeof(unsigned) * m, hipMemcpyDeviceToHost));
+        if (wide) GSX_HIP(hipMemcpy(hb.data(), okb, sizeof(unsigned) * m, hipMemcpyDeviceToHost));
     }
     // packed keys order like (x, y, z) tuples because kmin is subtracted per axis: sort = np.unique's row order
     std::vector<size_t> order(m);
     for (size_t i = 0; i < m; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] != hk[b] ? hk[a] < hk[b] : hb[a] < hb[b]; });
     for (size_t i = 0; i < m; ++i) {
         unsigned long long k = hk[order[i]] - 1ull;
-        dense_keys_out[3 * i + 0] = (int64_t)(k >> 42) + hvf.kmin[0];
-        dense_keys_out[3 * i + 1] = (int64_t)((k >> 21) & 0x1fffff) + hvf.kmin[1];
-        dense_keys_out[3 * i + 2] = (int64_t)(k & 0x1fffff) + hvf.kmin[2];
+        if (wide) {
+            dense_keys_out[3 * i + 0] = (int64_t)(k >> 32) + hvf.kmin[0];
+            dense_keys_out[3 * i + 1] = (int64_t)(k & 0xffffffffull) + hvf.kmin[1];
+            dense_keys_out[3 * i + 2] = (int64_t)(hb[order[i]] - 1u) + hvf.kmin[2];
+        } else {
+            dense_keys_out[3 * i + 0] = (int64_t)(k >> 42) + hvf.kmin[0];
+            dense_keys_out[3 * i + 1] = (int64_t)((k >> 21) & 0x1fffff) + hvf.kmin[1];
+            dense_keys_out[3 * i + 2] = (int64_t)(k & 0x1fffff) + hvf.kmin[2];
+        }
         dense_counts_out[i] = hc[order[i]];
     }
     *n_unique_out = hctr[0];
@@ -340,7 +413,8 @@ int density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z,
     VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
     VoxelFrame hvf;
     GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
-    std::vector<unsigned long long> packed;
+    const bool wide = hvf.ok == 2;
+    std::vector<std::pair<unsigned long long, unsigned>> packed;
     packed.reserve((size_t)n_kept);
     for (int64_t i = 0; i < n_kept; ++i) {
         int64_t r[3];
@@ -350,18 +424,36 @@ int density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z,
             inside &= r[a] >= 0 && r[a] < hvf.dim[a];
         }
         if (!inside) continue;  // a kept voxel outside the cloud's key range can match no point
-        packed.push_back((((unsigned long long)r[0] << 42) | ((unsigned long long)r[1] << 21) | (unsigned long long)r[2]) + 1ull);
+        if (wide)
+            packed.emplace_back((((unsigned long long)r[0] << 32) | (unsigned long long)r[1]) + 1ull, (unsigned)r[2] + 1u);
+        else
+            packed.emplace_back((((unsigned long long)r[0] << 42) | ((unsigned long long)r[1] << 21) | (unsigned long long)r[2]) + 1ull, 0u);
     }
     std::sort(packed.begin(), packed.end());
     packed.erase(std::unique(packed.begin(), packed.end()), packed.end());
     const int nk = (int)packed.size();
-    GSX_CHECK(c->scratch2.reserve(sizeof(unsigned long long) * (size_t)std::max(nk, 1)));
-    if (nk)
-        GSX_HIP(hipMemcpyAsync(c->scratch2.p, packed.data(), sizeof(unsigned long long) * nk, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(voxel_mask_kernel, dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
-                       dvf, c->scratch2.as<unsigned long long>(), nk, mask_dev);
+    std::vector<unsigned long long> pa((size_t)std::max(nk, 1));
+    std::vector<unsigned> pb((size_t)std::max(nk, 1));
+    for (int i = 0; i < nk; ++i) {
+        pa[i] = packed[i].first;
+        pb[i] = packed[i].second;
+    }
+    const size_t off_b = sizeof(unsigned long long) * (size_t)std::max(nk, 1);
+    GSX_CHECK(c->scratch2.reserve(off_b + sizeof(unsigned) * (size_t)std::max(nk, 1)));
+    unsigned long long *dka = c->scratch2.as<unsigned long long>();
+    unsigned *dkb = reinterpret_cast<unsigned *>(c->scratch2.as<char>() + off_b);
+    if (nk) {
+        GSX_HIP(hipMemcpyAsync(dka, pa.data(), sizeof(unsigned long long) * nk, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(hipMemcpyAsync(dkb, pb.data(), sizeof(unsigned) * nk, hipMemcpyHostToDevice, c->stream));
+    }
+    if (wide)
+        hipLaunchKernelGGL((voxel_mask_kernel<true>), dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
+                           dvf, dka, dkb, nk, mask_dev);
+    else
+        hipLaunchKernelGGL((voxel_mask_kernel<false>), dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
+                           dvf, dka, dkb, nk, mask_dev);
     GSX_HIP(hipGetLastError());
-    GSX_HIP(hipStreamSynchronize(c->stream));  // `packed` (pageable host memory) must outlive the async copy
+    GSX_HIP(hipStreamSynchronize(c->stream));  // the host key vectors (pageable memory) must outlive the async copies
     GSX_CHECK(timing_end(c, GSX_T_DENSITY));
     return 0;
 }

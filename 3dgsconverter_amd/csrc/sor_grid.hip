@@ -1943,7 +1943,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     // slab mode (multi-GPU): every point is binned once, the halo [ref_only_from, n_ref) is flagged reference-only
     const bool slab = ref_only_from < n_ref;
     const bool all = (q_begin == 0 && q_count == n_ref) || slab;
-    adaptive = adaptive && all && !slab && nshares == 1 && level + 1 < KNN_MAX_LEVELS;
+    // (a share of the bricks -- the replicated multi-GPU exchange -- refines the deferred bricks of ITS share only)
+    adaptive = adaptive && all && !slab && level + 1 < KNN_MAX_LEVELS;
     const int bbox_blocks = std::min(grid_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
     // cell edge h is also the guaranteed search radius: the expected number of points within h is
     // 4.19 * m, and a query falls back to knn_ring when fewer than k+1 are.  m = 0.47 (k+1) puts

@@ -52,6 +52,13 @@ class HipCompute:
         self._lib = _lib
         self.ctx = _lib.Context(device_index)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.adaptive = False
+
+    def set_adaptive(self, on: bool):
+        """adaptive KNN grid for the calls below: exact and fast on clouds with far floaters -- what the
+        replicated exchange is the fallback for -- at the price of one host synchronisation per call"""
+        self.adaptive = bool(on)
+        self.ctx.set_param("adaptive", 1 if on else 0)
 
     def check(self):
         """synchronise and raise GsxError if the asynchronous KNN calls met non-finite coordinates (their outputs were

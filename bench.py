@@ -147,6 +147,7 @@ def main():
                     return _SlabRes(r)
                 except gslab.SlabUncertain as e:   # raised on every rank together (the count is all-reduced)
                     exchange["path"] = "replicated (slab certificate failed: %s)" % e
+                    compute.set_adaptive(True)     # the clouds that get here are the ones the adaptive grid exists for
             return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
 
         for _ in range(warmup):
