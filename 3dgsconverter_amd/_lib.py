@@ -59,6 +59,7 @@ SIGNATURES = {
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
+    "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_knn_share_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
@@ -370,3 +371,89 @@ class Context:
 
     def sor_mask(self, mean_dists: int, n: int, threshold_ptr: int, mask_out: int):
         check(self.lib.gsx_sor_mask_dev(self.handle, mean_dists, n, threshold_ptr, mask_out), "gsx_sor_mask_dev")
+
+
+class DeviceChain:
+    """Coordinates resident in HBM across consecutive filters (device half).
+
+    The reference ends every filter with ``self.data = vertices[mask]`` on the host table (data_processor.py:114,149)
+    and re-gathers ``coords`` at the start of the next one (:38,139).  Here the (n,3) rows are uploaded once, every
+    filter leaves its mask in HBM, ``gsx_compact_rows_dev`` compacts the rows there, and the composed survivor list comes
+    back once -- the 248-byte host rows are compacted once, after the last filter."""
+
+    def __init__(self, xyz_rows: np.ndarray, device: int = 0):
+        a = np.ascontiguousarray(xyz_rows, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] != 3:
+            raise ValueError("Requires 3D data")
+        self.ctx = Context(device)
+        self.ctx.set_param("adaptive", 1)   # every step below synchronises anyway
+        self.n0 = self.n = int(a.shape[0])
+        self.rows = self.ctx.alloc(max(a.nbytes, 16)).upload(a)
+        self.spare = self.ctx.alloc(max(a.nbytes, 16))
+        self.orig = None                    # None = identity
+        self.orig_spare = None
+        self.mask = self.ctx.alloc(self.n0 + 16)
+
+    def _xyz(self):
+        p = self.rows.ptr
+        return p, p + 4, p + 8, 3
+
+    def density_voxels(self, voxel_size: float, min_points: int):
+        n = self.n
+        dense_cap = int(min(n, n // max(int(min_points), 1) + 1))
+        keys = np.empty((max(dense_cap, 1), 3), dtype=np.int64)
+        counts = np.empty(max(dense_cap, 1), dtype=np.int64)
+        nu, nd = C.c_int64(), C.c_int64()
+        x, y, z, st = self._xyz()
+        check(self.ctx.lib.gsx_density_voxels_dev(self.ctx.handle, x, y, z, st, n, float(voxel_size), int(min_points), dense_cap,
+                                                  C.byref(nu), C.byref(nd), keys.ctypes.data, counts.ctypes.data), "gsx_density_voxels_dev")
+        m = int(nd.value)
+        return {"n_unique": int(nu.value), "dense_keys": keys[:m].copy(), "dense_counts": counts[:m].copy()}
+
+    def _compact(self) -> int:
+        out = self.orig_spare if self.orig_spare is not None else self.ctx.alloc(4 * self.n0 + 16)
+        n_out = C.c_int64()
+        check(self.ctx.lib.gsx_compact_rows_dev(self.ctx.handle, self.rows.ptr, self.orig.ptr if self.orig is not None else None,
+                                                self.mask.ptr, self.n, self.spare.ptr, out.ptr, C.byref(n_out)),
+              "gsx_compact_rows_dev")
+        self.rows, self.spare = self.spare, self.rows
+        self.orig, self.orig_spare = out, self.orig   # the previous list (None the first time) becomes the spare
+        self.n = int(n_out.value)
+        return self.n
+
+    def density_keep(self, voxel_size: float, kept_keys: np.ndarray) -> int:
+        kk = np.ascontiguousarray(kept_keys, dtype=np.int64).reshape(-1, 3)
+        x, y, z, st = self._xyz()
+        check(self.ctx.lib.gsx_density_mask_dev(self.ctx.handle, x, y, z, st, self.n, float(voxel_size), kk.ctypes.data, len(kk),
+                                                self.mask.ptr), "gsx_density_mask_dev")
+        return self._compact()
+
+    def keep_none(self):
+        self.n = 0
+
+    def sor_keep(self, k: int, threshold_factor: float):
+        n = self.n
+        md = self.ctx.alloc(4 * n + 16)
+        st = self.ctx.alloc(16)
+        x, y, z, stride = self._xyz()
+        self.ctx.sor_knn(x, y, z, stride, n, 0, n, int(k), md.ptr)
+        self.ctx.sor_stats(md.ptr, n, float(threshold_factor), st.ptr)
+        self.ctx.sor_mask(md.ptr, n, st.ptr + 8, self.mask.ptr)
+        self.ctx.check()
+        stats = st.download(np.float32, 3)
+        md.free()
+        st.free()
+        kept = self._compact()
+        return {"mean": stats[0], "std": stats[1], "threshold": stats[2], "kept": kept}
+
+    def survivors(self) -> np.ndarray:
+        """indices (ascending) of the surviving rows in the table the chain started from"""
+        if self.orig is None:
+            return np.arange(self.n0, dtype=np.uint32)
+        return self.orig.download(np.uint32, self.n) if self.n else np.zeros(0, np.uint32)
+
+    def close(self):
+        for b in (self.rows, self.spare, self.orig, self.orig_spare, self.mask):
+            if b is not None:
+                b.free()
+        self.ctx.close()

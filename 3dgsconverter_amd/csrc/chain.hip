@@ -1,0 +1,114 @@
+// chain.hip -- device-resident filter chain: stable compaction of the xyz rows between filters.
+//
+// The reference applies its filters one after the other on the host table (converter.py:196-236: bbox, alpha, density,
+// SOR), each ending in `self.data = vertices[mask]` (data_processor.py:114,149).  Keeping the coordinates in HBM
+// across density -> SOR (BASELINE.json configs[2]) removes the second gather + upload and lets the host compact its
+// 248-byte rows ONCE, by the composed survivor list: SURVEY.md 8(f) rank 1, device half.
+//   rows_out / orig_out = the rows with mask != 0, order kept; orig = index into the table the chain started from
+#include "gsx_common.h"
+
+namespace gsx {
+
+constexpr int CMP_TILE = 2048;
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const uint8_t *__restrict__ mask, int64_t n, unsigned *__restrict__ tile_cnt)
+{
+    __shared__ unsigned s[4];
+    const int64_t base = (int64_t)blockIdx.x * CMP_TILE;
+    unsigned c = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        c += (i < n && mask[i]) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of the tile counts in place (one workgroup); total -> *total_out
+__global__ __launch_bounds__(1024) void compact_scan_kernel(unsigned *__restrict__ tile_cnt, int ntiles, unsigned *__restrict__ total_out)
+{
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b = 0; b < ntiles; b += 1024) {
+        const int i = b + threadIdx.x;
+        const unsigned v = i < ntiles ? tile_cnt[i] : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off);
+            if ((int)(threadIdx.x & 63) >= off) inc += o;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned pre = s_carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s_w[w];
+        if (i < ntiles) tile_cnt[i] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = pre + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(256) void compact_write_kernel(const float *__restrict__ rows, const unsigned *__restrict__ orig,
+                                                            const uint8_t *__restrict__ mask, int64_t n,
+                                                            const unsigned *__restrict__ tile_off, float *__restrict__ rows_out,
+                                                            unsigned *__restrict__ orig_out)
+{
+    __shared__ unsigned s_w[4];
+    const int64_t base = (int64_t)blockIdx.x * CMP_TILE;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned run = tile_off[blockIdx.x];
+    // element order inside the tile: u-major (u * 256 + thread), so the output keeps the input order
+    for (int u = 0; u < 8; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        const bool keep = i < n && mask[i];
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_w[wv] = (unsigned)__builtin_popcountll(bal);
+        __syncthreads();
+        unsigned pos = run + (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) pos += s_w[w];
+        if (keep) {
+            rows_out[3 * (size_t)pos + 0] = rows[3 * i + 0];
+            rows_out[3 * (size_t)pos + 1] = rows[3 * i + 1];
+            rows_out[3 * (size_t)pos + 2] = rows[3 * i + 2];
+            orig_out[pos] = orig ? orig[i] : (unsigned)i;
+        }
+        run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" int gsx_compact_rows_dev(gsx_ctx *c, const float *rows_dev, const uint32_t *orig_dev, const uint8_t *mask_dev, int64_t n,
+                                    float *rows_out_dev, uint32_t *orig_out_dev, int64_t *n_out)
+{
+    if (!c || !rows_dev || !mask_dev || !rows_out_dev || !orig_out_dev || !n_out) GSX_FAIL("gsx_compact_rows_dev: null argument");
+    if (n < 0 || n >= (1LL << 32)) GSX_FAIL("gsx_compact_rows_dev: n out of range");
+    GSX_HIP(hipSetDevice(c->device));
+    *n_out = 0;
+    if (n == 0) return 0;
+    const int ntiles = div_up(n, CMP_TILE);
+    GSX_CHECK(c->statspart.reserve(sizeof(unsigned) * ((size_t)ntiles + 4)));
+    unsigned *tiles = c->statspart.as<unsigned>();
+    unsigned *total = tiles + ntiles;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(ntiles), dim3(256), 0, c->stream, mask_dev, n, tiles);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, c->stream, tiles, ntiles, total);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(ntiles), dim3(256), 0, c->stream, rows_dev, orig_dev, mask_dev, n, tiles, rows_out_dev,
+                       orig_out_dev);
+    GSX_HIP(hipGetLastError());
+    unsigned h = 0;
+    GSX_HIP(hipMemcpyAsync(&h, total, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    *n_out = h;
+    return 0;
+}

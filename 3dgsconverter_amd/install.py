@@ -2,7 +2,8 @@
 
 ``install()`` rebinds the three names the reference's orchestrator and SOG writer resolve
 at call time:
-    gsconverter.converter.DataProcessor            (converter.py:10 -> used at :150)
+    gsconverter.converter.DataProcessor            (converter.py:10 -> used at :150; bound to ChainedDataProcessor,
+                                                    which keeps the coordinates in HBM across density -> SOR)
     gsconverter.processing.DataProcessor / gsconverter.processing.data_processor.DataProcessor
     gsconverter.formats.sog.gpu_ops                (sog.py:11 -> used at :402,443,524,544)
     gsconverter.processing.gpu_ops                 (data_processor.py:142 imports it lazily)
@@ -18,7 +19,8 @@ _saved = {}
 
 def install():
     from . import processing
-    from .processing import gpu_ops, DataProcessor
+    from .processing import gpu_ops
+    from .processing.data_processor import ChainedDataProcessor as DataProcessor   # lazy: coordinates stay in HBM across filters
     import gsconverter.processing as rp  # type: ignore  (raises ImportError if the reference is absent)
     import gsconverter.processing.data_processor as rdp  # type: ignore
     from .processing import data_processor as mine

@@ -61,18 +61,75 @@ def _xyz_rows(vertices):
 
 
 class DataProcessor:
-    def __init__(self, data):
-        self.data = data
+    """Drop-in for the reference's class (module docstring).  ``lazy=True`` (what ``install()`` gives the reference's orchestrator, which ignores the filters' return values,
+    converter.py:196-236): consecutive density / SOR filters keep the coordinates in HBM (``_lib.DeviceChain``) and the
+    host table is compacted ONCE, when ``.data`` is read -- SURVEY.md 8(f) rank 1.  The filter methods then return
+    ``None``.  Default (eager): every method updates and returns ``self.data`` like the reference."""
+
+    lazy_default = False
+
+    def __init__(self, data, lazy=None):
+        self._data = data
+        self._chain = None          # _lib.DeviceChain over the rows of self._data, or None
+        self.lazy = DataProcessor.lazy_default if lazy is None else bool(lazy)
+
+    @property
+    def data(self):
+        self._materialize()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._drop_chain()
+        self._data = value
+
+    def _drop_chain(self):
+        if self._chain is not None:
+            self._chain.close()
+            self._chain = None
+
+    def _materialize(self):
+        """apply the composed survivor list of the device chain to the host table (one threaded compaction)"""
+        if self._chain is None:
+            return
+        ch = self._chain
+        self._chain = None
+        try:
+            if ch.n != ch.n0:
+                mask = np.zeros(ch.n0, dtype=bool)
+                mask[ch.survivors()] = True
+                self._data = _lib.host_compact_rows(self._data, mask)
+        finally:
+            ch.close()
+
+    def _chain_for(self, vertices):
+        if self._chain is None:
+            self._chain = _lib.DeviceChain(_xyz_rows(vertices))
+        return self._chain
+
+    def __len__(self):   # rows currently surviving, without materialising
+        return self._chain.n if self._chain is not None else len(self._data)
 
     # ------------------------------------------------------------------ SOR
     def remove_flyers(self, k=25, threshold_factor=10.5, chunk_size=50000, intensity=None):
         debug_print("[DEBUG] Executing 'remove_flyers' function...")
-        if not isinstance(self.data, np.ndarray):
+        if not isinstance(self._data, np.ndarray):
             raise TypeError("self.data must be a numpy structured array.")
         if intensity is not None:
             k, threshold_factor = sor_params_from_intensity(intensity)
         debug_print(f"SOR Filter (Remove Flyers) Params: K={k}, Sigma={threshold_factor:.2f}")
 
+        if self.lazy and isinstance(self._data, np.ndarray) and len(self) > 0:
+            if not 1 <= int(k) <= MAX_SOR_K:
+                raise ValueError(f"SOR: k={k} is outside the supported range 1..{MAX_SOR_K} of the MI355X path "
+                                 f"(--sor_intensity maps to k = 10..50, the CLI default is 25)")
+            ch = self._chain_for(self._data)
+            num_points = ch.n
+            status_print("[SOR] Determining outliers on GPU (HIP gfx950, exact KNN, device-resident chain)...")
+            res = ch.sor_keep(int(k), float(threshold_factor))
+            self.last_sor = {"mean": res["mean"], "std": res["std"], "threshold": res["threshold"]}
+            status_print(f"After removing flyers (GPU), retained {res['kept']} out of {num_points} vertices.")
+            return None
         vertices = self.data
         num_points = len(vertices)
         if num_points == 0:
@@ -93,13 +150,15 @@ class DataProcessor:
     def apply_density_filter(self, voxel_size=1.0, threshold_percentage=0.32, sensitivity=None,
                              keep_multicluster=False):
         debug_print("[DEBUG] Executing 'apply_density_filter' function...")
-        if not isinstance(self.data, np.ndarray):
+        if not isinstance(self._data, np.ndarray):
             raise TypeError("self.data must be a numpy structured array.")
         if sensitivity is not None:
             voxel_size, threshold_percentage = density_params_from_sensitivity(sensitivity)
         debug_print(f"Density Filter Params: Voxel={voxel_size:.4f}, Thresh={threshold_percentage:.4f}%, "
                     f"MultiCluster={keep_multicluster}")
 
+        if self.lazy and len(self) > 0:
+            return self._density_lazy(voxel_size, threshold_percentage, keep_multicluster)
         vertices = self.data
         n = len(vertices)
         min_points = int(n * (threshold_percentage / 100.0))  # reference :48
@@ -125,6 +184,28 @@ class DataProcessor:
         status_print(f"Density Filter: Kept {kept_clusters} clusters (largest: {max_len} voxels).")
         status_print(f"After density filter, retained {len(self.data)} out of {len(vertices)} vertices.")
         return self.data
+
+    def _density_lazy(self, voxel_size, threshold_percentage, keep_multicluster):
+        """the same steps on the device-resident rows; the host table is untouched until ``.data`` is read"""
+        ch = self._chain_for(self._data)
+        n = ch.n
+        min_points = int(n * (threshold_percentage / 100.0))  # reference :48
+        occ = ch.density_voxels(float(voxel_size), min_points)
+        debug_print(f"[DEBUG] Found {occ['n_unique']} unique voxels.")
+        if len(occ["dense_keys"]) == 0:
+            status_print("Warning: Density filter removed all points.")
+            ch.keep_none()
+            return None
+        comps = _clusters.connected_clusters(map(tuple, occ["dense_keys"].tolist()))
+        kept, kept_clusters, max_len = _clusters.select_clusters(comps, keep_multicluster)
+        if not kept:
+            ch.keep_none()
+            return None
+        kept_keys = np.array(sorted(kept), dtype=np.int64).reshape(-1, 3)
+        left = ch.density_keep(float(voxel_size), kept_keys)
+        status_print(f"Density Filter: Kept {kept_clusters} clusters (largest: {max_len} voxels).")
+        status_print(f"After density filter, retained {left} out of {n} vertices.")
+        return None
 
     # ------------------------------------------------------------------ O(N) row filters (SURVEY.md 8(f) rank 4)
     # Same masks as the reference, computed by the same numpy expressions; only `self.data[mask]`
@@ -181,3 +262,11 @@ class DataProcessor:
             finally:
                 self.data = ref.data
         return forward
+
+
+class ChainedDataProcessor(DataProcessor):
+    """what ``install()`` binds to ``gsconverter.converter.DataProcessor``: the orchestrator ignores the filters' return
+    values (converter.py:196-236) and reads ``processor.data`` once at the end (:259), so the device-resident chain applies"""
+
+    def __init__(self, data):
+        super().__init__(data, lazy=True)

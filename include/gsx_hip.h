@@ -120,6 +120,15 @@ int gsx_host_gather_f32(const void *rows, int64_t row_bytes, int64_t n, const in
 int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *mask,
                           void *out, int64_t out_rows, int64_t *n_out);
 
+/*
+ * Device-resident filter chain (device half): stable compaction of (n,3) float32 rows by a device
+ * mask -- the device-side `vertices[mask]` of data_processor.py:114,149 for the coordinates only.  orig_dev (nullable =
+ * identity) / orig_out_dev carry the index into the table the chain started from, so that the host compacts its
+ * 248-byte rows once, after the last filter.  *n_out = survivors (one small synchronisation).
+ */
+int gsx_compact_rows_dev(gsx_ctx *ctx, const float *rows_dev, const uint32_t *orig_dev, const uint8_t *mask_dev, int64_t n,
+                         float *rows_out_dev, uint32_t *orig_out_dev, int64_t *n_out);
+
 /* ---- Statistical Outlier Removal --------------------------------------- */
 /*
  * KNN mean distance -- replaces data_processor.py:156-173 (cKDTree build + chunked

@@ -64,8 +64,44 @@ def dropin(gsx, monkeypatch):
         hits.append(("gsx_quantize_sorted_codebook", len(vals), len(cb)))
         return okm.quantize_to_codebook(np.asarray(vals, np.float32), np.asarray(cb, np.float32))
 
+    class FakeChain:
+        """_lib.DeviceChain (coordinates resident in HBM across filters) with the oracle as the device"""
+
+        def __init__(self, xyz_rows, device=0):
+            self.xyz = np.ascontiguousarray(xyz_rows, dtype=np.float32)
+            self.n0 = self.n = len(self.xyz)
+            self.idx = np.arange(self.n0)
+            hits.append(("DeviceChain", self.n0))
+
+        def density_voxels(self, voxel_size, min_points):
+            hits.append(("gsx_density_voxels_dev", self.n, float(voxel_size), int(min_points)))
+            return density_voxels(self.xyz, voxel_size, min_points)
+
+        def _keep(self, mask):
+            self.xyz, self.idx = self.xyz[mask], self.idx[mask]
+            self.n = len(self.idx)
+            return self.n
+
+        def density_keep(self, voxel_size, kept_keys):
+            hits.append(("gsx_density_mask_dev", self.n, len(kept_keys)))
+            return self._keep(density_mask(self.xyz, voxel_size, kept_keys))
+
+        def keep_none(self):
+            self._keep(np.zeros(self.n, bool))
+
+        def sor_keep(self, k, threshold_factor):
+            hits.append(("gsx_sor_knn_dev", self.n, int(k), float(threshold_factor)))
+            r = osor.sor(self.xyz, int(k), float(threshold_factor))
+            return {"mean": r["mean"], "std": r["std"], "threshold": r["threshold"], "kept": self._keep(r["mask"])}
+
+        def survivors(self):
+            return self.idx.astype(np.uint32)
+
+        def close(self):
+            pass
+
     for name, fn in (("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
-                     ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize)):
+                     ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain)):
         monkeypatch.setattr(lib, name, fn)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_HIP", True)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_TAICHI", True)
@@ -102,11 +138,13 @@ def _run(tmp_path, inp, tag, **kw):
 def test_converter_run_density_flag_goes_through_the_dropin(tmp_path, gsx, dropin):
     inp, _ = _write_input(tmp_path)
     import gsconverter.converter as conv
-    assert conv.DataProcessor is gsx.DataProcessor
+    assert issubclass(conv.DataProcessor, gsx.DataProcessor)
     got = _run(tmp_path, inp, "dropin", density_sensitivity=0.3)
-    assert [h[0] for h in dropin] == ["gsx_density_voxels", "gsx_density_mask"]
+    # install() binds the chained class: one upload, the filters' device entry points, one compaction at `.data`
+    assert [h[0] for h in dropin if h[0] not in ("gsx_density_voxels", "gsx_density_mask")] == \
+        ["DeviceChain", "gsx_density_voxels_dev", "gsx_density_mask_dev"]   # (the fake chain reuses the fake host entries)
     gsx.uninstall()
-    assert conv.DataProcessor is not gsx.DataProcessor
+    assert not issubclass(conv.DataProcessor, gsx.DataProcessor)
     want = _run(tmp_path, inp, "reference", density_sensitivity=0.3)
     assert 0 < len(want) < 6000
     assert got.equals(want)
@@ -115,9 +153,9 @@ def test_converter_run_density_flag_goes_through_the_dropin(tmp_path, gsx, dropi
 def test_converter_run_sor_flags_go_through_the_dropin(tmp_path, gsx, dropin):
     inp, _ = _write_input(tmp_path)
     got = _run(tmp_path, inp, "dropin", sor_k=12.0, sor_sigma=1.5)  # main.py parses --sor_k as float
-    assert dropin == [("gsx_sor_filter", 6000, 12, 1.5)]
+    assert dropin == [("DeviceChain", 6000), ("gsx_sor_knn_dev", 6000, 12, 1.5)]
     got_i = _run(tmp_path, inp, "dropin_i", sor_intensity=7)
-    assert dropin[1][:2] == ("gsx_sor_filter", 6000) and dropin[1][2] == int(10 + 6 * (40 / 9))
+    assert dropin[3][:2] == ("gsx_sor_knn_dev", 6000) and dropin[3][2] == int(10 + 6 * (40 / 9))
     gsx.uninstall()
     # the un-patched reference: mask computed (data_processor.py:180) but not applied (:181-182)
     ref_all = _run(tmp_path, inp, "reference", sor_k=12.0, sor_sigma=1.5)
@@ -128,6 +166,22 @@ def test_converter_run_sor_flags_go_through_the_dropin(tmp_path, gsx, dropin):
     assert got.reset_index(drop=True).equals(ref_all[cap["mask"]].reset_index(drop=True))
     cap_i = refload.reference_sor(xyz, 25, 10.5, intensity=7)
     assert got_i.reset_index(drop=True).equals(ref_all[cap_i["mask"]].reset_index(drop=True))
+
+
+def test_converter_run_density_then_sor_stays_on_the_device(tmp_path, gsx, dropin):
+    """BASELINE.json configs[2] through the reference's CLI path: --density_sensitivity + --sor_k/--sor_sigma.  ONE chain:
+    the second filter runs on the rows the first one left in HBM, the host table is compacted once."""
+    inp, _ = _write_input(tmp_path)
+    got = _run(tmp_path, inp, "dropin", density_sensitivity=0.3, sor_k=10.0, sor_sigma=1.0)
+    names = [h[0] for h in dropin]
+    assert names.count("DeviceChain") == 1 and names[-1] == "gsx_sor_knn_dev"
+    n_after_density = dropin[-1][1]
+    gsx.uninstall()
+    dens = _run(tmp_path, inp, "reference_density", density_sensitivity=0.3)
+    assert len(dens) == n_after_density
+    xyz = np.column_stack([dens["x"], dens["y"], dens["z"]]).astype(np.float32)
+    cap = refload.reference_sor(xyz, 10, 1.0)   # the reference's own SOR mask on its own density output (SURVEY F3)
+    assert got.reset_index(drop=True).equals(dens[cap["mask"]].reset_index(drop=True))
 
 
 def _decode(path):
