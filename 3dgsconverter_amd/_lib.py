@@ -83,6 +83,10 @@ SIGNATURES = {
     "gsx_density_mask": (_I, [_P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_kmeans_lloyd": (_I, [_P, _I64, _I, _I, _I, _P, _P, _P]),
     "gsx_quantize_sorted_codebook": (_I, [_P, _I64, _P, _I, _P]),
+    "gsx_lexsort3": (_I, [_P, _P, _P, _I64, _P]),
+    "gsx_lexsort3_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "gsx_sog_quats": (_I, [_P, _I64, _P]),
+    "gsx_sog_quats_dev": (_I, [_P, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
@@ -269,6 +273,29 @@ def quantize_sorted_codebook(vals: np.ndarray, codebook: np.ndarray) -> np.ndarr
     out = np.empty(vals.shape, dtype=np.uint8)
     check(lib.gsx_quantize_sorted_codebook(vals.ctypes.data, vals.size, cb.ctypes.data, len(cb), out.ctypes.data),
           "gsx_quantize_sorted_codebook")
+    return out
+
+
+def lexsort3(k0: np.ndarray, k1: np.ndarray, k2: np.ndarray) -> np.ndarray:
+    """np.lexsort((k0, k1, k2)) for float32 keys on the GPU (C ABI gsx_lexsort3) -> int64 indices"""
+    lib = require_hip()
+    cols = [np.ascontiguousarray(c, dtype=np.float32) for c in (k0, k1, k2)]
+    n = len(cols[0])
+    out = np.empty(n, dtype=np.uint32)
+    if n:
+        check(lib.gsx_lexsort3(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, n, out.ctypes.data), "gsx_lexsort3")
+    return out.astype(np.int64)
+
+
+def sog_quats(rot_rows: np.ndarray) -> np.ndarray:
+    """formats/sog.py:315-386 on the GPU (C ABI gsx_sog_quats): (n,4) float32 -> (n,4) uint8 (c0, c1, c2, 252 + argmax)"""
+    lib = require_hip()
+    q = np.ascontiguousarray(rot_rows, dtype=np.float32)
+    if q.ndim != 2 or q.shape[1] != 4:
+        raise ValueError("expected (n,4) quaternion rows")
+    out = np.empty((len(q), 4), dtype=np.uint8)
+    if len(q):
+        check(lib.gsx_sog_quats(q.ctypes.data, len(q), out.ctypes.data), "gsx_sog_quats")
     return out
 
 

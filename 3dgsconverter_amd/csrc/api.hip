@@ -549,4 +549,42 @@ int gsx_quantize_sorted_codebook(const float *vals, int64_t n, const float *code
     return 0;
 }
 
+// ------------------------------------------------------------------ SOG writer numeric core (host buffers)
+int gsx_lexsort3_dev(gsx_ctx *c, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n, uint32_t *perm_out_dev);
+int gsx_sog_quats_dev(gsx_ctx *c, const float *rot_rows_dev, int64_t n, uint8_t *out4_dev);
+
+int gsx_lexsort3(const float *k0, const float *k1, const float *k2, int64_t n, uint32_t *perm_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!k0 || !k1 || !k2 || !perm_out) GSX_FAIL("gsx_lexsort3: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * 3 * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve(sizeof(uint32_t) * (size_t)n));
+    float *base = c->scratch.as<float>();
+    const float *src[3] = {k0, k1, k2};
+    for (int a = 0; a < 3; ++a) GSX_HIP(hipMemcpyAsync(base + (size_t)a * n, src[a], sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_lexsort3_dev(c, base, base + n, base + 2 * (size_t)n, 1, n, c->scratch4.as<uint32_t>()));
+    GSX_HIP(hipMemcpyAsync(perm_out, c->scratch4.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_sog_quats(const float *rot_rows, int64_t n, uint8_t *out4)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!rot_rows || !out4) GSX_FAIL("gsx_sog_quats: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * 4 * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve(4 * (size_t)n));
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, rot_rows, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_sog_quats_dev(c, c->scratch.as<float>(), n, c->scratch4.as<uint8_t>()));
+    GSX_HIP(hipMemcpyAsync(out4, c->scratch4.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 }  // extern "C"

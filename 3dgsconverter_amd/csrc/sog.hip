@@ -1,0 +1,132 @@
+// sog.hip -- numeric core of the SOG writer next to the K-Means codebooks.
+//
+//   formats/sog.py:264      indices = np.lexsort((z, y, x))        -> gsx_lexsort3: three stable radix-sort passes
+//   formats/sog.py:315-386  quaternion normalise + smallest-three  -> gsx_sog_quats: one elementwise pass, byte-exact
+//
+// NOT here, on purpose: the log-transformed positions (:279-309) and the sigmoid of the opacity (:457-459) go through
+// numpy's float32 log / exp, which are SIMD routines of up to 3 ulp error (measured: 16 % / 39 % of the values differ
+// from the correctly rounded result).  A device log/exp cannot reproduce them bit for bit, and one ulp flips the u16 / u8
+// texel in 3e-4 / 3e-6 of the splats -- so those two stay numpy on the host (they ARE the reference's arithmetic) and
+// the writer stays byte-identical.  HBM-bound: 16 B in, 4 B out per splat (quats); 3 x (8 B + 8 B) per splat (sort).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gsx_common.h"
+
+namespace gsx {
+
+// float32 -> uint32 whose unsigned order is numpy's sort order: -0.0 == +0.0, every NaN last
+__device__ __forceinline__ unsigned sort_key(float v)
+{
+    if (v != v) return 0xffffffffu;
+    if (v == 0.0f) v = 0.0f;  // -0.0 -> +0.0
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void lexsort_keys_kernel(const float *__restrict__ col, int64_t stride,
+                                                           const unsigned *__restrict__ perm /* null: identity */, int64_t n,
+                                                           unsigned *__restrict__ keys, unsigned *__restrict__ vals)
+{
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+        const unsigned i = perm ? perm[j] : (unsigned)j;
+        keys[j] = sort_key(col[(int64_t)i * stride]);
+        vals[j] = i;
+    }
+}
+
+// sog.py:315-386.  rot: (n,4) float32 rows (rot_0..rot_3); out: 4 bytes per splat (c0, c1, c2, 252 + max_idx)
+__global__ __launch_bounds__(256) void sog_quats_kernel(const float *__restrict__ rot, int64_t n, uchar4 *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 q4 = reinterpret_cast<const float4 *>(rot)[i];
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        // np.linalg.norm(q, axis=1): sqrt(add.reduce(q*q)) in float32, four elements summed left to right
+        float s = __fmul_rn(q[0], q[0]);
+        s = __fadd_rn(s, __fmul_rn(q[1], q[1]));
+        s = __fadd_rn(s, __fmul_rn(q[2], q[2]));
+        s = __fadd_rn(s, __fmul_rn(q[3], q[3]));
+        const float nrm = __fsqrt_rn(s);
+        int mi = 0;
+        float ma = -1.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            q[c] = __fdiv_rn(q[c], nrm);                // qn = q / norm
+            const float a = fabsf(q[c]);
+            if (a > ma) {                               // np.abs(qn).argmax(axis=1): first maximum
+                ma = a;
+                mi = c;
+            }
+        }
+        const float mv = q[mi];
+        const float sg = mv > 0.0f ? 1.0f : (mv < 0.0f ? -1.0f : 0.0f);   // np.sign(max_val)
+        unsigned char b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = __fmul_rn(q[c], sg);                                  // qn *= sign_flip
+            v = (float)((double)v * 1.4142135623730951);                    // qn *= np.sqrt(2.0): float64 scalar, cast back
+            float t = __fadd_rn(__fmul_rn(v, 0.5f), 0.5f);                  // quantize_vec: (v*0.5 + 0.5) * 255.0, float32
+            t = __fmul_rn(t, 255.0f);
+            t = fminf(fmaxf(t, 0.0f), 255.0f);                              // np.clip
+            b[c] = (unsigned char)t;                                        // astype(uint8): truncation
+        }
+        // the three components that are not the maximum, in index order
+        const int i0 = mi == 0 ? 1 : 0, i1 = mi <= 1 ? 2 : 1, i2 = mi == 3 ? 2 : 3;
+        out[i] = make_uchar4(b[i0], b[i1], b[i2], (unsigned char)(252 + mi));
+    }
+}
+
+static int lexsort3_dev(gsx_ctx *c, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n, uint32_t *perm_out)
+{
+    // buffers: keys A/B, vals A/B (4 x n x u32) + rocprim temporary storage
+    size_t temp_bytes = 0;
+    unsigned *nul = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, nul, nul, nul, nul, (size_t)n, 0, 32, c->stream) != hipSuccess)
+        GSX_FAIL("lexsort: rocprim size query failed");
+    const size_t col = sizeof(unsigned) * (size_t)n;
+    GSX_CHECK(c->scratch5.reserve(4 * col + temp_bytes + 256));
+    unsigned *ka = c->scratch5.as<unsigned>(), *kb = ka + n, *va = kb + n, *vb = va + n;
+    void *temp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(vb + n) + 255) & ~(uintptr_t)255);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    const float *cols[3] = {k0, k1, k2};   // least significant first, like np.lexsort's argument order
+    const unsigned *perm = nullptr;
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(lexsort_keys_kernel, dim3(blocks), dim3(256), 0, c->stream, cols[pass], stride, perm, n, ka, va);
+        unsigned *vo = pass == 2 ? perm_out : vb;
+        GSX_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, ka, kb, va, vo, (size_t)n, 0, 32, c->stream));   // stable
+        perm = vo;
+    }
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gsx
+
+using namespace gsx;
+
+extern "C" {
+
+int gsx_lexsort3_dev(gsx_ctx *c, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n, uint32_t *perm_out_dev)
+{
+    if (!c || !k0 || !k1 || !k2 || !perm_out_dev) GSX_FAIL("gsx_lexsort3_dev: null argument");
+    if (n < 0 || n >= (1LL << 32) || stride < 1) GSX_FAIL("gsx_lexsort3_dev: bad size");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    return lexsort3_dev(c, k0, k1, k2, stride, n, perm_out_dev);
+}
+
+int gsx_sog_quats_dev(gsx_ctx *c, const float *rot_rows_dev, int64_t n, uint8_t *out4_dev)
+{
+    if (!c || !rot_rows_dev || !out4_dev) GSX_FAIL("gsx_sog_quats_dev: null argument");
+    if ((reinterpret_cast<uintptr_t>(rot_rows_dev) & 15) || (reinterpret_cast<uintptr_t>(out4_dev) & 3))
+        GSX_FAIL("gsx_sog_quats_dev: rows must be 16-byte and output 4-byte aligned");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(sog_quats_kernel, dim3(blocks), dim3(256), 0, c->stream, rot_rows_dev, n, reinterpret_cast<uchar4 *>(out4_dev));
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

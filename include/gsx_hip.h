@@ -268,6 +268,17 @@ int gsx_kmeans_lloyd_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, 
 int gsx_quantize_sorted_codebook_dev(gsx_ctx *ctx, const float *vals_dev, int64_t n,
                                      const float *codebook_dev, int kcb, uint8_t *idx_out_dev);
 
+/* ---- SOG writer numeric core next to the codebooks ---- */
+/* perm = np.lexsort((k0, k1, k2)): k2 is the primary key -- formats/sog.py:264 lexsort((z, y, x)).  Three stable radix
+ * passes; -0.0 == +0.0 and NaNs last, like numpy.  perm_out: n uint32 */
+int gsx_lexsort3(const float *k0, const float *k1, const float *k2, int64_t n, uint32_t *perm_out);
+int gsx_lexsort3_dev(gsx_ctx *ctx, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n,
+                     uint32_t *perm_out_dev);
+/* formats/sog.py:315-386: normalise the (n,4) float32 quaternion rows, flip to the positive hemisphere of the largest
+ * component, scale by sqrt(2), quantise the three others to bytes; out4[i] = (c0, c1, c2, 252 + argmax), byte-exact */
+int gsx_sog_quats(const float *rot_rows, int64_t n, uint8_t *out4);
+int gsx_sog_quats_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, uint8_t *out4_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,3 +97,22 @@ def test_sog_call_site_contract(kref, name):
         for ch, col in enumerate(cols):
             got = okm.quantize_to_codebook(ds[col], cb)
             np.testing.assert_array_equal(got[visible], arr[name + "__" + tex][visible, ch])
+
+
+@pytest.mark.parametrize("name", ["sog_20k_l2", "sog_3k_l8"])
+def test_sog_numeric_core_restatement_matches_the_reference_bundle(kref, name):
+    """oracle/sog.py (sog.py:264-386,457-459 restated) against the textures the reference wrote"""
+    import hashlib
+    from oracle import sog as osog
+    cases, arr = kref
+    case = cases["sog"][name]
+    data = datasets.sog_scene(case["n"], case["scene_seed"])
+    order = osog.order(data)
+    assert hashlib.sha256(order.tobytes()).digest() == arr[name + "__order_sha"].tobytes()
+    ds = data[order]
+    lo, hi, mins, maxs = osog.positions(ds)
+    np.testing.assert_array_equal(lo, arr[name + "__means_l"][:, :3])
+    np.testing.assert_array_equal(hi, arr[name + "__means_u"][:, :3])
+    assert [float(m) for m in mins] == case["meta"]["means"]["mins"] and [float(m) for m in maxs] == case["meta"]["means"]["maxs"]
+    np.testing.assert_array_equal(osog.quats(ds), arr[name + "__quats"])
+    np.testing.assert_array_equal(osog.opacity_u8(ds), arr[name + "__sh0"][:, 3])
