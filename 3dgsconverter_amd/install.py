@@ -17,7 +17,10 @@ import sys
 _saved = {}
 
 
-def install():
+def install(sog_writer: bool = True):
+    """sog_writer: also rebind ``gsconverter.formats.sog.SogFormat.write`` to formats/sog_writer.py:write_sog (spatial
+    sort, quaternion packing, codebook quantiser and SH palette on the GPU; identical bytes where the reference is
+    deterministic)."""
     from . import processing
     from .processing import gpu_ops
     from .processing.data_processor import ChainedDataProcessor as DataProcessor   # lazy: coordinates stay in HBM across filters
@@ -37,6 +40,14 @@ def install():
     for mod, attr, val in targets:
         _saved.setdefault((mod.__name__, attr), getattr(mod, attr, None))
         setattr(mod, attr, val)
+    if sog_writer:
+        try:
+            sogmod = importlib.import_module("gsconverter.formats.sog")
+            from .formats.sog_writer import write_sog
+            _saved.setdefault(("sogformat", "write"), sogmod.SogFormat.write)
+            sogmod.SogFormat.write = lambda self, data, path, **kw: write_sog(data, path, **kw)
+        except Exception:
+            pass  # pillow missing: the reference's own writer is not importable either
     _saved.setdefault(("sys.modules", "gsconverter.processing.gpu_ops"),
                       sys.modules.get("gsconverter.processing.gpu_ops"))
     sys.modules["gsconverter.processing.gpu_ops"] = gpu_ops
@@ -45,6 +56,9 @@ def install():
 
 def uninstall():
     for (modname, attr), val in list(_saved.items()):
+        if modname == "sogformat":
+            importlib.import_module("gsconverter.formats.sog").SogFormat.write = val
+            continue
         if modname == "sys.modules":
             if val is None:
                 sys.modules.pop(attr, None)

@@ -100,8 +100,21 @@ def dropin(gsx, monkeypatch):
         def close(self):
             pass
 
+    def lexsort3(k0, k1, k2):
+        hits.append(("gsx_lexsort3", len(k0)))
+        return np.lexsort((k0, k1, k2))
+
+    def sog_quats(rows):
+        from oracle import sog as osog
+        hits.append(("gsx_sog_quats", len(rows)))
+        ds = np.zeros(len(rows), dtype=[("rot_%d" % c, "f4") for c in range(4)])
+        for c in range(4):
+            ds["rot_%d" % c] = rows[:, c]
+        return osog.quats(ds)
+
     for name, fn in (("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
-                     ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain)):
+                     ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
+                     ("lexsort3", lexsort3), ("sog_quats", sog_quats)):
         monkeypatch.setattr(lib, name, fn)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_HIP", True)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_TAICHI", True)
@@ -193,7 +206,10 @@ def _decode(path):
     return meta, tex
 
 
-def test_sog_writer_kmeans_goes_through_the_dropin(tmp_path, gsx, dropin):
+def test_sog_writer_goes_through_the_dropin(tmp_path, gsx, dropin):
+    """install() rebinds SogFormat.write to formats/sog_writer.py:write_sog: spatial sort, quaternion packing, codebooks,
+    quantiser and SH palette reach the product's entry points; every texture that does not depend on the random K-Means
+    init is byte-identical to what the un-patched reference writes from the same table"""
     refload.load()
     import gsconverter.formats.sog as sogmod
     assert sogmod.gpu_ops is gsx.gpu_ops
@@ -202,6 +218,8 @@ def test_sog_writer_kmeans_goes_through_the_dropin(tmp_path, gsx, dropin):
     a = str(tmp_path / "dropin.sog")
     np.random.seed(1)
     sogmod.SogFormat().write(data, a, compression_level=2)
+    names = [h[0] for h in dropin]
+    assert names[0] == "gsx_lexsort3" and names[1] == "gsx_sog_quats"
     plan = okm.sog_sh_plan(n, 2)
     km = [h for h in dropin if h[0] == "gsx_kmeans_lloyd"]
     # two scalar codebooks (sog.py:402,443) + one call per SH chunk (:544); the K >= N shortcut never reaches the device
@@ -209,18 +227,23 @@ def test_sog_writer_kmeans_goes_through_the_dropin(tmp_path, gsx, dropin):
     sizes = [min(plan["chunk_size"], n - i * plan["chunk_size"]) for i in range(plan["num_chunks"])]
     want_chunks = [((s, 45), min(s, plan["k_per_chunk"]), 10) for s in sizes if min(s, plan["k_per_chunk"]) < s]
     assert [h[1:] for h in km[2:]] == want_chunks
+    # the quantiser is reachable now: 3 scale columns + 3 colour columns + the palette's centroid scalars
+    qz = [h for h in dropin if h[0] == "gsx_quantize_sorted_codebook"]
+    assert [h[1] for h in qz[:6]] == [n] * 6 and len(qz) == 7 and qz[6][1] == 45 * sum(min(s, plan["k_per_chunk"]) for s in sizes)
     gsx.uninstall()
     b = str(tmp_path / "reference.sog")
     np.random.seed(1)
     sogmod.SogFormat().write(data, b, compression_level=2)
     ma, ta = _decode(a)
     mb, tb = _decode(b)
-    # textures that do not involve the random K-Means init: identical to the un-patched reference
     for name in ("means_l", "means_u", "quats"):
         np.testing.assert_array_equal(ta[name], tb[name])
     np.testing.assert_array_equal(ta["sh0"][:, 3], tb["sh0"][:, 3])  # opacity byte
     assert ma["means"] == mb["means"] and ma["count"] == mb["count"] == n
     assert ma["shN"]["count"] == mb["shN"]["count"] and ma["shN"]["bands"] == 3
+    assert {k: v["files"] for k, v in ma.items() if isinstance(v, dict) and "files" in v} == \
+           {k: v["files"] for k, v in mb.items() if isinstance(v, dict) and "files" in v}
+    assert ta["shN_centroids"].shape == tb["shN_centroids"].shape and ta["shN_labels"].shape == tb["shN_labels"].shape
     # the clustered textures are consistent with the codebooks written next to them (sog.py:408-423,447-449)
     ds = data[np.lexsort((data["z"], data["y"], data["x"]))]
     for tex, cols in (("scales", ["scale_0", "scale_1", "scale_2"]), ("sh0", ["f_dc_0", "f_dc_1", "f_dc_2"])):
@@ -228,6 +251,9 @@ def test_sog_writer_kmeans_goes_through_the_dropin(tmp_path, gsx, dropin):
         vis = ta[tex][:n, 3] != 0
         for ch, col in enumerate(cols):
             np.testing.assert_array_equal(okm.quantize_to_codebook(ds[col], cb)[vis], ta[tex][:n, ch][vis])
+    # every splat's palette label points at a valid centroid; labels of a chunk stay inside the chunk's slice of the palette
+    lab = ta["shN_labels"][:n, 0].astype(np.int64) + 256 * ta["shN_labels"][:n, 1].astype(np.int64)
+    assert lab.max() < ma["shN"]["count"]
     # (codebook QUALITY is not compared here: the un-patched run used the reference's sklearn fallback, whose
     # k-means++ init beats the random-sample init of the reference's own GPU path on 1-D data -- see
     # tests/test_kmeans_gpu.py::test_scalar_codebook_quality_is_the_taichi_paths_not_sklearns)

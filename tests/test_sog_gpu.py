@@ -63,3 +63,41 @@ def test_quats_random_and_axis_aligned(gsx):
     with np.errstate(all="ignore"):
         want = osog.quats(ds)
     np.testing.assert_array_equal(lib.sog_quats(q), want)
+
+
+def test_write_sog_on_the_device_reproduces_the_reference_bundle(gsx, kref, tmp_path):
+    """formats/sog_writer.py:write_sog with the real library: the textures that do not depend on the random K-Means init
+    are byte-identical to the bundle the reference wrote from the same table (committed fixture); the clustered ones are
+    consistent with the codebooks stored next to them"""
+    import importlib
+    import io
+    import zipfile
+    from PIL import Image
+    from oracle import kmeans as okm
+    cases, arr = kref
+    name = "sog_20k_l2"
+    case = cases["sog"][name]
+    n = case["n"]
+    data = datasets.sog_scene(n, case["scene_seed"])
+    w = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
+    path = str(tmp_path / "out.sog")
+    np.random.seed(case["np_seed"])
+    w.write_sog(data, path, compression_level=case["compression_level"])
+    with zipfile.ZipFile(path) as zf:
+        meta = json.loads(zf.read("meta.json"))
+        tex = {f[:-5]: np.asarray(Image.open(io.BytesIO(zf.read(f))).convert("RGBA"), dtype=np.uint8).reshape(-1, 4)
+               for f in zf.namelist() if f.endswith(".webp")}
+    for t in ("means_l", "means_u", "quats"):
+        np.testing.assert_array_equal(tex[t][:n], arr[name + "__" + t])
+    np.testing.assert_array_equal(tex["sh0"][:n, 3], arr[name + "__sh0"][:, 3])
+    assert meta["means"] == case["meta"]["means"] and meta["count"] == n
+    assert meta["shN"]["count"] == case["meta"]["shN"]["count"] and meta["shN"]["bands"] == 3
+    assert tex["shN_centroids"].shape == arr[name + "__shN_centroids"].shape
+    ds = data[np.lexsort((data["z"], data["y"], data["x"]))]
+    for t, cols in (("scales", ["scale_0", "scale_1", "scale_2"]), ("sh0", ["f_dc_0", "f_dc_1", "f_dc_2"])):
+        cb = np.array(meta[t]["codebook"], dtype=np.float32)
+        vis = tex[t][:n, 3] != 0
+        for ch, col in enumerate(cols):
+            np.testing.assert_array_equal(okm.quantize_to_codebook(ds[col], cb)[vis], tex[t][:n, ch][vis])
+    lab = tex["shN_labels"][:n, 0].astype(np.int64) + 256 * tex["shN_labels"][:n, 1].astype(np.int64)
+    assert lab.max() < meta["shN"]["count"]
