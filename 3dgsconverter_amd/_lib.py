@@ -60,6 +60,8 @@ SIGNATURES = {
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
     "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
+    "gsx_mask_bbox_dev": (_I, [_P, _P, _I64, _P, _P]),
+    "gsx_mask_ge_dev": (_I, [_P, _P, _P, _I64, _D, _P]),
     "gsx_sor_knn_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_knn_share_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _I, _P, C.POINTER(SorInfo)]),
     "gsx_sor_stats_dev": (_I, [_P, _P, _I64, _D, _P]),
@@ -457,6 +459,26 @@ class DeviceChain:
 
     def keep_none(self):
         self.n = 0
+
+    def bbox_keep(self, bounds6) -> int:
+        """crop_by_bbox (data_processor.py:215-224): bounds as numpy would see them -- Python floats are weak scalars
+        (rounded to float32 before the comparison), numpy float64 scalars promote the comparison to f64"""
+        b = np.array([float(np.float32(v)) if type(v) in (float, int) else float(v) for v in bounds6], dtype=np.float64)
+        check(self.ctx.lib.gsx_mask_bbox_dev(self.ctx.handle, self.rows.ptr, self.n, b.ctypes.data, self.mask.ptr), "gsx_mask_bbox_dev")
+        return self._compact()
+
+    def ge_keep(self, column: np.ndarray, threshold: float) -> int:
+        """rows whose value in ``column`` (float32, one per row of the table the chain started from) is >= threshold"""
+        col = np.ascontiguousarray(column, dtype=np.float32)
+        if col.shape != (self.n0,):
+            raise ValueError("column must have one value per original row")
+        dev = self.ctx.alloc(max(col.nbytes, 16)).upload(col)
+        try:
+            check(self.ctx.lib.gsx_mask_ge_dev(self.ctx.handle, dev.ptr, self.orig.ptr if self.orig is not None else None, self.n,
+                                               float(threshold), self.mask.ptr), "gsx_mask_ge_dev")
+            return self._compact()
+        finally:
+            dev.free()
 
     def sor_keep(self, k: int, threshold_factor: float):
         n = self.n

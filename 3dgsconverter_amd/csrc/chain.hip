@@ -85,9 +85,54 @@ __global__ __launch_bounds__(256) void compact_write_kernel(const float *__restr
     }
 }
 
+// The two O(N) row filters that precede density / SOR in the reference's orchestrator (converter.py:196-203), as masks over
+// the device-resident rows -- SURVEY.md 8(f) rank 4.  Both compare in f64: a float32 compared with a float32-rounded bound
+// gives the same answer in either width, and numpy itself promotes to f64 when the bound is a np.float64 scalar (the
+// alpha filter's logit threshold, data_processor.py:207-210).
+__global__ __launch_bounds__(256) void mask_bbox_kernel(const float *__restrict__ rows, int64_t n, double lox, double loy, double loz,
+                                                        double hix, double hiy, double hiz, uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = rows[3 * i], y = rows[3 * i + 1], z = rows[3 * i + 2];
+    mask[i] = (x >= lox) & (x <= hix) & (y >= loy) & (y <= hiy) & (z >= loz) & (z <= hiz);   // data_processor.py:217-224
+}
+
+__global__ __launch_bounds__(256) void mask_ge_kernel(const float *__restrict__ vals, const unsigned *__restrict__ orig, int64_t n,
+                                                      double thr, uint8_t *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    mask[i] = (double)vals[orig ? orig[i] : (unsigned)i] >= thr;   // data_processor.py:210
+}
+
 }  // namespace gsx
 
 using namespace gsx;
+
+extern "C" int gsx_mask_bbox_dev(gsx_ctx *c, const float *rows_dev, int64_t n, const double *bounds6, uint8_t *mask_dev)
+{
+    if (!c || !bounds6 || (n > 0 && (!rows_dev || !mask_dev))) GSX_FAIL("gsx_mask_bbox_dev: null argument");
+    if (n < 0 || n >= (1LL << 32)) GSX_FAIL("gsx_mask_bbox_dev: n out of range");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_bbox_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, rows_dev, n, bounds6[0], bounds6[1],
+                       bounds6[2], bounds6[3], bounds6[4], bounds6[5], mask_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gsx_mask_ge_dev(gsx_ctx *c, const float *vals_dev, const uint32_t *orig_dev, int64_t n, double threshold,
+                               uint8_t *mask_dev)
+{
+    if (!c || (n > 0 && (!vals_dev || !mask_dev))) GSX_FAIL("gsx_mask_ge_dev: null argument");
+    if (n < 0 || n >= (1LL << 32)) GSX_FAIL("gsx_mask_ge_dev: n out of range");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_ge_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, vals_dev, orig_dev, n, threshold, mask_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int gsx_compact_rows_dev(gsx_ctx *c, const float *rows_dev, const uint32_t *orig_dev, const uint8_t *mask_dev, int64_t n,
                                     float *rows_out_dev, uint32_t *orig_out_dev, int64_t *n_out)

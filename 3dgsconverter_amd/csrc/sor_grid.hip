@@ -183,9 +183,21 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---------------------------------------------------------------- bbox + grid params
+struct GridParamArgs {   // what grid_params needs besides the partial boxes
+    int n;
+    double pts_per_cell;
+    int cell_cap, debug_skip, share, nshares, defer_words;
+    float parent_h;
+    GridParams *gp;
+    unsigned *devflags;
+};
+__device__ void grid_params_body(const float *part, int nparts, const GridParamArgs &a);
+
+// The LAST workgroup to arrive (ticket in GridParams) turns the partial boxes into the grid parameters: a separate
+// one-wave launch cost ~9 us per step -- 2.5 % of the 1M-splat step.
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                            const float *__restrict__ z, int64_t stride, int n,
-                                                           float *__restrict__ part)
+                                                           float *__restrict__ part, GridParamArgs gpa)
 {
     __shared__ float red[7][4];
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -222,15 +234,26 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
     if (threadIdx.x < 7) {
         float v = red[threadIdx.x][0];
         for (int i = 1; i < 4; ++i) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][i]) : fmaxf(v, red[threadIdx.x][i]);
-        part[blockIdx.x * 7 + threadIdx.x] = v;
+        __hip_atomic_store(&part[blockIdx.x * 7 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
     }
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_s_waitcnt(0);   // the write-through stores above have completed before the ticket (no L2 write-back needed)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&gpa.gp->ticket_bbox, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) gpa.gp->ticket_bbox = 0;
+    if (threadIdx.x < 64) grid_params_body(part, (int)gridDim.x, gpa);
 }
 
-__global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict__ part, int nparts, int n,
-                                                         double pts_per_cell, int cell_cap, int debug_skip,
-                                                         int share, int nshares, int defer_words, float parent_h,
-                                                         GridParams *__restrict__ gp, unsigned *__restrict__ devflags)
+__device__ void grid_params_body(const float *part, int nparts, const GridParamArgs &a)
 {
+    const int n = a.n, cell_cap = a.cell_cap, debug_skip = a.debug_skip, share = a.share, nshares = a.nshares,
+              defer_words = a.defer_words;
+    const double pts_per_cell = a.pts_per_cell;
+    const float parent_h = a.parent_h;
+    GridParams *gp = a.gp;
+    unsigned *devflags = a.devflags;
     const int lane = threadIdx.x;
     // all 7 x ceil(nparts/64) loads are independent: issue them together (reducing one value at a time
     // serialised 7 round trips and made this one-wave kernel 9 us, 2 % of the 1M-splat step)
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(64) void grid_params_kernel(const float *__restrict
     for (int i = lane; i < nparts; i += 64) {
         float t[7];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) t[a] = part[i * 7 + a];
+        for (int a = 0; a < 7; ++a) t[a] = __hip_atomic_load(&part[i * 7 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by other workgroups
 #pragma unroll
         for (int a = 0; a < 7; ++a) v[a] = a < 3 ? fminf(v[a], t[a]) : fmaxf(v[a], t[a]);
     }
@@ -394,10 +417,13 @@ __device__ __forceinline__ int bucket_of(const GridParams &g, int cy, int cz)
 //   B  bucket_sort    one workgroup per bucket: LDS histogram over the bucket's cells, LDS scan ->
 //                     cell_start (bucket base + local prefix, no global scan), LDS cursors -> final
 //                     position; reads are contiguous, writes stay inside the bucket's ~64 KiB window.
+__device__ void bucket_scan_body(int nb, unsigned *bk_cnt, unsigned *bk_start, unsigned *bk_cursor);
+
 __global__ __launch_bounds__(256) void bucket_hist_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ z, int64_t stride, int first, int n,
-                                                          const GridParams *__restrict__ gp,
-                                                          unsigned *__restrict__ bk_cnt)
+                                                          GridParams *__restrict__ gp,
+                                                          unsigned *__restrict__ bk_cnt, unsigned *__restrict__ bk_start,
+                                                          unsigned *__restrict__ bk_cursor)
 {
     __shared__ unsigned hist[MAX_BUCKETS];
     const GridParams g = *gp;
@@ -428,6 +454,15 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const float *__restric
         }
         __syncthreads();
     }
+    // the last workgroup to arrive scans the bucket sizes (formerly a one-workgroup launch of its own)
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_s_waitcnt(0);   // this workgroup's device-scope atomics have completed
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&gp->ticket_hist, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) gp->ticket_hist = 0;
+    bucket_scan_body(g.bk_count, bk_cnt, bk_start, bk_cursor);
 }
 
 __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned *total, unsigned *wsum /*[4]*/)
@@ -454,16 +489,15 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigne
     return base + inc - v;
 }
 
-// bk_start[0..bk_count] = exclusive scan of bk_cnt; bk_cursor = copy of bk_start; bk_cnt re-zeroed for the next call
-__global__ __launch_bounds__(256) void bucket_scan_kernel(const GridParams *__restrict__ gp, unsigned *__restrict__ bk_cnt,
-                                                          unsigned *__restrict__ bk_start, unsigned *__restrict__ bk_cursor)
+// bk_start[0..bk_count] = exclusive scan of bk_cnt; bk_cursor = copy of bk_start; bk_cnt re-zeroed for the next call.
+// Run by the 256 threads of bucket_hist's last workgroup; bk_cnt was accumulated with device-scope atomics (L2).
+__device__ void bucket_scan_body(int nb, unsigned *bk_cnt, unsigned *bk_start, unsigned *bk_cursor)
 {
     __shared__ unsigned wsum[4];
-    const int nb = gp->bk_count;
     unsigned carry = 0;
     for (int b = 0; b < nb; b += 256) {
         const int i = b + threadIdx.x;
-        const unsigned v = i < nb ? bk_cnt[i] : 0u;
+        const unsigned v = i < nb ? __hip_atomic_load(&bk_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         unsigned tot;
         const unsigned ex = block_exclusive_scan_256(v, &tot, wsum);
         if (i < nb) {
@@ -1909,8 +1943,7 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
     float4 *tmp = w.bucketpts.as<float4>();
     const int tiles = (int)std::min<int64_t>(div_up(n, BIN_TILE), (int64_t)ctx->num_cu * 4);
     hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n, gp,
-                       bk_cnt);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, gp, bk_cnt, bk_start, bk_cursor);
+                       bk_cnt, bk_start, bk_cursor);   // its last workgroup scans the bucket sizes
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(tiles), dim3(SCATTER_THREADS), 0, ctx->stream, x, y, z, stride, (int)first, (int)n,
                        gp, bk_cursor, tmp, (int)std::min<int64_t>(ref_only_from, INT32_MAX));
     if (big_path) GSX_HIP(hipMemsetAsync(start, 0, sizeof(unsigned) * (size_t)(cell_cap + 1), ctx->stream));  // counts of big buckets
@@ -1964,7 +1997,10 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         GSX_CHECK(w.bkcnt.reserve(sizeof(unsigned) * (3 * MAX_BUCKETS + 8)));
         GSX_HIP(hipMemsetAsync(w.bkcnt.p, 0, sizeof(unsigned) * (3 * MAX_BUCKETS + 8), ctx->stream));
     }
-    GSX_CHECK(w.gridparams.reserve(sizeof(GridParams)));
+    if (!w.gridparams.p) {   // the arrival tickets inside must start at zero (they reset themselves afterwards)
+        GSX_CHECK(w.gridparams.reserve(sizeof(GridParams)));
+        GSX_HIP(hipMemsetAsync(w.gridparams.p, 0, sizeof(GridParams), ctx->stream));
+    }
     GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
     GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(std::max(q_count, slab ? n_ref : q_count) / 64 + 64)));
@@ -1981,11 +2017,10 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     unsigned *rstart = w.cellstart.as<unsigned>();
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
+    GridParamArgs gpa{(int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0, parent_h, gp,
+                      ctx->devflags.as<unsigned>()};
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
-                       w.bboxpart.as<float>());
-    hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(64), 0, ctx->stream, w.bboxpart.as<float>(), bbox_blocks,
-                       (int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0,
-                       parent_h, gp, ctx->devflags.as<unsigned>());
+                       w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
     GSX_HIP(hipGetLastError());
     if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr,

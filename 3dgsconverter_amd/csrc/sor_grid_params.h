@@ -38,6 +38,9 @@ struct GridParams {
     unsigned brick_ctr[8 * 32];   // dynamic-tail counters, one per XCD, separate cache lines
     unsigned extra_ctr[8 * 32];
     unsigned ring_ctr[8 * 32];
+    // arrival tickets of the kernels whose last workgroup finishes the job of a former one-workgroup launch
+    // (bbox_partial -> grid parameters, bucket_hist -> bucket scan); never touched by grid_params, self-resetting
+    unsigned ticket_bbox, ticket_hist;
 };
 
 // Work distribution shared by knn_brick / knn_ring (device): static stride + a small dynamic tail.

@@ -74,10 +74,73 @@ __device__ __forceinline__ float replay_tree(int n, const float *lv, int &li)
     }
 }
 
+// mode 0: stats[0] = mean.  mode 1: stats[1] = std, stats[2] = threshold.
+// One wave: numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial; the
+// wave loads 64 piece sums per step (coalesced) and folds them in order through v_readlane.
+__device__ __forceinline__ void stats_finalize_body(const float *__restrict__ chunk_sum, int64_t n, int64_t nchunks, int mode,
+                                                    float factor, float *__restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    float acc = 0.0f;
+    for (int64_t base = 0; base < nchunks; base += 64) {
+        const int m = (int)((nchunks - base) < 64 ? (nchunks - base) : 64);
+        const float v = lane < m ? __hip_atomic_load(&chunk_sum[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        if (m == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+        } else {
+            for (int j = 0; j < m; ++j) acc += __shfl(v, j);
+        }
+    }
+    if (lane != 0) return;
+    const float q = (float)((double)acc / (double)n);  // f32 sum / np.intp count: float64 divide, cast back
+    if (mode == 0) {
+        stats[0] = q;
+    } else {
+        const float sd = __builtin_sqrtf(q);
+        stats[1] = sd;
+        stats[2] = stats[0] + factor * sd;
+    }
+}
+
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n, int64_t nchunks,
+                                                            int mode, float factor, float *__restrict__ stats)
+{
+    stats_finalize_body(chunk_sum, n, nchunks, mode, factor, stats);
+}
+
+// Single-GPU path: the last workgroup of chunk_sums_kernel to arrive folds the piece sums itself (ticket != NULL),
+// which saves the two one-wave launches; the multi-GPU path exchanges the piece sums first and keeps them separate.
+struct StatsFold {
+    unsigned *ticket;
+    float factor;
+    float *stats_out;
+};
+
+template <bool SQ>
+__device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int64_t n, const float *__restrict__ stats,
+                                               float *__restrict__ chunk_sum);
+
 template <bool SQ>
 __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *__restrict__ a, int64_t n,
                                                                    const float *__restrict__ stats,
-                                                                   float *__restrict__ chunk_sum)
+                                                                   float *__restrict__ chunk_sum, StatsFold fold)
+{
+    chunk_sum_body<SQ>(a, n, stats, chunk_sum);
+    if (!fold.ticket) return;
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_s_waitcnt(0);   // the write-through piece sum has completed before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(fold.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *fold.ticket = 0;
+    if (threadIdx.x < 64) stats_finalize_body(chunk_sum, n, (int64_t)gridDim.x, SQ ? 1 : 0, fold.factor, fold.stats_out);
+}
+
+template <bool SQ>
+__device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int64_t n, const float *__restrict__ stats,
+                                               float *__restrict__ chunk_sum)
 {
     __shared__ int s_leaf_start[160];
     __shared__ int s_leaf_len[160];
@@ -109,7 +172,7 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
         for (int off = 2; off < 64; off <<= 1) s = s + __shfl_xor(s, off);
         if (lane == 0) s_half[wv] = s;
         __syncthreads();
-        if (threadIdx.x == 0) chunk_sum[c] = s_half[0] + s_half[1];  // 4096 + 4096
+        if (threadIdx.x == 0) __hip_atomic_store(&chunk_sum[c], s_half[0] + s_half[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 4096 + 4096
         return;
     }
 
@@ -179,36 +242,7 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
     __syncthreads();
     if (threadIdx.x == 0) {
         int li = 0;
-        chunk_sum[c] = replay_tree<7>(len, lv, li);
-    }
-}
-
-// mode 0: stats[0] = mean.  mode 1: stats[1] = std, stats[2] = threshold.
-// One wave: numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial; the
-// wave loads 64 piece sums per step (coalesced) and folds them in order through v_readlane.
-__global__ __launch_bounds__(64) void stats_finalize_kernel(const float *__restrict__ chunk_sum, int64_t n, int64_t nchunks,
-                                                            int mode, float factor, float *__restrict__ stats)
-{
-    const int lane = threadIdx.x;
-    float acc = 0.0f;
-    for (int64_t base = 0; base < nchunks; base += 64) {
-        const int m = (int)((nchunks - base) < 64 ? (nchunks - base) : 64);
-        const float v = lane < m ? chunk_sum[base + lane] : 0.0f;
-        if (m == 64) {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-        } else {
-            for (int j = 0; j < m; ++j) acc += __shfl(v, j);
-        }
-    }
-    if (lane != 0) return;
-    const float q = (float)((double)acc / (double)n);  // f32 sum / np.intp count: float64 divide, cast back
-    if (mode == 0) {
-        stats[0] = q;
-    } else {
-        const float sd = __builtin_sqrtf(q);
-        stats[1] = sd;
-        stats[2] = stats[0] + factor * sd;
+        __hip_atomic_store(&chunk_sum[c], replay_tree<7>(len, lv, li), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -238,10 +272,9 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
     float *cs = ctx->statspart.as<float>();
     const int blocks = (int)nchunks;
     const float tf = (float)factor;  // python float is a weak scalar: rounded to f32 first
-    hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, nchunks, 0, tf, stats_dev);
-    hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, n, nchunks, 1, tf, stats_dev);
+    const StatsFold fold{ctx->devflags.as<unsigned>() + 8, tf, stats_dev};   // word 8 of the flag block: arrival ticket
+    hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs, fold);
+    hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs, fold);
     GSX_HIP(hipGetLastError());
     return 0;
 }
@@ -252,9 +285,9 @@ int launch_sor_piece_sums(gsx_ctx *ctx, const float *a, int64_t n, const float *
 {
     const int blocks = (int)((n + NP_BUF - 1) / NP_BUF);
     if (mean_dev)
-        hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out);
+        hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out, StatsFold{nullptr, 0.0f, nullptr});
     else
-        hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out);
+        hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out, StatsFold{nullptr, 0.0f, nullptr});
     GSX_HIP(hipGetLastError());
     return 0;
 }

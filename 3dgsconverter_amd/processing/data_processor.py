@@ -208,12 +208,13 @@ class DataProcessor:
         return None
 
     # ------------------------------------------------------------------ O(N) row filters
-    # Same masks as the reference, computed by the same numpy expressions; only `self.data[mask]`
-    # -- 1.2 s per call at 10M splats in numpy -- goes through the threaded C compaction.
+    # Lazy mode (the orchestrator's): masks over the device-resident rows (chain.hip), composed with density / SOR into the
+    # one host compaction at the end.  Eager mode: the reference's numpy expressions; only `self.data[mask]` -- 1.2 s per
+    # call at 10M splats in numpy -- goes through the threaded C compaction.
     def apply_alpha_filter(self, min_opacity_u8):
         """reference :184-213"""
         debug_print(f"[DEBUG] Executing 'apply_alpha_filter' with min={min_opacity_u8}")
-        if 'opacity' not in self.data.dtype.names:
+        if 'opacity' not in self._data.dtype.names:
             status_print("Warning: No opacity channel found. Alpha filter skipped.")
             return
         limit = min_opacity_u8
@@ -224,6 +225,12 @@ class DataProcessor:
             return
         alpha_thresh = np.clip(limit / 255.0, 1e-6, 1.0 - 1e-6)
         logit_thresh = np.log(alpha_thresh / (1.0 - alpha_thresh))
+        if self.lazy and len(self) > 0 and self._data['opacity'].dtype == np.float32:
+            ch = self._chain_for(self._data)
+            original_len = ch.n
+            left = ch.ge_keep(self._data['opacity'], float(logit_thresh))   # np.float64 threshold: an f64 comparison
+            status_print(f"Alpha Filter (min {limit}): Retained {left} out of {original_len} splats.")
+            return None
         mask = self.data['opacity'] >= logit_thresh
         original_len = len(self.data)
         self.data = _lib.host_compact_rows(self.data, mask)
@@ -232,6 +239,12 @@ class DataProcessor:
 
     def crop_by_bbox(self, min_x, min_y, min_z, max_x, max_y, max_z):
         """reference :215-231"""
+        if self.lazy and isinstance(self._data, np.ndarray) and len(self) > 0 and all(
+                self._data.dtype[f] == np.float32 for f in ("x", "y", "z")):
+            left = self._chain_for(self._data).bbox_keep((min_x, min_y, min_z, max_x, max_y, max_z))
+            debug_print(f"[DEBUG] Number of vertices after cropping: {left}")
+            status_print(f"After cropping, retained {left} vertices.")
+            return None
         d = self.data
         mask = ((d['x'] >= min_x) & (d['x'] <= max_x) & (d['y'] >= min_y) & (d['y'] <= max_y) &
                 (d['z'] >= min_z) & (d['z'] <= max_z))

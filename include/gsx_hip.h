@@ -129,6 +129,18 @@ int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_t n, const 
 int gsx_compact_rows_dev(gsx_ctx *ctx, const float *rows_dev, const uint32_t *orig_dev, const uint8_t *mask_dev, int64_t n,
                          float *rows_out_dev, uint32_t *orig_out_dev, int64_t *n_out);
 
+/*
+ * The O(N) row filters that run before density / SOR (converter.py:196-203), as device masks over the chain's rows --
+ * SURVEY.md 8(f) rank 4.  gsx_mask_bbox_dev replaces crop_by_bbox's six comparisons (data_processor.py:217-224);
+ * bounds6 = {min_x,min_y,min_z,max_x,max_y,max_z} on the host, compared in f64 (pass float32-rounded values for Python
+ * floats, which numpy treats as weak scalars).  gsx_mask_ge_dev replaces apply_alpha_filter's
+ * `self.data['opacity'] >= logit_thresh` (:210, an f64 comparison because logit_thresh is a np.float64): vals_dev is
+ * the float32 column of the ORIGINAL table, orig_dev (nullable = identity) the chain's survivor list.
+ */
+int gsx_mask_bbox_dev(gsx_ctx *ctx, const float *rows_dev, int64_t n, const double *bounds6, uint8_t *mask_dev);
+int gsx_mask_ge_dev(gsx_ctx *ctx, const float *vals_dev, const uint32_t *orig_dev, int64_t n, double threshold,
+                    uint8_t *mask_dev);
+
 /* ---- Statistical Outlier Removal --------------------------------------- */
 /*
  * KNN mean distance -- replaces data_processor.py:156-173 (cKDTree build + chunked

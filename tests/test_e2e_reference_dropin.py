@@ -89,6 +89,16 @@ def dropin(gsx, monkeypatch):
         def keep_none(self):
             self._keep(np.zeros(self.n, bool))
 
+        def bbox_keep(self, b):
+            hits.append(("gsx_mask_bbox_dev", self.n))
+            b = [np.float32(v) if type(v) in (float, int) else v for v in b]
+            x, y, z = self.xyz.T
+            return self._keep((x >= b[0]) & (x <= b[3]) & (y >= b[1]) & (y <= b[4]) & (z >= b[2]) & (z <= b[5]))
+
+        def ge_keep(self, column, threshold):
+            hits.append(("gsx_mask_ge_dev", self.n))
+            return self._keep(column[self.idx].astype(np.float64) >= threshold)
+
         def sor_keep(self, k, threshold_factor):
             hits.append(("gsx_sor_knn_dev", self.n, int(k), float(threshold_factor)))
             r = osor.sor(self.xyz, int(k), float(threshold_factor))
@@ -195,6 +205,24 @@ def test_converter_run_density_then_sor_stays_on_the_device(tmp_path, gsx, dropi
     xyz = np.column_stack([dens["x"], dens["y"], dens["z"]]).astype(np.float32)
     cap = refload.reference_sor(xyz, 10, 1.0)   # the reference's own SOR mask on its own density output
     assert got.reset_index(drop=True).equals(dens[cap["mask"]].reset_index(drop=True))
+
+
+def test_converter_run_all_four_filters_are_one_chain(tmp_path, gsx, dropin):
+    """--bbox, --min_opacity, --density_sensitivity, --sor_k/--sor_sigma in the orchestrator's order (converter.py:196-236):
+    four masks over the device-resident rows, one chain, one host compaction; same table as the reference's own run with
+    its (computed, not applied) SOR mask applied"""
+    inp, _ = _write_input(tmp_path)
+    box = (-2.5, -3.0, -2.0, 3.0, 2.75, 2.2)
+    got = _run(tmp_path, inp, "dropin", bbox=box, min_opacity=40, density_sensitivity=0.3, sor_k=10.0, sor_sigma=1.0)
+    names = [h[0] for h in dropin if h[0] not in ("gsx_density_voxels", "gsx_density_mask")]
+    assert names == ["DeviceChain", "gsx_mask_bbox_dev", "gsx_mask_ge_dev", "gsx_density_voxels_dev", "gsx_density_mask_dev",
+                     "gsx_sor_knn_dev"]
+    gsx.uninstall()
+    pre = _run(tmp_path, inp, "reference_pre", bbox=box, min_opacity=40, density_sensitivity=0.3)
+    assert 0 < len(pre) < 6000 and len(pre) == dropin[-1][1]
+    xyz = np.column_stack([pre["x"], pre["y"], pre["z"]]).astype(np.float32)
+    cap = refload.reference_sor(xyz, 10, 1.0)
+    assert got.reset_index(drop=True).equals(pre[cap["mask"]].reset_index(drop=True))
 
 
 def _decode(path):
