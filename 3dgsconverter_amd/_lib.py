@@ -89,6 +89,9 @@ SIGNATURES = {
     "gsx_lexsort3_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
     "gsx_sog_quats": (_I, [_P, _I64, _P]),
     "gsx_sog_quats_dev": (_I, [_P, _P, _I64, _P]),
+    "gsx_morton_order_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, C.POINTER(_I)]),
+    "gsx_cply_pack_dev": (_I, [_P, _P, _P, _I64, _P, _P]),
+    "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
@@ -299,6 +302,77 @@ def sog_quats(rot_rows: np.ndarray) -> np.ndarray:
     if len(q):
         check(lib.gsx_sog_quats(q.ctypes.data, len(q), out.ctypes.data), "gsx_sog_quats")
     return out
+
+
+def morton_order(x: np.ndarray, y: np.ndarray, z: np.ndarray, ctx: "Context | None" = None, keep_device: bool = False):
+    """formats/compressed_ply.py:245-291 on the GPU (C ABI gsx_morton_order_dev) -> (uint32 order, recursion levels).
+    Stable inside runs of equal Morton code.  keep_device: also return the device copy of the order (caller frees)."""
+    require_hip()
+    cols = [np.ascontiguousarray(c, dtype=np.float32) for c in (x, y, z)]
+    n = len(cols[0])
+    own = ctx is None
+    ctx = ctx or Context(0)
+    bufs = []
+    try:
+        bufs = [ctx.alloc(max(c.nbytes, 16)).upload(c) for c in cols]
+        order = ctx.alloc(max(4 * n, 16))
+        levels = C.c_int()
+        check(ctx.lib.gsx_morton_order_dev(ctx.handle, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, 1, n, order.ptr, C.byref(levels)),
+              "gsx_morton_order_dev")
+        host = order.download(np.uint32, n) if n else np.zeros(0, np.uint32)
+        if keep_device:
+            return host, int(levels.value), order
+        order.free()
+        return host, int(levels.value)
+    finally:
+        for b in bufs:
+            b.free()
+        if own:
+            ctx.close()
+
+
+CPLY_COLUMNS = ("x", "y", "z", "scale_0", "scale_1", "scale_2", "f_dc_0", "f_dc_1", "f_dc_2", "alpha", "rot_0", "rot_1", "rot_2", "rot_3")
+
+
+def cply_pack(columns: dict, order: "np.ndarray | None", sh_columns=(), ctx: "Context | None" = None):
+    """formats/compressed_ply.py:205-241 on the GPU (C ABI gsx_cply_pack_dev / gsx_cply_sh_dev).
+    columns: the 14 float32 columns named in CPLY_COLUMNS (original table order; 'alpha' = numpy's sigmoid of the opacity);
+    order: uint32 Morton order or None.  -> (chunks (ceil(n/256), 18) f32, vertices (n, 4) u32, sh (n, m) u8 or None)"""
+    require_hip()
+    cols = [np.ascontiguousarray(columns[name], dtype=np.float32) for name in CPLY_COLUMNS]
+    n = len(cols[0])
+    nchunks = (n + 255) // 256
+    own = ctx is None
+    ctx = ctx or Context(0)
+    bufs = []
+    try:
+        bufs = [ctx.alloc(max(c.nbytes, 16)).upload(c) for c in cols]
+        ptrs = (C.c_void_p * 14)(*[b.ptr for b in bufs])
+        d_order = None
+        if order is not None:
+            d_order = ctx.alloc(max(4 * n, 16)).upload(np.ascontiguousarray(order, dtype=np.uint32))
+            bufs.append(d_order)
+        d_chunk, d_vert = ctx.alloc(max(72 * nchunks, 16)), ctx.alloc(max(16 * n, 16))
+        bufs += [d_chunk, d_vert]
+        check(ctx.lib.gsx_cply_pack_dev(ctx.handle, ptrs, d_order.ptr if d_order else None, n, d_chunk.ptr, d_vert.ptr), "gsx_cply_pack_dev")
+        chunks = d_chunk.download(np.float32, 18 * nchunks).reshape(nchunks, 18)
+        verts = d_vert.download(np.uint32, 4 * n).reshape(n, 4)
+        sh = None
+        m = len(sh_columns)
+        if m:
+            flat = np.empty((m, n), dtype=np.float32)
+            for i, c in enumerate(sh_columns):
+                flat[i] = c
+            d_sh, d_out = ctx.alloc(max(flat.nbytes, 16)).upload(flat), ctx.alloc(max(n * m, 16))
+            bufs += [d_sh, d_out]
+            check(ctx.lib.gsx_cply_sh_dev(ctx.handle, d_sh.ptr, m, n, d_order.ptr if d_order else None, n, d_out.ptr), "gsx_cply_sh_dev")
+            sh = d_out.download(np.uint8, n * m).reshape(n, m)
+        return chunks, verts, sh
+    finally:
+        for b in bufs:
+            b.free()
+        if own:
+            ctx.close()
 
 
 class DeviceArray:

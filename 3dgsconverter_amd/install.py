@@ -20,7 +20,8 @@ _saved = {}
 def install(sog_writer: bool = True):
     """sog_writer: also rebind ``gsconverter.formats.sog.SogFormat.write`` to formats/sog_writer.py:write_sog (spatial
     sort, quaternion packing, codebook quantiser and SH palette on the GPU; identical bytes where the reference is
-    deterministic)."""
+    deterministic) and ``gsconverter.formats.compressed_ply.CompressedPlyFormat.write`` to
+    formats/compressed_ply_writer.py:write_compressed_ply (Morton order, chunk bounds and packers on the GPU)."""
     from . import processing
     from .processing import gpu_ops
     from .processing.data_processor import ChainedDataProcessor as DataProcessor   # lazy: coordinates stay in HBM across filters
@@ -48,6 +49,13 @@ def install(sog_writer: bool = True):
             sogmod.SogFormat.write = lambda self, data, path, **kw: write_sog(data, path, **kw)
         except Exception:
             pass  # pillow missing: the reference's own writer is not importable either
+        try:
+            cpmod = importlib.import_module("gsconverter.formats.compressed_ply")
+            from .formats.compressed_ply_writer import write_compressed_ply
+            _saved.setdefault(("cplyformat", "write"), cpmod.CompressedPlyFormat.write)
+            cpmod.CompressedPlyFormat.write = lambda self, data, path, **kw: write_compressed_ply(data, path, **kw)
+        except Exception:
+            pass
     _saved.setdefault(("sys.modules", "gsconverter.processing.gpu_ops"),
                       sys.modules.get("gsconverter.processing.gpu_ops"))
     sys.modules["gsconverter.processing.gpu_ops"] = gpu_ops
@@ -58,6 +66,9 @@ def uninstall():
     for (modname, attr), val in list(_saved.items()):
         if modname == "sogformat":
             importlib.import_module("gsconverter.formats.sog").SogFormat.write = val
+            continue
+        if modname == "cplyformat":
+            importlib.import_module("gsconverter.formats.compressed_ply").CompressedPlyFormat.write = val
             continue
         if modname == "sys.modules":
             if val is None:

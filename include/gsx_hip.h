@@ -291,6 +291,31 @@ int gsx_lexsort3_dev(gsx_ctx *ctx, const float *k0, const float *k1, const float
 int gsx_sog_quats(const float *rot_rows, int64_t n, uint8_t *out4);
 int gsx_sog_quats_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, uint8_t *out4_dev);
 
+/* ---- compressed-PLY writer numeric core ---- */
+/*
+ * formats/compressed_ply.py:245-291 _sort_morton_order: 10-bit-per-axis Morton codes inside the bounding box, groups of
+ * equal code with more than 256 members re-sorted inside their own box, recursively.  order_out_dev: n uint32, the
+ * `indices` array the reference sorts in place.  The sequence of codes is the reference's; splats with EQUAL code keep
+ * ascending input index here, while np.argsort (not stable) leaves them in a build-dependent order.  *levels_out
+ * (nullable) = recursion depth reached.  Coordinates must be finite.
+ */
+int gsx_morton_order_dev(gsx_ctx *ctx, const float *x_dev, const float *y_dev, const float *z_dev, int64_t stride, int64_t n,
+                         uint32_t *order_out_dev, int *levels_out);
+/*
+ * compressed_ply.py:205-234 (chunk loop) with :293-341 (_normalize_and_pack_11_10_11, _normalize_and_pack_8888,
+ * _pack_quaternions): one workgroup per 256-splat chunk.  cols14_dev: HOST array of 14 device columns of the ORIGINAL
+ * table (float32, contiguous): x y z, scale_0..2, f_dc_0..2, alpha = sigmoid(opacity) as numpy computed it (:200-203),
+ * rot_0..3.  order_dev (nullable = identity): the Morton order.  chunk_out_dev: ceil(n/256) x 18 float32 in the field
+ * order of the reference's chunk record (:167-174); vertex_out_dev: n x 4 uint32 (packed_position, packed_rotation,
+ * packed_scale, packed_color), 16-byte aligned.  Bit-exact given the same order.
+ */
+int gsx_cply_pack_dev(gsx_ctx *ctx, const float *const *cols14_dev, const uint32_t *order_dev, int64_t n,
+                      float *chunk_out_dev, uint32_t *vertex_out_dev);
+/* compressed_ply.py:236-241: out[i, c] = uint8(clip((col_c[order[i]] / 8.0 + 0.5) * 256, 0, 255)); cols_dev = m columns
+ * of col_stride floats each (m <= 45), out_dev = (n, m) bytes = the reference's `sh` element */
+int gsx_cply_sh_dev(gsx_ctx *ctx, const float *cols_dev, int m, int64_t col_stride, const uint32_t *order_dev, int64_t n,
+                    uint8_t *out_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,3 +121,41 @@ def load_gpu_ops_with_taichi_shim():
         taichi_shim.uninstall()
     assert mod.HAS_TAICHI, "the shim did not take"
     return mod
+
+
+def reference_cply(data, stable_ties=False):
+    """What the reference's ``CompressedPlyFormat.write`` (formats/compressed_ply.py:128-243) hands to its PLY
+    container -- the writer itself runs, only ``_write_ply_file`` (plyfile, absent here) is intercepted.
+    stable_ties: run it with ``np.argsort`` made stable inside that module (the only change), which fixes the order of
+    splats with equal Morton code.  -> dict(order, chunk, vertex, sh)"""
+    import numpy as np
+    load()
+    import gsconverter.formats.compressed_ply as mod  # type: ignore
+
+    class _StableNp:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def argsort(a, *args, **kw):
+            return np.argsort(a, kind="stable")
+
+    got = {}
+    fmt = mod.CompressedPlyFormat()
+    orig_sort = fmt._sort_morton_order
+
+    def sort_and_record(d, indices):
+        orig_sort(d, indices)
+        got["order"] = indices.copy()
+
+    fmt._sort_morton_order = sort_and_record
+    fmt._write_ply_file = lambda path, chunk, vertex, sh: got.update(chunk=chunk.copy(), vertex=vertex.copy(),
+                                                                   sh=None if sh is None else sh.copy())
+    saved = mod.np
+    try:
+        if stable_ties:
+            mod.np = _StableNp()
+        fmt.write(data, "/dev/null")
+    finally:
+        mod.np = saved
+    return got

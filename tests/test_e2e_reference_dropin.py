@@ -122,7 +122,38 @@ def dropin(gsx, monkeypatch):
             ds["rot_%d" % c] = rows[:, c]
         return osog.quats(ds)
 
-    for name, fn in (("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
+    def morton_order(x, y, z, ctx=None, keep_device=False):
+        from oracle import cply as ocply
+        hits.append(("gsx_morton_order_dev", len(x)))
+        return ocply.morton_order(x, y, z)
+
+    def cply_pack(columns, order, sh_columns=(), ctx=None):
+        from oracle import cply as ocply
+        hits.append(("gsx_cply_pack_dev", len(order), len(sh_columns)))
+        n = len(order)
+        d = np.zeros(n, dtype=[(c, "f4") for c in lib.CPLY_COLUMNS if c != "alpha"] + [("opacity", "f4")] +
+                     [("f_rest_%d" % i, "f4") for i in range(len(sh_columns))])
+        for c in lib.CPLY_COLUMNS:
+            if c != "alpha":
+                d[c] = columns[c]
+        a = np.asarray(columns["alpha"], dtype=np.float32)
+        with np.errstate(divide="ignore"):
+            d["opacity"] = -np.log(1.0 / a - 1.0)       # only used to rebuild alpha below; replaced right after
+        for i, col in enumerate(sh_columns):
+            d["f_rest_%d" % i] = col
+        chunks, verts, sh = ocply.encode(d, order, ["f_rest_%d" % i for i in range(len(sh_columns))])
+        na = np.clip(np.floor(a[order] * 255 + 0.5), 0, 255).astype(np.uint32)   # the alpha byte from the alpha actually given
+        verts[:, 3] = (verts[:, 3] & 0xffffff00) | na
+        return chunks, verts, sh
+
+    class FakeCtx:
+        def __init__(self, device=0):
+            pass
+
+        def close(self):
+            pass
+
+    for name, fn in (("morton_order", morton_order), ("cply_pack", cply_pack), ("Context", FakeCtx), ("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
                      ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
                      ("lexsort3", lexsort3), ("sog_quats", sog_quats)):
         monkeypatch.setattr(lib, name, fn)
@@ -223,6 +254,33 @@ def test_converter_run_all_four_filters_are_one_chain(tmp_path, gsx, dropin):
     xyz = np.column_stack([pre["x"], pre["y"], pre["z"]]).astype(np.float32)
     cap = refload.reference_sor(xyz, 10, 1.0)
     assert got.reset_index(drop=True).equals(pre[cap["mask"]].reset_index(drop=True))
+
+
+def test_compressed_ply_writer_goes_through_the_dropin(tmp_path, gsx, dropin):
+    """install() rebinds CompressedPlyFormat.write: Morton order, chunk bounds and packers reach the product's entry points;
+    the file holds exactly the elements the reference's own writer produces (with its argsort made stable)"""
+    refload.load()
+    from gsconverter.converter import Converter
+    data = ocply_scene()
+    inp = str(tmp_path / "in.parquet")
+    from gsconverter.formats.parquet import ParquetFormat
+    ParquetFormat().write(data, inp)
+    out = str(tmp_path / "out.compressed.ply")
+    Converter(inp, out, "compressed_ply").run()
+    assert [h[0] for h in dropin] == ["gsx_morton_order_dev", "gsx_cply_pack_dev"] and dropin[1][1:] == (len(data), 45)
+    gsx.uninstall()
+    table = ParquetFormat().read(inp)
+    ref = refload.reference_cply(table, stable_ties=True)
+    raw = open(out, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    nc = len(ref["chunk"])
+    assert ("element chunk %d" % nc).encode() in head and ("element vertex %d" % len(data)).encode() in head
+    assert body == ref["chunk"].tobytes() + ref["vertex"].tobytes() + ref["sh"].tobytes()
+
+
+def ocply_scene():
+    from oracle import cply as ocply
+    return ocply.cply_scene(2500, 12, "clustered")
 
 
 def _decode(path):
