@@ -368,6 +368,7 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
     gp->extra_count = 0;
     gp->heavy_limit = defer_words > 0 ? HEAVY_RING_CANDIDATES : 0;  // both need the host in the loop
     gp->heavy_count = 0;
+    gp->ring2_count = 0;
     for (int a = 0; a < 3; ++a) {
         gp->qb_lo[a] = __builtin_inff();
         gp->qb_hi[a] = -__builtin_inff();
@@ -380,6 +381,7 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
         gp->brick_ctr[i * 32] = 0;
         gp->extra_ctr[i * 32] = 0;
         gp->ring_ctr[i * 32] = 0;
+        gp->ringf_ctr[i * 32] = 0;
     }
 
 }
@@ -1312,7 +1314,7 @@ template <int KCAP>
 __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, int k, int q_begin,
-    float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ heavylist, int out_count)
+    float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ heavylist, int out_count, int after_fast)
 {
     __shared__ double s_out[BRICK_THREADS / 64][KCAP];
     __shared__ int s_rs[BRICK_THREADS / 64][RING_ROWS];       // first point of each row
@@ -1327,7 +1329,8 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
             mean_out[i] = __builtin_nanf("");
         return;
     }
-    const int nfail = (int)g.fail_count;
+    const int nfail = (int)(after_fast ? g.ring2_count : g.fail_count);   // after_fast: what knn_ring_fast could not finish
+    if (nfail == 0) return;
     const int kk = k + 1;
 
     WorkQueue wq;
@@ -1335,7 +1338,8 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     for (;;) {
         const int t = uniform(wq_next(wq));
         if (t < 0) break;
-        const float4 qp = qpts[faillist[t]];
+        const unsigned fq = faillist[t];
+        const float4 qp = qpts[fq];
         const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
         const int cx = cell_coord(qp.x, g.ox, g.inv_h, g.nx);
         const int cy = cell_coord(qp.y, g.oy, g.inv_h, g.ny);
@@ -1389,7 +1393,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                 }
                 const int total = carry;
                 if (g.heavy_limit > 0 && total > g.heavy_limit) {  // wave-uniform
-                    if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = faillist[t];
+                    if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = fq;
                     break;
                 }
                 if (lane == 0) ro[nrows] = total;
@@ -1422,7 +1426,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
                     if (uniform(total) > g.heavy_limit) {
-                        if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = faillist[t];
+                        if (lane == 0) heavylist[atomicAdd(&gp->heavy_count, 1u)] = fq;
                         break;
                     }
                 }
@@ -1809,10 +1813,12 @@ struct BrickLaunch {
     float *mean_out;
     double *kth_out;
     unsigned *faillist;
+    unsigned *ring2;      // what knn_ring_fast hands on to knn_ring
     uint2 *extra;
     unsigned *deferred;
     unsigned *heavylist;
-    int64_t out_count;  // entries of mean_out (poisoned with NaN when the input is not finite)
+    int64_t out_count;    // entries of mean_out (poisoned with NaN when the input is not finite)
+    int64_t n_ref;        // reference points binned at this level (mean density for knn_ring_fast)
 };
 
 template <int KCAP, bool MF, bool NET>
@@ -1840,17 +1846,281 @@ static int launch_bricks(gsx_ctx *ctx, const BrickLaunch &a)
     return 0;
 }
 
+// ---------------------------------------------------------------- knn_ring_fast
+// First attempt at the queries knn_brick could not certify, before knn_ring's per-lane lists.  A failed query's k-th
+// neighbour is just beyond its brick's searched cells, i.e. 1..1.4 cell edges away.  So: ONE pass over the cells of the
+// 5x5x5 block around the query's cell that a ball of radius r_t reaches (r_t chosen so that ~5(k+1) points are expected
+// inside; second attempt with 1.9 cell edges, the most 2 cells certify), with a float32 filter at r_t (relative error of
+// d32 <= 3e-7) that moves the few dozen candidates that matter to LDS.  A 64-bin histogram of
+// their d32 isolates the ~k+2 that can be among the k+1 nearest; those are ranked exactly in float64 (rank = number of
+// candidates before mine).  If at least k+1 candidates are inside r_t, the k+1 nearest are among them and every point
+// within r_t was looked at: exact.  One wave per query, < 80 VGPRs (no per-lane lists): six waves per SIMD overlap
+// the dependent loads (list entry -> query -> row bounds -> candidates) of different queries.  The queries it cannot
+// finish (fewer than k+1 points within 1.9 cell edges, more than CAND inside r_t, heavy rings) go to a second list for
+// knn_ring -- appended per wave in batches, because same-address atomics cost ~11 ns each.
+#ifndef GSX_RING_FAST
+#define GSX_RING_FAST 1   // 0: knn_ring alone (A/B)
+#endif
+#ifndef GSX_RINGF_INFLIGHT
+#define GSX_RINGF_INFLIGHT 4
+#endif
+#ifndef GSX_RINGF_TARGET
+#define GSX_RINGF_TARGET 5.0   // candidates expected inside r_t, in units of k+1
+#endif
+#ifndef GSX_RINGF_WAVES
+#define GSX_RINGF_WAVES 6
+#endif
+constexpr int RINGF_ROWS = 25;   // 5 x 5 rows of 5 cells
+constexpr int RINGF_LEFT = 32;   // leftovers a wave collects before it appends them to the second list
+// histogram bin of a float32 squared distance d <= thr: two roundings of monotone operations, hence monotone in d
+// (bins uniform in d hold ~sqrt(d/thr) * 1.5 cnt / 64 candidates: one or two where the (k+1)-th lies)
+__device__ __forceinline__ int ringf_bin(float d32, float inv_thr)
+{
+    return min(63, (int)(d32 * inv_thr * 64.0f));
+}
+constexpr int ringf_cand(int kcap) { return kcap <= 17 ? 128 : (kcap <= 33 ? 256 : 512); }
+template <int KCAP>
+__global__ __launch_bounds__(BRICK_THREADS, KCAP <= 33 ? GSX_RINGF_WAVES : 3) void knn_ring_fast_kernel(
+    GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
+    const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, unsigned *__restrict__ ring2, int k, int q_begin,
+    int64_t n_ref, float *__restrict__ mean_out, double *__restrict__ kth_out)
+{
+    constexpr int CAND = ringf_cand(KCAP);
+    constexpr int NF = GSX_RINGF_INFLIGHT;
+    __shared__ double s_out[BRICK_THREADS / 64][KCAP];
+    __shared__ int s_rs[BRICK_THREADS / 64][RINGF_ROWS];
+    __shared__ int s_ro[BRICK_THREADS / 64][RINGF_ROWS + 1];
+    __shared__ float4 s_cand[BRICK_THREADS / 64][CAND];   // xyz + float32 squared distance
+    __shared__ float4 s_fin[BRICK_THREADS / 64][64];      // the candidates that are ranked exactly
+    __shared__ double s_cd[BRICK_THREADS / 64][64];
+    __shared__ int s_hist[BRICK_THREADS / 64][64];
+    __shared__ unsigned s_left[BRICK_THREADS / 64][RINGF_LEFT];
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    double *out = s_out[wv];
+    int *rs = s_rs[wv], *ro = s_ro[wv];
+    float4 *cand = s_cand[wv], *fin = s_fin[wv];
+    double *cd = s_cd[wv];
+    int *hist = s_hist[wv];
+    unsigned *left = s_left[wv];
+    const GridParams g = *gp;
+    if (g.bad_input) return;   // knn_ring fills the output with NaN
+    const int nfail = (int)g.fail_count;
+    const int kk = k + 1;
+    // r_t: ~5(k+1) points expected inside at the cloud's mean density, at most 1.9 cell edges (2 cells certify 1.998)
+    const double per_cell = (double)n_ref / (double)max(g.ncells, 1);
+    const double rt_max = 1.9 * g.hprime;
+    const double rt_first = __builtin_fmin(::cbrt(GSX_RINGF_TARGET * kk / (4.18879 * per_cell)) * g.hprime, rt_max);
+
+    int nleft = 0;   // wave-uniform
+    auto flush_left = [&]() __attribute__((always_inline)) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&gp->ring2_count, (unsigned)nleft);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        wave_sync();
+        if (lane < nleft) ring2[base + lane] = left[lane];
+        wave_sync();
+        nleft = 0;
+    };
+
+    WorkQueue wq;
+    wq_init(wq, gp->ringf_ctr, nfail, BRICK_THREADS / 64);
+    // the next query's list entry and point are fetched while the current one is being worked on: the chain
+    // entry -> point -> row bounds -> candidates is what a wave waits for
+    int t_next = uniform(wq_next(wq));
+    unsigned fq_next = t_next >= 0 ? faillist[t_next] : 0u;
+    float4 qp_next = t_next >= 0 ? qpts[fq_next] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (;;) {
+        if (t_next < 0) break;
+        const float4 qp = qp_next;
+        const unsigned fq = fq_next;
+        t_next = uniform(wq_next(wq));
+        fq_next = t_next >= 0 ? faillist[t_next] : 0u;   // consumed after this query's row bounds have arrived
+        bool fetched_next = false;
+        const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
+        const int cx = cell_coord(qp.x, g.ox, g.inv_h, g.nx);
+        const int cy = cell_coord(qp.y, g.oy, g.inv_h, g.ny);
+        const int cz = cell_coord(qp.z, g.oz, g.inv_h, g.nz);
+        const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
+        const int y0 = max(cy - 2, 0), y1 = min(cy + 2, g.ny - 1);
+        const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.nz - 1);
+        const int nyr = y1 - y0 + 1;
+        const int nrows = nyr * (z1 - z0 + 1);
+        const double ux = (qxd - (double)g.ox) * (double)g.inv_h, uy = (qyd - (double)g.oy) * (double)g.inv_h,
+                     uz = (qzd - (double)g.oz) * (double)g.inv_h;
+        bool solved = false;
+        double rt = rt_first;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2 && !solved; ++attempt, rt = rt_max) {
+            if (attempt == 1 && !(rt_first < rt_max)) break;
+            const float thr = (float)(rt * rt) * (1.0f + 1e-6f);
+            const float inv_thr = 1.0f / thr;
+            const double rtc = rt * (double)g.inv_h;   // r_t in cell units (<= 1.9)
+            // all row bounds in parallel (one lane per row), wave scan -> flat offsets.  Each row is trimmed to the cells
+            // the ball of radius r_t can reach (the kernel is bound by the candidate fetch: 37 cells instead of 125): in
+            // cell units a point of cell c lies in [c - 2.5e-4, c + 1 + 2.5e-4] (the f32 cell index is off by
+            // < 2.5e-4 cells, section 4.2), so with a slack of 1e-3 per side no point within r_t is missed.
+            int st = 0, len = 0;
+            if (lane < nrows) {
+                const int yy = y0 + lane % nyr, zz = z0 + lane / nyr;
+                const double dy = uy < yy - 1e-3 ? yy - 1e-3 - uy : (uy > yy + 1.001 ? uy - (yy + 1.001) : 0.0);
+                const double dz = uz < zz - 1e-3 ? zz - 1e-3 - uz : (uz > zz + 1.001 ? uz - (zz + 1.001) : 0.0);
+                const double rem = rtc * rtc - dy * dy - dz * dz;
+                if (rem >= 0.0) {
+                    const double dxc = __builtin_sqrt(rem) + 1e-3;
+                    const int xa = max(x0, (int)__builtin_floor(ux - dxc)), xb = min(x1, (int)__builtin_floor(ux + dxc));
+                    if (xa <= xb) {
+                        const int row = row_base(g, yy, zz);
+                        st = (int)rstart[row + xa];
+                        len = (int)rstart[row + xb + 1] - st;
+                    }
+                }
+            }
+            int inc = len;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                int o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (lane < nrows) {
+                rs[lane] = st;
+                ro[lane] = inc - len;
+            }
+            const int total = __shfl(inc, nrows - 1);
+            if (lane == 0) ro[nrows] = total;
+            hist[lane] = 0;
+            wave_sync();
+            if (!fetched_next) {
+                qp_next = t_next >= 0 ? qpts[fq_next] : qp;   // in flight together with this query's candidates
+                fetched_next = true;
+            }
+            if (g.heavy_limit > 0 && total > g.heavy_limit) break;   // wave-uniform: knn_ring routes it to knn_heavy
+            int cnt = 0, row = 0;
+            for (int f0 = 0; f0 < total; f0 += 64 * NF) {   // wave-uniform trip count, NF loads in flight per lane
+                float4 p[NF];
+                bool in[NF];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    const int f = f0 + 64 * u + lane;
+                    in[u] = f < total;
+                    if (in[u]) {
+                        while (f >= ro[row + 1]) ++row;
+                        p[u] = refs[rs[row] + (f - ro[row])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    bool acc = false;
+                    float d32 = 0.0f;
+                    if (in[u]) {
+                        const float dx = qp.x - p[u].x, dy = qp.y - p[u].y, dz = qp.z - p[u].z;
+                        d32 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        acc = d32 <= thr;
+                    }
+                    const unsigned long long bal = __ballot(acc);
+                    if (acc) {
+                        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                        if (pos < CAND) {
+                            p[u].w = d32;
+                            cand[pos] = p[u];
+                            atomicAdd(&hist[ringf_bin(d32, inv_thr)], 1);
+                        }
+                    }
+                    cnt += (int)__builtin_popcountll(bal);
+                }
+            }
+            wave_sync();
+            if (cnt > CAND) break;      // too dense around this query: knn_ring
+            if (cnt < kk) continue;     // too sparse: once more with the widest certifiable radius
+            // ---- the k+1 nearest are among the candidates of the first histogram bins that hold k+1 of them (bins are
+            // a monotone function of d32); thr2 = the largest d32 in those bins, and a candidate with
+            // d32 <= thr2 (1 + 1e-6) cannot be excluded (float32 error 3e-7 on either side)
+            int incl = hist[lane];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                int o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            const int bstar = (int)__builtin_ctzll(__ballot(incl >= kk));   // exists: the bins hold cnt >= kk candidates
+            float dmy[CAND / 64];
+            float m32 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < CAND / 64; ++u) {
+                const int j = lane + 64 * u;
+                dmy[u] = j < cnt ? cand[j].w : __builtin_inff();
+                if (j < cnt && ringf_bin(dmy[u], inv_thr) <= bstar) m32 = fmaxf(m32, dmy[u]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m32 = fmaxf(m32, __shfl_xor(m32, off));
+            const float thr2 = m32 * (1.0f + 1e-6f);
+            int cnt2 = 0;
+#pragma unroll
+            for (int u = 0; u < CAND / 64; ++u) {
+                const bool sel = dmy[u] <= thr2;   // (+inf for the lanes beyond cnt)
+                const unsigned long long bal = __ballot(sel);
+                if (sel) {
+                    const int pos = cnt2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (pos < 64) fin[pos] = cand[lane + 64 * u];
+                }
+                cnt2 += (int)__builtin_popcountll(bal);
+            }
+            wave_sync();
+            if (cnt2 > 64) break;   // a crowd of near-ties: knn_ring
+            double dme = __builtin_inf();
+            if (lane < cnt2) {
+                const float4 pp = fin[lane];
+                dme = dist2_f64(qxd, qyd, qzd, pp.x, pp.y, pp.z);
+                cd[lane] = dme;
+            }
+            wave_sync();
+            int rank = 0;
+#pragma unroll 4
+            for (int j = 0; j < cnt2; ++j) {   // exact: rank = candidates before mine (ties by position)
+                const double dj = cd[j];
+                rank += (dj < dme || (dj == dme && j < lane)) ? 1 : 0;
+            }
+            if (lane < cnt2 && rank < kk) out[rank] = dme;
+            wave_sync();
+            const double kth = out[kk - 1];
+            if (!(kth <= rt * rt)) continue;   // (the float32 filter admits a hair more than r_t: then r_t certifies nothing)
+            for (int i = lane; i < kk; i += 64) out[i] = __dsqrt_rn(out[i]);
+            wave_sync();
+            if (lane == 0) {   // out[0] = the query itself
+                double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
+                mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+            }
+            wave_sync();
+            solved = true;
+        }
+        if (!fetched_next) qp_next = t_next >= 0 ? qpts[fq_next] : qp;
+        if (!solved) {
+            if (lane == 0) left[nleft] = fq;
+            ++nleft;
+            if (nleft == RINGF_LEFT) flush_left();
+        }
+    }
+    if (nleft) flush_left();
+}
+
 template <int KCAP>
 static int launch_ring(gsx_ctx *ctx, const BrickLaunch &a)
 {
-    static int occ_ring = 0;
+    static int occ_ring = 0, occ_fast = 0;
     if (!occ_ring) {
         GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ring, knn_ring_kernel<KCAP>, BRICK_THREADS, 0));
         occ_ring = std::max(1, std::min(occ_ring, 8));
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, knn_ring_fast_kernel<KCAP>, BRICK_THREADS, 0));
+        occ_fast = std::max(1, std::min(occ_fast, 8));
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
+    const bool fast = GSX_RING_FAST && ctx->ring_fast;
+    if (fast)
+        hipLaunchKernelGGL((knn_ring_fast_kernel<KCAP>), dim3(ctx->num_cu * occ_fast), dim3(BRICK_THREADS), 0, ctx->stream, a.gp, a.refs,
+                           a.rstart, a.qpts, a.faillist, a.ring2, a.k, (int)a.q_begin, a.n_ref, a.mean_out, a.kth_out);
     hipLaunchKernelGGL((knn_ring_kernel<KCAP>), dim3(ctx->num_cu * occ_ring), dim3(BRICK_THREADS), 0, ctx->stream, a.gp, a.refs,
-                       a.rstart, a.qpts, a.faillist, a.k, (int)a.q_begin, a.mean_out, a.kth_out, a.heavylist, (int)a.out_count);
+                       a.rstart, a.qpts, fast ? a.ring2 : a.faillist, a.k, (int)a.q_begin, a.mean_out, a.kth_out, a.heavylist, (int)a.out_count,
+                       fast ? 1 : 0);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
     return 0;
@@ -1987,8 +2257,13 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     double pts_per_cell = ctx->grid_points_per_cell;
     if (!(pts_per_cell > 0.0)) {
         pts_per_cell = std::max(2.0, 0.47 * (double)(k + 1));
+        // a brick's queries must fit ONE 64-lane batch with a margin.  Fewer points per cell = fewer candidates per
+        // query in knn_brick but more queries for the ring kernels, which are cheap per query once tens of thousands
+        // of them keep every wave busy and latency-bound below that (profiles/r02_variants.txt: 10M k=16 is fastest at
+        // 54 / 8 cells, 1M at 58 / 8, 50M k=32 at 52-54 / 4)
+        const double fill = n_ref >= 4000000 ? 54.0 : 58.0;
         for (int cells = 8; cells >= 1; cells /= 2)
-            if (pts_per_cell * cells > 58.0 && pts_per_cell * cells <= 66.0) pts_per_cell = 58.0 / cells;
+            if (pts_per_cell * cells > fill && pts_per_cell * cells <= 66.0) pts_per_cell = fill / cells;
     }
     GSX_CHECK(w.packed.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(w.bucketpts.reserve(sizeof(float4) * (size_t)n_ref));
@@ -2002,7 +2277,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         GSX_HIP(hipMemsetAsync(w.gridparams.p, 0, sizeof(GridParams), ctx->stream));
     }
     GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
-    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * (size_t)std::max<int64_t>(q_count, 1)));
+    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * 2 * (size_t)std::max<int64_t>(q_count, 1)));   // fail list | knn_ring_fast's leftovers
     GSX_CHECK(w.extraitems.reserve(sizeof(uint2) * (size_t)(std::max(q_count, slab ? n_ref : q_count) / 64 + 64)));
     if (adaptive) {
         GSX_CHECK(w.deferred.reserve(sizeof(unsigned) * (size_t)(cap + 64)));  // nbricks <= ncells <= cap
@@ -2036,7 +2311,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
     BrickLaunch a{gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, kth_out, w.faillist.as<unsigned>(),
-                  w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>(), q_count};
+                  w.faillist.as<unsigned>() + std::max<int64_t>(q_count, 1),
+                  w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>(), q_count, n_ref};
     GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0, ctx->phase2_net != 0));
 
     const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;

@@ -35,9 +35,11 @@ struct GridParams {
     int heavy_limit;          // > 0: a knn_ring query whose ring holds more candidates than this is not scanned by its
                               // single wave but handed to knn_heavy (the whole chip scans the whole cloud for it)
     unsigned heavy_count;
+    unsigned ring2_count;     // queries knn_ring_fast left to knn_ring (its second list)
     unsigned brick_ctr[8 * 32];   // dynamic-tail counters, one per XCD, separate cache lines
     unsigned extra_ctr[8 * 32];
     unsigned ring_ctr[8 * 32];
+    unsigned ringf_ctr[8 * 32];
     // arrival tickets of the kernels whose last workgroup finishes the job of a former one-workgroup launch
     // (bbox_partial -> grid parameters, bucket_hist -> bucket scan); never touched by grid_params, self-resetting
     unsigned ticket_bbox, ticket_hist;

@@ -239,12 +239,13 @@ class HipSlabBackend:
 
 
 # ------------------------------------------------------------------------------------------ the step
-def pts_per_cell(k: int) -> float:
-    """the KNN grid's cell population (csrc/sor_grid.hip: knn_grid_level)"""
+def pts_per_cell(k: int, n: int = 0) -> float:
+    """the KNN grid's cell population for n reference points (csrc/sor_grid.hip: knn_grid_level)"""
     m = max(2.0, 0.47 * (k + 1))
+    fill = 54.0 if n >= 4_000_000 else 58.0
     for cells in (8, 4, 2, 1):
-        if 58.0 < m * cells <= 66.0:
-            m = 58.0 / cells
+        if fill < m * cells <= 66.0:
+            m = fill / cells
     return m
 
 
@@ -325,7 +326,7 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
         raise ValueError("slab_sor needs equally sized index shards (%d points in total, %d x %d expected)" % (n_total, G, n_local))
     ext64 = ext.astype(np.float64)
     nd = int((ext64 > 0).sum())
-    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k) / max(n_total, 1) if nd else 0.0
+    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k, n_total // max(G, 1)) / max(n_total, 1) if nd else 0.0
     h_est = per ** (1.0 / nd) if nd else 0.0
     bw = (float(hi) - float(lo)) / BINS if hi > lo else 0.0
     halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS

@@ -114,6 +114,7 @@ def main():
         exchange["path"] = "replicated (requested)"
 
     def barrier():
+        ctx.synchronize()          # the library's stream (its RCCL calls too) is drained before torch's communicator runs
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
