@@ -259,12 +259,20 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
     // serialised 7 round trips and made this one-wave kernel 9 us, 2 % of the 1M-splat step)
     float v[7] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(),
                   -__builtin_inff(), -__builtin_inff()};
-    for (int i = lane; i < nparts; i += 64) {
-        float t[7];
+    // (written by other workgroups: device-scope loads, which the compiler keeps in program order -- so eight
+    // partial boxes are requested back to back before the first one is consumed: 2 round trips for 1024 parts, not 16)
+    for (int i0 = lane; i0 < nparts; i0 += 64 * 8) {
+        float t[8][7];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) t[a] = __hip_atomic_load(&part[i * 7 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by other workgroups
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u < nparts ? i0 + 64 * u : i0;
 #pragma unroll
-        for (int a = 0; a < 7; ++a) v[a] = a < 3 ? fminf(v[a], t[a]) : fmaxf(v[a], t[a]);
+            for (int a = 0; a < 7; ++a) t[u][a] = __hip_atomic_load(&part[i * 7 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int a = 0; a < 7; ++a) v[a] = a < 3 ? fminf(v[a], t[u][a]) : fmaxf(v[a], t[u][a]);
     }
 #pragma unroll
     for (int a = 0; a < 7; ++a)
@@ -496,10 +504,20 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigne
 __device__ void bucket_scan_body(int nb, unsigned *bk_cnt, unsigned *bk_start, unsigned *bk_cursor)
 {
     __shared__ unsigned wsum[4];
+    static_assert(MAX_BUCKETS <= 256 * 16, "bucket_scan_body preloads 16 values per thread");
+    unsigned vals[16];   // every bucket size requested before the first scan round (one round trip, not nb/256)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = 256 * u + (int)threadIdx.x;
+        vals[u] = i < nb ? __hip_atomic_load(&bk_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
     unsigned carry = 0;
-    for (int b = 0; b < nb; b += 256) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int b = 256 * u;
+        if (b >= nb) break;
         const int i = b + threadIdx.x;
-        const unsigned v = i < nb ? __hip_atomic_load(&bk_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned v = vals[u];
         unsigned tot;
         const unsigned ex = block_exclusive_scan_256(v, &tot, wsum);
         if (i < nb) {
