@@ -779,6 +779,9 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #ifndef GSX_NET_WAVES17
 #define GSX_NET_WAVES17 3
 #endif
+#ifndef GSX_NET_WAVES33
+#define GSX_NET_WAVES33 2   // 50M k=32: 17.35 vs 17.72 ms at 3 (192 B of scratch per lane there)
+#endif
 #ifndef GSX_NET_HB
 #define GSX_NET_HB 4
 #endif
@@ -792,7 +795,7 @@ constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
     // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
-    if (net) return kcap <= 9 ? 5 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? 3 : 2));
+    if (net) return kcap <= 9 ? 5 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? GSX_NET_WAVES33 : 2));
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 

@@ -29,6 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # G wave64 instructions per second (MI355X: 256 CUs, 4 SIMD16 each, 2.4 GHz)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_SLOTS_PER_S = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 
@@ -241,18 +242,28 @@ def main():
     if pmc and "valu_busy_frac" in pmc:
         valu = {"busy_frac": pmc["valu_busy_frac"], "insts_per_launch": pmc.get("valu_insts"),
                 "kind": "static: rocprofv3 --pmc pass of this build committed under profiles/ (%s), not measured in this run" % pmc.get("source", "pmc_latest.json")}
-    roofline = {
-        # the contract's fields: algorithmic HBM bytes of one launch / its HIP-event duration vs the 8 TB/s peak
-        "bound": "valu", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json "
-                         "(fetch as counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
-        "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_per_splat": bytes_per_splat,
-        "kernel_ms": round(knn_ms, 4),
-        "binding_resource": {"name": "VALU issue (f32 filter assembly + f64 exact distances, selection network, sqrt)",
-                             "valu": valu,
-                             "note": "achieved/peak/frac above are the HBM figures BASELINE.json's metric asks for; the "
-                                     "kernel is limited by VALU issue, not by HBM (DESIGN.md section 5)"}}
+    hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+           "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_per_splat": bytes_per_splat, "traffic": traffic,
+           "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json "
+                            "(fetch as counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
+           "note": "the figures BASELINE.json's metric asks for: algorithmic HBM bytes of one launch / its HIP-event duration vs 8 TB/s"}
+    if valu and valu.get("insts_per_launch") and knn_ms > 0:
+        # the binding resource: VALU issue.  One wave64 instruction occupies its SIMD16 for
+        # >= 4 cycles, so the chip issues at most CUs x 4 SIMDs x clock / 4 wave-instructions per second.  The
+        # instruction count of a launch is a property of (build, cloud) -- taken from the committed PMC pass and labelled
+        # static -- the duration is this run's HIP-event average.
+        peak_ginst = VALU_PEAK_GINST
+        ach_ginst = valu["insts_per_launch"] / (knn_ms * 1e-3) / 1e9
+        roofline = {"bound": "valu", "kernel": kernel, "achieved": round(ach_ginst, 2), "peak": peak_ginst,
+                    "unit": "G wave-instructions/s", "frac": round(ach_ginst / peak_ginst, 4), "traffic": traffic,
+                    "kernel_ms": round(knn_ms, 4),
+                    "valu": dict(valu, name="VALU issue (f32 filter assembly + f64 exact distances, selection network, sqrt)",
+                                 peak_note="256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"),
+                    "hbm": hbm}
+    else:   # multi-GPU runs and configurations without a committed PMC pass: the HBM figures only
+        roofline = dict(hbm, bound="hbm", kernel=kernel, kernel_ms=round(knn_ms, 4),
+                        note="HBM figures only (no committed instruction count for this configuration); the kernel itself is "
+                             "bound by VALU issue, see the N=1 line of the default configuration")
 
     out = {
         "metric": "Msplats/sec SOR k=%d" % args.k, "value": round(value, 2), "unit": "Msplats/s",
