@@ -74,7 +74,7 @@ SIGNATURES = {
     "gsx_comm_all_to_all_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _I]),
     "gsx_slab_bbox_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
     "gsx_slab_hist_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
-    "gsx_slab_partition_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _P]),
+    "gsx_slab_partition_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _P, _P]),
     "gsx_sor_knn_slab_dev": (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     "gsx_slab_certify_dev": (_I, [_P, _P, _I64, _I64, _P, C.c_float, C.c_float, _P]),
     "gsx_slab_unpermute_dev": (_I, [_P, _P, _P, _I64, _P]),

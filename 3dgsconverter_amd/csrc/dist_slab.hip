@@ -181,6 +181,7 @@ struct SlabPlan {
     int cut[SLAB_MAX_RANKS + 1];     // slab s OWNS bins [cut[s], cut[s+1])
     int halo_bins;                   // ... and RECEIVES (reference-only) bins [cut[s] - halo_bins, cut[s+1] + halo_bins):
                                      // membership by bin index, so every count follows from the histograms alone
+    unsigned off[2 * SLAB_MAX_RANKS];  // first row of every slot in the send buffer (slot 2s: owned by s, 2s+1: halo copy for s)
 };
 
 // Per 2048-point tile (points stay in registers): count the rows per slot (slot 2s = owned by slab s, 2s+1 =
@@ -189,7 +190,7 @@ struct SlabPlan {
 // slabs (slabs thinner than the halo).
 __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, int64_t stride, int64_t n,
-                                                             SlabPlan plan, unsigned *__restrict__ cursor /* [2*world] */,
+                                                             SlabPlan plan, unsigned *__restrict__ cursor /* [2*world], zeroed: rows handed out per slot */,
                                                              float *__restrict__ send /* rows of 3 floats */,
                                                              unsigned *__restrict__ send_src /* local index of each OWN row */)
 {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
     __syncthreads();
     if (threadIdx.x < nslot) {
         const unsigned c = s_cnt[threadIdx.x];
-        s_base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
+        s_base[threadIdx.x] = c ? plan.off[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], c) : 0u;
         s_cnt[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -371,17 +372,21 @@ int gsx_comm_all_to_all_v(gsx_ctx *c, const void *send_dev, const int64_t *send_
     GSX_CHECK(dtype_of(elem_bytes == 12 ? 4 : elem_bytes, &dt));
     const size_t mul = elem_bytes == 12 ? 3 : 1;   // rows of 3 floats travel as floats
     const size_t eb = elem_bytes;
-    GSX_RCCL(g_rccl.GroupStart());
-    for (int p = 0; p < m->world; ++p) {
-        if (p == m->rank) continue;
-        if (send_cnt[p] > 0)
-            GSX_RCCL(g_rccl.Send(static_cast<const char *>(send_dev) + eb * (size_t)send_off[p], (size_t)send_cnt[p] * mul, dt, p,
-                                 m->comm, c->stream));
-        if (recv_cnt[p] > 0)
-            GSX_RCCL(g_rccl.Recv(static_cast<char *>(recv_dev) + eb * (size_t)recv_off[p], (size_t)recv_cnt[p] * mul, dt, p,
-                                 m->comm, c->stream));
+    bool remote = false;
+    for (int p = 0; p < m->world; ++p) remote |= p != m->rank && (send_cnt[p] > 0 || recv_cnt[p] > 0);
+    if (remote) {   // (an empty group still costs RCCL bookkeeping)
+        GSX_RCCL(g_rccl.GroupStart());
+        for (int p = 0; p < m->world; ++p) {
+            if (p == m->rank) continue;
+            if (send_cnt[p] > 0)
+                GSX_RCCL(g_rccl.Send(static_cast<const char *>(send_dev) + eb * (size_t)send_off[p], (size_t)send_cnt[p] * mul, dt, p,
+                                     m->comm, c->stream));
+            if (recv_cnt[p] > 0)
+                GSX_RCCL(g_rccl.Recv(static_cast<char *>(recv_dev) + eb * (size_t)recv_off[p], (size_t)recv_cnt[p] * mul, dt, p,
+                                     m->comm, c->stream));
+        }
+        GSX_RCCL(g_rccl.GroupEnd());
     }
-    GSX_RCCL(g_rccl.GroupEnd());
     const int me = m->rank;
     if (send_cnt[me] != recv_cnt[me]) GSX_FAIL("gsx_comm_all_to_all_v: local block sizes differ");
     if (send_cnt[me] > 0)
@@ -422,15 +427,16 @@ int gsx_slab_hist_dev(gsx_ctx *c, const float *x, const float *y, const float *z
 
 /*
  * plan (host): world, axis, [lo, hi] = the binned range (the all-reduced bbox words of that axis), cut[world+1], halo_bins.
- * Rows (3 floats) are written to send_dev at the row cursors cursor_dev[2*world] (start offsets, advanced): slot 2s = rows
+ * Rows (3 floats) are written to send_dev from start_off[2*world] (HOST array: first row of every slot; cursor_dev[2*world]
+ * is device scratch for the rows handed out so far, zeroed here): slot 2s = rows
  * owned by slab s, slot 2s+1 = reference-only copies for slab s; send_src_dev[row] = local index of every own row.
  * planes_out (host, 2*world floats, nullable): coordinates between which slab s is guaranteed to hold EVERY point.
  */
 int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, int world,
-                           int axis, float lo, float hi, const int32_t *cut, int halo_bins, uint32_t *cursor_dev,
-                           float *send_dev, uint32_t *send_src_dev, float *planes_out)
+                           int axis, float lo, float hi, const int32_t *cut, int halo_bins, const uint32_t *start_off,
+                           uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev, float *planes_out)
 {
-    if (!c || !x || !y || !z || !cut || world < 1 || world > SLAB_MAX_RANKS || axis < 0 || axis > 2 || halo_bins < 0)
+    if (!c || !x || !y || !z || !cut || !start_off || world < 1 || world > SLAB_MAX_RANKS || axis < 0 || axis > 2 || halo_bins < 0)
         GSX_FAIL("gsx_slab_partition_dev: bad arguments");
     GSX_HIP(hipSetDevice(c->device));
     SlabPlan p;
@@ -440,6 +446,7 @@ int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const flo
     p.inv_w = hi > lo ? (float)SLAB_BINS / (hi - lo) : 0.0f;
     p.halo_bins = halo_bins;
     for (int s = 0; s <= world; ++s) p.cut[s] = cut[s];
+    for (int s = 0; s < 2 * world; ++s) p.off[s] = start_off[s];
     if (planes_out) {
         // slab s holds every point whose bin is in [cut[s] - halo_bins, cut[s+1] + halo_bins).  bin(c) is a monotone f32
         // function of c whose steps sit within ~1e-3 of a bin of lo + b * bw: half a bin inside is safely inside.
@@ -452,6 +459,7 @@ int gsx_slab_partition_dev(gsx_ctx *c, const float *x, const float *y, const flo
     }
     if (n <= 0) return 0;
     if (!cursor_dev || !send_dev || !send_src_dev) GSX_FAIL("gsx_slab_partition_dev: null buffer");
+    GSX_HIP(hipMemsetAsync(cursor_dev, 0, sizeof(uint32_t) * 2 * world, c->stream));
     hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n, 2048)), dim3(256), 0, c->stream, x, y, z, stride, n, p, cursor_dev,
                        send_dev, send_src_dev);
     GSX_HIP(hipGetLastError());
@@ -497,7 +505,7 @@ int gsx_slab_certify_dev(gsx_ctx *c, const float *coord, int64_t stride, int64_t
 {
     if (!c || !coord || !kth_d2_dev || !n_uncertain_dev) GSX_FAIL("gsx_slab_certify_dev: null argument");
     GSX_HIP(hipSetDevice(c->device));
-    GSX_HIP(hipMemsetAsync(n_uncertain_dev, 0, sizeof(uint32_t), c->stream));
+    GSX_HIP(hipMemsetAsync(n_uncertain_dev, 0, 2 * sizeof(uint32_t), c->stream));   // 8 bytes: the count is all-reduced as an int64
     if (n_own <= 0) return 0;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_own, 1024), (int64_t)c->num_cu * 8));
     hipLaunchKernelGGL(slab_certify_kernel, dim3(blocks), dim3(256), 0, c->stream, coord, stride, n_own, kth_d2_dev, open_lo,

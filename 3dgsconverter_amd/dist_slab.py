@@ -200,12 +200,14 @@ class HipSlabBackend:
         p = rows.ptr
         self._chk(self.lib.gsx_slab_hist_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), bbox7.ptr, hist.ptr), "gsx_slab_hist_dev")
 
-    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, cursor, send, send_src):
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, start_off, cursor, send, send_src):
+        """start_off: first row of every slot of the send buffer (2*world, host); cursor: device scratch"""
         p = rows.ptr
         cuts = (C.c_int32 * (world + 1))(*[int(c) for c in cut])
+        offs = (C.c_uint32 * (2 * world))(*[int(o) for o in start_off])
         planes = (C.c_float * (2 * world))()
         self._chk(self.lib.gsx_slab_partition_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), int(world), int(axis), float(lo),
-                                                  float(hi), cuts, int(halo_bins), cursor.ptr, send.ptr, send_src.ptr, planes),
+                                                  float(hi), cuts, int(halo_bins), offs, cursor.ptr, send.ptr, send_src.ptr, planes),
                   "gsx_slab_partition_dev")
         return np.array(planes[:], dtype=np.float32).reshape(world, 2)
 
@@ -298,20 +300,21 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     n_local = int(n_local)
     if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):
         raise ValueError("slab_sor: index shards must hold a multiple of 4 and at least 8192 points (got %d)" % n_local)
-    # ---- 1. bounding box (device-resident), 2. histogram of the longest axis; all-gathered: cuts AND every row count
-    b7 = be.buf("bbox", 32)
+    # ---- 1. bounding box (device-resident), 2. histogram of the longest axis; all-gathered: cuts AND every row count.
+    # Box and histograms share one buffer, so the step's host synchronisation is ONE download.
+    plan_in = be.buf("plan_in", 32 + 4 * BINS * G)
+    b7 = be.at(plan_in, 0)
     be.bbox(rows, n_local, b7)
     if G > 1:
         comm.all_reduce(b7, 7, KIND_F32_MAX)
-    hist = be.buf("hist", 4 * BINS)
-    be.hist(rows, n_local, b7, hist)
-    allhist_buf = be.buf("allhist", 4 * BINS * G)
-    if G > 1:
-        comm.all_gather(hist, allhist_buf, 4 * BINS)
+        hist = be.buf("hist", 4 * BINS)
+        be.hist(rows, n_local, b7, hist)
+        comm.all_gather(hist, be.at(plan_in, 32), 4 * BINS)
     else:
-        allhist_buf = hist
-    hb = be.to_host(b7, np.float32, 7)                                         # <- the step's host synchronisation
-    allhist = be.to_host(allhist_buf, np.uint32, BINS * G).reshape(G, BINS)
+        be.hist(rows, n_local, b7, be.at(plan_in, 32))
+    words = be.to_host(plan_in, np.uint32, 8 + BINS * G)                       # <- the step's host synchronisation
+    hb = words[:7].view(np.float32)
+    allhist = words[8:].reshape(G, BINS)
     if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
         raise ValueError("sor: coordinates are not finite (NaN/inf)")
     ext = hb[3:6] + hb[:3]                                                     # float32, like the device (slab_axis)
@@ -340,10 +343,9 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     cursor = be.buf("cursor", 4 * 2 * G)
     cur = np.empty(2 * G, np.uint32)
     cur[0::2], cur[1::2] = own_off, halo_off
-    be.from_host(cursor, cur)
     send = be.buf("send", 12 * max(n_send, 1))
     send_src = be.buf("send_src", 4 * max(n_local, 1))
-    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_bins, cursor, send, send_src)
+    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_bins, cur, cursor, send, send_src)
     in_own, in_halo = own[:, r], halo[:, r]                                    # rows every source sends me
     n_own, n_halo = int(in_own.sum()), int(in_halo.sum())
     r_own_off = np.concatenate([[0], np.cumsum(in_own)[:-1]])
@@ -357,9 +359,10 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     if n_own:
         be.knn_slab(slab, n_own, n_halo, k, md_slab, kth)
     unc = be.buf("unc", 8)
-    be.zero(unc, 8)
     if n_own:
-        be.certify(slab, axis, n_own, kth, planes[r, 0], planes[r, 1], unc)
+        be.certify(slab, axis, n_own, kth, planes[r, 0], planes[r, 1], unc)   # (zeroes the counter itself)
+    else:
+        be.zero(unc, 8)
     if G > 1:
         comm.all_reduce(unc, 1, KIND_I64_SUM)
     # ---- 6. mean distances back to the index owners, original order

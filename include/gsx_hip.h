@@ -204,18 +204,21 @@ int gsx_slab_bbox_dev(gsx_ctx *ctx, const float *x, const float *y, const float 
 int gsx_slab_hist_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
                       const float *bbox7_dev, uint32_t *hist4096_dev);
 /* Slab s OWNS the bins [cut[s], cut[s+1]) of the axis range [lo, hi] and also receives, as REFERENCE-ONLY rows, the
- * bins within halo_bins of them.  Rows (3 floats) are written to send_dev at the row cursors cursor_dev[2*world]
- * (slot 2s: owned by slab s, slot 2s+1: halo copies for slab s; advanced), send_src_dev[row] = local index of each own
- * row.  planes_out (host, 2*world floats, nullable): coordinates between which slab s holds EVERY point of the cloud. */
+ * bins within halo_bins of them.  Rows (3 floats) are written to send_dev starting at start_off[2*world] (HOST array:
+ * first row of slot 2s = rows owned by slab s, slot 2s+1 = halo copies for slab s; cursor_dev[2*world] is device scratch,
+ * zeroed by the call), send_src_dev[row] = local index of each own row.  planes_out (host, 2*world floats, nullable):
+ * coordinates between which slab s holds EVERY point of the cloud. */
 int gsx_slab_partition_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
                            int world, int axis, float lo, float hi, const int32_t *cut, int halo_bins,
-                           uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev, float *planes_out);
+                           const uint32_t *start_off, uint32_t *cursor_dev, float *send_dev, uint32_t *send_src_dev,
+                           float *planes_out);
 /* exact KNN mean distance of the first n_own rows against all n_own + n_halo rows (the halo rows are never
  * queries); kth_d2_dev[i] = squared distance of query i's (k+1)-th neighbour INCLUDING itself, i.e. its k-th other */
 int gsx_sor_knn_slab_dev(gsx_ctx *ctx, const float *rows_dev, int64_t n_own, int64_t n_halo, int k,
                          float *mean_out_dev, double *kth_d2_dev);
 /* *n_uncertain_dev = number of queries whose k-th neighbour is not provably among the rows this rank holds:
- * kth_d2 > min(coord - open_lo, open_hi - coord)^2 (open_* = the slab's planes_out entries, +-inf at the cloud's ends) */
+ * kth_d2 > min(coord - open_lo, open_hi - coord)^2 (open_* = the slab's planes_out entries, +-inf at the cloud's ends).
+ * The counter is 8 bytes (uint32 count + a zeroed upper word, so that it can be all-reduced as an int64); set by the call */
 int gsx_slab_certify_dev(gsx_ctx *ctx, const float *coord, int64_t stride, int64_t n_own, const double *kth_d2_dev,
                          float open_lo, float open_hi, uint32_t *n_uncertain_dev);
 /* out_dev[send_src_dev[p]] = recv_dev[p]: mean distances come back in the order the rows were sent */

@@ -94,7 +94,7 @@ class NumpySlabBackend:
         c = rows.view(np.float32, 3 * n).reshape(n, 3)[:, axis]
         hist.view(np.uint32, BINS)[:] = np.bincount(self._bin(c, lo, hi), minlength=BINS)
 
-    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, cursor, send, send_src):
+    def partition(self, rows, n, world, axis, lo, hi, cut, halo_bins, start_off, cursor, send, send_src):
         x = rows.view(np.float32, 3 * n).reshape(n, 3)
         b = self._bin(x[:, axis], lo, hi)
         owner = np.searchsorted(np.asarray(cut[1:world], dtype=np.int64), b, side="right")
@@ -102,6 +102,7 @@ class NumpySlabBackend:
         bw = (hi64 - lo64) / BINS if hi > lo else 0.0
         pl = np.empty((world, 2), np.float32)
         cur = cursor.view(np.uint32, 2 * world)
+        cur[:] = np.asarray(start_off, dtype=np.uint32)
         out = send.view(np.float32, 3 * (send.nbytes // 12)).reshape(-1, 3)
         src = send_src.view(np.uint32, n)
         for s in range(world):
