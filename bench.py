@@ -153,6 +153,30 @@ def main():
                     compute.set_adaptive(True)     # the clouds that get here are the ones the adaptive grid exists for
             return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
 
+        if world > 1 and exchange["path"] == "slab" and not exchange.get("cross_checked"):
+            # the slab exchange and the replicated one (all-gather of the rows, every rank bins everything) must agree
+            # bit for bit -- statistics and this rank's survivor mask -- before the slab path is what gets timed
+            ref = gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
+            ok = 1
+            try:
+                got = step()
+                if not isinstance(got, _SlabRes):
+                    ok = 1   # the certificate already sent this cloud to the replicated path
+                else:
+                    same_stats = bool(np.array_equal(got.stats.numpy().view(np.uint32), ref.stats.cpu().numpy().view(np.uint32)[:3]))
+                    same_mask = bool(np.array_equal(got.mask_local.numpy().astype(bool), ref.mask_local.cpu().numpy().astype(bool)))
+                    ok = 1 if (same_stats and same_mask) else 0
+            except gslab.SlabUncertain:
+                ok = 1
+            except Exception as e:   # noqa: BLE001 -- anything the exchange raises on this rank
+                sys.stderr.write("[bench] rank %d: slab exchange failed its cross-check: %r\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                exchange["path"] = "replicated (slab exchange disagreed with the replicated exchange on this cloud)"
+            exchange["cross_checked"] = True
+            del ref
         for _ in range(warmup):
             res = step()
         barrier()
