@@ -621,6 +621,54 @@ __global__ __launch_bounds__(256) void kmeans_centroid_reduce_kernel(const float
     if (threadIdx.x == 0) counts[c] = 0u;
 }
 
+// Segmented-sum update (default): every wave takes 64 CONSECUTIVE entries of the sorted-by-label permutation -- rows of
+// one or two clusters -- reads the rows coalesced (lanes = dimensions, 16 in flight), and adds its float64 partial sums
+// to the cluster's accumulators when the label changes: perfectly balanced whatever the cluster sizes are (one workgroup
+// per centroid, above, runs as long as its largest cluster and reads through one CU), ~2 x 45 float64 atomics per wave.
+// kmeans_finalize_reset_kernel divides and re-zeroes.
+#ifndef GSX_KM_SEGSUM
+#define GSX_KM_SEGSUM 1
+#endif
+__global__ __launch_bounds__(256) void kmeans_segment_sum_kernel(const float *__restrict__ data, int D,
+                                                                 const unsigned *__restrict__ perm,
+                                                                 const unsigned *__restrict__ starts,
+                                                                 const unsigned *__restrict__ counts, int k,
+                                                                 const int32_t *__restrict__ labels, double *__restrict__ sums)
+{
+    const int64_t n = (int64_t)starts[k - 1] + counts[k - 1];   // rows with a label (unassignable rows are not in the permutation)
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w * 64 < n; w += nw) {
+        const int64_t j0 = w * 64;
+        const int m = (int)((n - j0) < 64 ? (n - j0) : 64);
+        const unsigned my_row = lane < m ? perm[j0 + lane] : 0u;
+        const int my_lab = lane < m ? labels[my_row] : -1;
+        int cur = __builtin_amdgcn_readfirstlane(my_lab);
+        double acc = 0.0;
+        for (int i0 = 0; i0 < m; i0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const unsigned row = (unsigned)__shfl((int)my_row, (i0 + u) & 63);
+                v[u] = (i0 + u < m && lane < D) ? data[(int64_t)row * D + lane] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (i0 + u < m) {   // wave-uniform
+                    const int lab = __shfl(my_lab, (i0 + u) & 63);
+                    if (lab != cur) {
+                        if (lane < D && cur >= 0) unsafeAtomicAdd(&sums[(int64_t)cur * D + lane], acc);
+                        acc = 0.0;
+                        cur = lab;
+                    }
+                    acc += (double)v[u];
+                }
+            }
+        }
+        if (lane < D && cur >= 0) unsafeAtomicAdd(&sums[(int64_t)cur * D + lane], acc);
+    }
+}
+
 // any D (slow path): coordinates re-read from memory
 __global__ __launch_bounds__(256) void kmeans_assign_generic_kernel(const float *__restrict__ data, int64_t n, int D,
                                                                     const float *__restrict__ cent, int k,
@@ -727,7 +775,8 @@ static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const floa
 }
 
 template <int D>
-static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float *cent, int k, int32_t *labels, unsigned *counts)
+static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float *cent, int k, int32_t *labels, double *sums,
+                                unsigned *counts)
 {
     constexpr int NS = km_dp(D) / 16;
     const int ktiles = (k + 31) / 32;
@@ -756,7 +805,13 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
     hipLaunchKernelGGL(kmeans_label_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, k, starts, cursor);
     hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
                        labels, n, k, cursor, list);
-    hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
+    if (GSX_KM_SEGSUM && D <= 64) {
+        const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 256), (int64_t)c->num_cu * 8));
+        hipLaunchKernelGGL(kmeans_segment_sum_kernel, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+        hipLaunchKernelGGL(kmeans_finalize_reset_kernel, dim3(k), dim3(64), 0, c->stream, sums, counts, D, cent);
+    } else {
+        hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
+    }
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(c, GSX_T_KMEANS_UPDATE));
     return 0;
@@ -771,9 +826,9 @@ static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, float 
     if (c->kmeans_mfma && k >= 64 && (d == 9 || d == 24 || d == 45)) {
         // matrix-core filter + exact certificate (identical labels), update by segmented reduction: the whole iteration
         *updated = true;
-        if (d == 9) return launch_assign_mfma_t<9>(c, data, n, cent, k, labels, counts);
-        if (d == 24) return launch_assign_mfma_t<24>(c, data, n, cent, k, labels, counts);
-        return launch_assign_mfma_t<45>(c, data, n, cent, k, labels, counts);
+        if (d == 9) return launch_assign_mfma_t<9>(c, data, n, cent, k, labels, sums, counts);
+        if (d == 24) return launch_assign_mfma_t<24>(c, data, n, cent, k, labels, sums, counts);
+        return launch_assign_mfma_t<45>(c, data, n, cent, k, labels, sums, counts);
     }
     switch (d) {
         case 1: launch_assign_t<1>(c, data, n, cent, k, labels, sums, counts); break;
