@@ -202,11 +202,49 @@ def host_compact_rows(rows: np.ndarray, mask: np.ndarray) -> np.ndarray:
     return out
 
 
+_numpy_reduction_checked = None
+
+
+def numpy_reduction_selfcheck(ctx: "Context | None" = None) -> bool:
+    """The SOR threshold is bit-exact only if the device reproduces THIS process's numpy float32 reductions
+    (csrc/sor_stats.hip restates numpy 2.2's rule: 8192-element buffer pieces added sequentially, pairwise inside a piece).
+    The reference does not pin numpy, so the rule is probed once per process: np.mean / np.std of a 20 001-element
+    float32 array with a wide dynamic range against gsx_sor_stats_dev.  A mismatch is reported with a warning (masks can
+    then differ from this numpy's for mean distances within one ulp of the threshold); nothing falls back."""
+    global _numpy_reduction_checked
+    if _numpy_reduction_checked is not None:
+        return _numpy_reduction_checked
+    import warnings
+    rng = np.random.default_rng(8192)
+    a = (rng.standard_normal(20001) * np.exp(rng.uniform(-6, 6, 20001))).astype(np.float32)
+    a = np.abs(a) + np.float32(1e-3)
+    own = ctx is None
+    ctx = ctx or Context(0)
+    try:
+        d, st = ctx.alloc(a.nbytes + 16).upload(a), ctx.alloc(16)
+        ctx.sor_stats(d.ptr, len(a), 1.5, st.ptr)
+        got = st.download(np.float32, 3)
+        d.free()
+        st.free()
+    finally:
+        if own:
+            ctx.close()
+    m, sd = np.mean(a), np.std(a)
+    want = np.array([m, sd, m + 1.5 * sd], dtype=np.float32)
+    _numpy_reduction_checked = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    if not _numpy_reduction_checked:
+        warnings.warn("numpy %s reduces float32 arrays in a different order than the one libgsx_hip reproduces (numpy 2.2: "
+                      "8192-element pieces, pairwise inside): SOR thresholds can differ from this numpy's in the last bit "
+                      "(device %r, numpy %r)" % (np.__version__, got.tolist(), want.tolist()), RuntimeWarning, stacklevel=2)
+    return _numpy_reduction_checked
+
+
 def sor_filter(xyz, k: int, threshold_factor: float, algo: int = KNN_AUTO, want_mean: bool = True,
                want_info: bool = False):
     """Whole SOR on one GPU from host buffers (C ABI gsx_sor_filter).
     -> dict(mask bool[N], mean_dists f32[N] | None, mean, std, threshold (np.float32), info | None)"""
     lib = require_hip()
+    numpy_reduction_selfcheck()
     keep, px, py, pz, stride, n = _xyz_pointers(xyz)
     mask = np.empty(n, dtype=np.uint8)
     mean = np.empty(n, dtype=np.float32) if want_mean else None
@@ -555,6 +593,7 @@ class DeviceChain:
             dev.free()
 
     def sor_keep(self, k: int, threshold_factor: float):
+        numpy_reduction_selfcheck(self.ctx)
         n = self.n
         md = self.ctx.alloc(4 * n + 16)
         st = self.ctx.alloc(16)
