@@ -227,6 +227,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
 #endif
     } else if (!strcmp(name, "kmeans_mfma")) {
         c->kmeans_mfma = value != 0.0;
+    } else if (!strcmp(name, "kmeans_cs")) {
+        c->kmeans_cs = value != 0.0;
     } else if (!strcmp(name, "ring_fast")) {
         c->ring_fast = value != 0.0;
     } else if (!strcmp(name, "phase2_net")) {

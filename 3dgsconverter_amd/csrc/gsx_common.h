@@ -109,6 +109,7 @@ struct gsx_ctx {
     int adaptive = 0;    // 1: bricks too populated for the grid are re-run on a finer grid (one host sync per call)
     int defer_words = 64;
     int kmeans_mfma = 1;  // K-Means assign for D in {9,24,45}, K >= 64: 1 = matrix-core filter + exact certificate, 0 = packed-f32 VALU scan
+    int kmeans_cs = 1;   // centroid-stationary matrix-core assign for K <= 1024 (0: the streaming kernel; A/B)
     int ring_fast = 1;   // knn_ring_fast before knn_ring (0: A/B only)
     int phase2_net = 1;  // knn_brick phase 2: 1 = sorting-network block selection (TopNet), 0 = per-candidate bubble insert (A/B only)
     int filter_mfma = 1; // knn_brick phase 1: 1 = bf16-split MFMA filter for batches whose mask words fit LDS, 0 = scalar-load f32 VALU filter only

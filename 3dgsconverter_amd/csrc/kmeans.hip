@@ -438,6 +438,8 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
     }
 }
 
+#include "kmeans_cs.h"
+
 // the points the matrix-core filter could not certify (near ties: ~0.3 % on SOG data): the reference's arithmetic
 // (gpu_ops.py:57-73) over ALL centroids, one wave per point; lane = centroids lane, lane + 64, ...; the lowest index wins
 // inside a lane by the strict '<' and across lanes by the merge.  D is a compile-time constant so that a lane's 45 loads
@@ -789,10 +791,17 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
     GSX_HIP(hipMemsetAsync(meta, 0, sizeof(unsigned) * 16, c->stream));
     hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
                        reinterpret_cast<float *>(meta));
-    const int64_t tiles = div_up(n, KM_MF_TILE);
-    const int blocks = (int)std::min<int64_t>(tiles, (int64_t)c->num_cu * 8);
-    hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
-                       reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+    if (GSX_KM_CS && c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
+        // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h)
+        const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)c->num_cu);
+        hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
+                           ktiles, reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+    } else {
+        const int64_t tiles = div_up(n, KM_MF_TILE);
+        const int blocks = (int)std::min<int64_t>(tiles, (int64_t)c->num_cu * 8);
+        hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
+                           reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+    }
     hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * 2), dim3(256), 0, c->stream, data, cent, k, list,
                        meta + 1, labels);
     GSX_HIP(hipGetLastError());

@@ -73,6 +73,9 @@ def main(args):
             L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j].data_ptr(), chunks[j].shape[0], d, k, iters,
                                                  cents[j].data_ptr(), labels[j].data_ptr()), "gsx_kmeans_lloyd_dev")
 
+    for kv in getattr(args, "param", []) or []:
+        name, val = kv.split("=")
+        ctx.set_param(name, float(val))
     for _ in range(warmup):
         step()
     barrier()
