@@ -118,7 +118,7 @@ def main(args):
                                "of %d rows, K=%d per chunk, %d Lloyd iterations, rows resident in HBM" % (n_scene, level, nch, cs, k, iters),
                    "splats": n_scene, "chunks": nch, "k_per_chunk": k, "iterations": iters,
                    "parallelism": "chunks dealt out round robin, no collective" if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "kmeans_assign_mfma_kernel<45> (+ operand prep and exact list kernel in the same interval)",
+        "roofline": {"bound": "mfma", "kernel": "kmeans_assign_mfma_cs_kernel<45> (+ operand prep and exact list kernel in the same interval)",
                      "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(assign_ms, 4),
                      "flops_per_launch": flops, "algorithmic_bytes": alg_bytes,
