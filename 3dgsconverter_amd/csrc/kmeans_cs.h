@@ -18,8 +18,11 @@
 #ifndef GSX_KM_CS_MERGE
 #define GSX_KM_CS_MERGE 0   // 1: 8 lanes per point + shuffles (51 us), 0: one thread per point loops over the 16 views (47 us)
 #endif
-constexpr int KM_CS_WAVES = 16;
-constexpr int KM_CS_CT = 2;                  // centroid tiles per wave -> K <= 16 * 2 * 32 = 1024
+#ifndef GSX_KM_CS_WAVES
+#define GSX_KM_CS_WAVES 16
+#endif
+constexpr int KM_CS_WAVES = GSX_KM_CS_WAVES;
+constexpr int KM_CS_CT = 32 / KM_CS_WAVES;    // centroid tiles per wave -> K <= KM_CS_WAVES * KM_CS_CT * 32 = 1024
 constexpr int KM_CS_PTILES = 4;              // 32-point tiles per block
 constexpr int KM_CS_BLOCK = 32 * KM_CS_PTILES;
 
@@ -53,39 +56,46 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
             for (int v = 0; v < 2; ++v) a[ct][j][v] = opnd[(size_t)t * AW + (size_t)(j * 2 + v) * 64 + lane];
     }
     const int64_t nblocks = (n + KM_CS_BLOCK - 1) / KM_CS_BLOCK;
-    // one item = 8 dimensions of one point = one operand word pair; the first 768 threads own one item per block
-    constexpr int NITEMS = KM_CS_PTILES * NS * 64;
-    static_assert(NITEMS <= 64 * KM_CS_WAVES, "one item per thread");
-    const bool has_item = (int)threadIdx.x < NITEMS;
-    const int il = threadIdx.x & 63, ij = (threadIdx.x >> 6) % NS, ipt = threadIdx.x / (64 * NS);
-    float v[8];
+    // one item = 8 dimensions of one point = one operand word pair; 768 items per block, IPT per thread
+    constexpr int NITEMS = KM_CS_PTILES * NS * 64, NT = 64 * KM_CS_WAVES, IPT = (NITEMS + NT - 1) / NT;
+    float v[IPT][8];
     auto fetch = [&](int64_t blk) __attribute__((always_inline)) {   // global loads only (consumed after the compute phase)
-        if (!has_item) return;
         const int64_t base = blk * KM_CS_BLOCK;
         const int rows = (int)(n - base < KM_CS_BLOCK ? n - base : KM_CS_BLOCK);
-        const int r = ipt * 32 + (il & 31);
-        const int rr = r < rows ? r : rows - 1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = 16 * ij + 8 * (il >> 5) + i;
-            v[i] = d < D ? data[(base + rr) * D + d] : 0.0f;
+        for (int q = 0; q < IPT; ++q) {
+            const int item = (int)threadIdx.x + q * NT;
+            if (item >= NITEMS) continue;
+            const int il = item & 63, ij = (item >> 6) % NS, ipt = item / (64 * NS);
+            const int r = ipt * 32 + (il & 31);
+            const int rr = r < rows ? r : rows - 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = 16 * ij + 8 * (il >> 5) + i;
+                v[q][i] = d < D ? data[(base + rr) * D + d] : 0.0f;
+            }
         }
     };
     auto split_store = [&](int buf) __attribute__((always_inline)) {
-        if (!has_item) return;
-        float acc2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc2 = __builtin_fmaf(v[i], v[i], acc2);
-        ku32x4 hi, lo;
-        km_split8(v, hi, lo);
+        for (int q = 0; q < IPT; ++q) {
+            const int item = (int)threadIdx.x + q * NT;
+            if (item >= NITEMS) continue;
+            const int il = item & 63, ij = (item >> 6) % NS, ipt = item / (64 * NS);
+            float acc2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {   // 1.0 against the three |c|^2 pieces, in the high operand only
-            const int d = 16 * ij + 8 * (il >> 5) + i;
-            if (d >= D && d < D + 3) hi[i >> 1] |= 0x3f80u << ((i & 1) * 16);
+            for (int i = 0; i < 8; ++i) acc2 = __builtin_fmaf(v[q][i], v[q][i], acc2);
+            ku32x4 hi, lo;
+            km_split8(v[q], hi, lo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {   // 1.0 against the three |c|^2 pieces, in the high operand only
+                const int d = 16 * ij + 8 * (il >> 5) + i;
+                if (d >= D && d < D + 3) hi[i >> 1] |= 0x3f80u << ((i & 1) * 16);
+            }
+            s_x[buf][ipt][ij][0][il] = hi;
+            s_x[buf][ipt][ij][1][il] = lo;
+            s_part[buf][ipt * 32 + (il & 31)][ij * 2 + (il >> 5)] = acc2;
         }
-        s_x[buf][ipt][ij][0][il] = hi;
-        s_x[buf][ipt][ij][1][il] = lo;
-        s_part[buf][ipt * 32 + (il & 31)][ij * 2 + (il >> 5)] = acc2;
     };
     if ((int64_t)blockIdx.x < nblocks) {
         fetch(blockIdx.x);
