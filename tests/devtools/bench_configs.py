@@ -4,7 +4,7 @@
   config 5: 10M-splat SOG K-Means: 2 scalar codebooks (50k x 1, K=256, 20 it), 64 chunks x
             (156 250 x 45, K=1024, 10 it), quantise 30M scalars x 2
 Host-level API (numpy in / numpy out, PCIe included) + per-slot kernel time from the library.
-usage: python tools/bench_configs.py [3] [5] [cpu]
+usage: python tests/devtools/bench_configs.py [3] [5] [cpu]
 """
 import importlib
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 gsx = importlib.import_module("3dgsconverter_amd")
 L = gsx._lib

@@ -1,9 +1,9 @@
 """Randomised parity sweep on the GPU box: gsx_sor_filter (host API, adaptive grid, MFMA filter) and the device
 API with both filters against the cKDTree restatement, over random sizes / k / cloud shapes.  Not a test
-(tests/ holds a fixed subset); prints one line per case and a summary.  usage: fuzz_parity.py [cases] [seed]"""
+(tests/ holds a fixed subset); prints one line per case and a summary.  usage: python tests/devtools/fuzz_parity.py [cases] [seed]"""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 gsx = importlib.import_module("3dgsconverter_amd")
 L = gsx._lib
 from oracle import datasets, sor as osor

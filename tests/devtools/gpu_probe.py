@@ -1,5 +1,5 @@
 """Exploratory timing on the GPU box (not a test, not the bench): per-slot kernel times of the
-SOR pipeline for a sweep of cloud sizes / k / grid density.  Usage: python tools/gpu_probe.py [quick]"""
+SOR pipeline for a sweep of cloud sizes / k / grid density.  Usage: python tests/devtools/gpu_probe.py [quick]"""
 import importlib
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 gsx = importlib.import_module("3dgsconverter_amd")
 L = gsx._lib
 
@@ -138,7 +138,7 @@ def main():
     run(ctx, x1, 32, 2, 10.0, label="grid 1M k32 m10")
     run(ctx, uniform(100_000, 10.0), 16, 1, None, label="brute 100k")
     host_level(x1, 16, "host 1M")
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import datasets
     for ad in (0, 1):
         ctx.set_param("adaptive", ad)

@@ -1,7 +1,7 @@
 #!/bin/bash
 timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/adaptive.log
 import sys, os, time
-sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests/devtools"); sys.path.insert(0, ".")
 import gpu_probe as g
 from oracle import datasets
 ctx = g.L.Context(0)

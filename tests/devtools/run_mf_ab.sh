@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_sor_gpu.py -m gpu -x -q -p no:cacheprovider -k "golden_small or kat_grid or k_buckets or clustered or degenerate" 2>&1 | tail -3
 timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/mf_ab.log
 import sys, os
-sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests/devtools"); sys.path.insert(0, ".")
 import gpu_probe as g
 ctx = g.L.Context(0)
 x1 = g.uniform(1_000_000, 10.0); x10 = g.uniform(10_000_000, 5.0)

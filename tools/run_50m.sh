@@ -1,7 +1,7 @@
 #!/bin/bash
 timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/probe_50m.log
 import sys
-sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests/devtools"); sys.path.insert(0, ".")
 import gpu_probe as g
 ctx = g.L.Context(0)
 x = g.uniform(50_000_000, 10.0)

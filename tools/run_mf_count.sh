@@ -1,7 +1,7 @@
 #!/bin/bash
 timeout 600 python - <<'PY' 2>&1 | tee gpurun_out/mf_count.log
 import sys, os
-sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests/devtools"); sys.path.insert(0, ".")
 import gpu_probe as g
 ctx = g.L.Context(0)
 x1 = g.uniform(1_000_000, 10.0)

@@ -1,7 +1,7 @@
 #!/bin/bash
 timeout 300 python - <<'PY' 2>&1 | tee gpurun_out/timing_overhead.log
 import sys, time
-sys.path.insert(0, "tools"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests/devtools"); sys.path.insert(0, ".")
 import gpu_probe as g
 import numpy as np
 ctx = g.L.Context(0)
