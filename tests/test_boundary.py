@@ -53,6 +53,30 @@ def test_product_never_imports_oracle_or_reference():
     assert not bad, bad
 
 
+def test_only_test_infrastructure_touches_the_oracle():
+    """outside tests/ and oracle/ the oracle is imported in exactly three places: smoke(), bench.py's cpu_baseline leg and
+    the cpu_baseline leg of its K-Means workload (tools/bench_kmeans.py)"""
+    root = os.path.dirname(PKG)
+    allowed = {"__graft_entry__.py", "bench.py", os.path.join("tools", "bench_kmeans.py")}
+    hits = set()
+    for dirpath, dirs, files in os.walk(root):
+        rel = os.path.relpath(dirpath, root)
+        if rel.split(os.sep)[0] in ("tests", "oracle", ".git", "gpurun_out", "profiles"):
+            dirs[:] = []
+            continue
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    hits.add(os.path.normpath(os.path.join(rel, f)))
+    assert hits <= allowed, hits - allowed
+    for f in ("bench.py", os.path.join("tools", "bench_kmeans.py")):   # ... and there only inside the cpu_baseline leg
+        src = open(os.path.join(root, f)).read()
+        for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+            before = src[:m.start()]
+            assert "cpu_baseline" in before[before.rfind("\n    if "):] or "no_cpu_baseline" in before[-1500:], (f, m.group(0))
+
+
 def test_no_gpu_means_loud_failure_not_fallback(gsx):
     if gsx.has_hip():
         pytest.skip("a GPU is present")
