@@ -1,0 +1,101 @@
+"""CPU: the selection argument of knn_ring_fast (csrc/sor_grid.hip) replayed in numpy.
+
+The kernel filters candidates by a float32 squared distance d32 <= r_t^2 (1 + 1e-6), bins d32 into 64 histogram bins
+(a monotone function of d32), takes the bins that hold the first k+1 candidates, thr2 = the largest d32 inside them, and
+ranks only the candidates with d32 <= thr2 (1 + 1e-6) exactly in float64.  Claim: whenever the exact (k+1)-th smallest
+float64 distance is <= r_t^2, the ranked subset contains the exact k+1 nearest (so its k+1 smallest exact distances are
+the true ones).  This test replays the arithmetic -- including adversarial near-ties one float32 ulp apart -- against
+a brute-force float64 selection."""
+import numpy as np
+
+
+def d32_of(q, p):
+    d = q.astype(np.float32) - p.astype(np.float32)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    # fmaf(dz, dz, fmaf(dy, dy, dx * dx)) in float32: emulate the two fused steps with float64 products rounded once
+    t = (dx.astype(np.float64) * dx.astype(np.float64)).astype(np.float32)
+    t = (dy.astype(np.float64) * dy.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+    return (dz.astype(np.float64) * dz.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+
+
+def d64_of(q, p):
+    d = p.astype(np.float64) - q.astype(np.float64)
+    return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+
+
+def select(q, pts, kk, rt):
+    """-> (indices ranked exactly, exact kth or None when the kernel would leave the query to knn_ring)"""
+    thr = np.float32(np.float32(rt * rt) * np.float32(1.0 + 1e-6))
+    inv_thr = np.float32(1.0) / thr
+    d32 = d32_of(q[None, :], pts)
+    cand = np.nonzero(d32 <= thr)[0]
+    if len(cand) < kk or len(cand) > 128:
+        return None, None
+    b = np.minimum(63, (d32[cand] * inv_thr * np.float32(64.0)).astype(np.int32))
+    hist = np.bincount(b, minlength=64)
+    bstar = int(np.argmax(np.cumsum(hist) >= kk))
+    m32 = d32[cand][b <= bstar].max()
+    thr2 = np.float32(m32 * np.float32(1.0 + 1e-6))
+    fin = cand[d32[cand] <= thr2]
+    if len(fin) > 64:
+        return None, None
+    dex = np.sort(d64_of(q, pts[fin]))
+    kth = dex[kk - 1]
+    if not kth <= rt * rt:
+        return None, None
+    return fin, dex[:kk]
+
+
+def test_histogram_select_keeps_the_true_nearest():
+    rng = np.random.default_rng(5)
+    solved = 0
+    for trial in range(3000):
+        kk = int(rng.choice([2, 4, 9, 17, 33]))
+        n = int(rng.integers(kk, 120))
+        scale = float(rng.choice([1e-3, 1.0, 37.0, 1e4]))
+        q = (rng.standard_normal(3) * scale).astype(np.float32)
+        pts = (q + rng.standard_normal((n, 3)) * 0.6 * scale * 1e-2).astype(np.float32)
+        pts[0] = q                                          # the query itself is among the candidates
+        if trial % 3 == 0:                                  # near ties: shells one float32 ulp apart around the k-th distance
+            r = np.float32(0.5 * scale * 1e-2)
+            dirs = rng.standard_normal((n - 1, 3))
+            dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+            radii = np.nextafter(r, np.float32(np.inf) if trial % 2 else np.float32(0), dtype=np.float32) if trial % 6 == 0 else r
+            pts[1:] = (q.astype(np.float64) + dirs * np.float64(radii)).astype(np.float32)
+        rt = 1.2 * scale * 1e-2
+        fin, got = select(q, pts, kk, rt)
+        if fin is None:
+            continue
+        solved += 1
+        want = np.sort(d64_of(q, pts))[:kk]
+        np.testing.assert_array_equal(got, want)
+    assert solved > 1500
+
+
+def test_row_trim_never_drops_a_point_inside_the_ball():
+    """the per-row cell range of knn_ring_fast: every point within r_t of the query lies in a visited (row, x-cell)"""
+    rng = np.random.default_rng(6)
+    for trial in range(400):
+        o = (rng.standard_normal(3) * 10).astype(np.float32)
+        h = np.float32(rng.uniform(0.01, 2.0))
+        inv_h = np.float32(1.0) / h
+        hp = 1.0 / np.float64(inv_h)
+        dims = rng.integers(5, 40, 3)
+        pts = (o + rng.random((4000, 3)).astype(np.float32) * (dims * h).astype(np.float32)).astype(np.float32)
+        cell = np.minimum(dims - 1, ((pts - o) * inv_h).astype(np.int32))        # cell_coord of csrc/sor_grid.hip
+        q = pts[rng.integers(len(pts))]
+        cq = np.minimum(dims - 1, ((q - o) * inv_h).astype(np.int32))
+        rt = min(rng.uniform(0.8, 1.9), 1.9) * hp
+        rtc = rt * np.float64(inv_h)
+        u = (q.astype(np.float64) - o.astype(np.float64)) * np.float64(inv_h)
+        inside = d64_of(q, pts) <= rt * rt
+        for p_cell in cell[inside]:
+            yy, zz = p_cell[1], p_cell[2]
+            assert abs(yy - cq[1]) <= 2 and abs(zz - cq[2]) <= 2 and abs(p_cell[0] - cq[0]) <= 2
+            dy = (yy - 1e-3 - u[1]) if u[1] < yy - 1e-3 else ((u[1] - (yy + 1.001)) if u[1] > yy + 1.001 else 0.0)
+            dz = (zz - 1e-3 - u[2]) if u[2] < zz - 1e-3 else ((u[2] - (zz + 1.001)) if u[2] > zz + 1.001 else 0.0)
+            rem = rtc * rtc - dy * dy - dz * dz
+            assert rem >= 0.0
+            dxc = np.sqrt(rem) + 1e-3
+            xa, xb = int(np.floor(u[0] - dxc)), int(np.floor(u[0] + dxc))
+            assert xa <= p_cell[0] <= xb
