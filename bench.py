@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--extent", type=float, default=5.0)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (grid), 1 brute force, 2 grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-splat configs[1] line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-splat configs[1] line (N=1) / the 50M k=32 configs[3] line (N>1)")
+    ap.add_argument("--config3", action="store_true", help="N=1: also run the 50M-splat k=32 configs[3] workload on this one GPU")
     ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
                     help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
@@ -121,8 +122,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n, extent, steps, warmup, side=True):
+    def run(n, extent, steps, warmup, side=True, k=None):
         """Time `steps` SOR steps on a fresh n-splat shard; returns a dict of raw measurements."""
+        k = args.k if k is None else k
         xyz_host = synth_shard(n, extent, rank)
         xyz_local = torch.from_numpy(xyz_host).to(dev)
         torch.cuda.synchronize()
@@ -143,7 +145,7 @@ def main():
         def step():
             if exchange["path"] == "slab":
                 try:
-                    r = gslab.slab_sor(slab_be, slab_comm, gslab._View(xyz_local.data_ptr()), n, args.k, args.sigma)
+                    r = gslab.slab_sor(slab_be, slab_comm, gslab._View(xyz_local.data_ptr()), n, k, args.sigma)
                     if not exchange.get("certified"):   # first step on this cloud: read the certificate before relying on
                         r.check()                        # the slab path (later steps read it after the timed region)
                         exchange["certified"] = True
@@ -151,12 +153,12 @@ def main():
                 except gslab.SlabUncertain as e:   # raised on every rank together (the count is all-reduced)
                     exchange["path"] = "replicated (slab certificate failed: %s)" % e
                     compute.set_adaptive(True)     # the clouds that get here are the ones the adaptive grid exists for
-            return gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
+            return gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
 
         if world > 1 and exchange["path"] == "slab" and not exchange.get("cross_checked"):
             # the slab exchange and the replicated one (all-gather of the rows, every rank bins everything) must agree
             # bit for bit -- statistics and this rank's survivor mask -- before the slab path is what gets timed
-            ref = gdist.sharded_sor(xyz_local, args.k, args.sigma, compute, algo=args.algo)
+            ref = gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
             ok = 1
             try:
                 got = step()
@@ -223,6 +225,10 @@ def main():
 
     main_run = run(args.n, args.extent, args.steps, args.warmup)
     res = main_run["res"]
+    # read the headline run's results NOW: later runs (secondary configurations) reuse the exchange's device buffers
+    survivors_main = int(res.mask_local.sum().item())
+    threshold_main = float(res.stats[2].item())
+    mask_main_host = res.mask_local.cpu().numpy().astype(bool) if (world == 1 and not args.no_cpu_baseline) else None
     info = None
     if world == 1 and slab_comm is None:
         t = main_run["xyz_local"]
@@ -237,6 +243,23 @@ def main():
                      "knn_kernel_ms": round(r2["knn_ms"], 4),
                      "survivors": int(r2["res"].mask_local.sum().item())}
         del r2
+
+    config3 = None
+    if (world > 1 or args.config3) and not args.no_secondary:
+        # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
+        # other N the same 50M are split N ways).  Reported next to the headline, never instead of it.
+        try:
+            n3 = max(8192, (50_000_000 // world) // 4 * 4)
+            s3, w3 = max(3, min(args.steps, 10)), 2
+            r3 = run(n3, 10.0, s3, w3, side=False, k=32)
+            config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, seed=rank) over %d GPU(s), SOR k=32 "
+                                     "sigma=%g" % (n3 * world, world, args.sigma),
+                         "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
+                         "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
+                         "knn_kernel_ms": round(r3["knn_ms"], 4)}
+            del r3
+        except Exception as e:   # noqa: BLE001 -- the headline line must survive a failure here
+            config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}
 
     if slab_comm is not None:
         ctx.check()
@@ -307,13 +330,15 @@ def main():
                                    if (world > 1 or slab_comm is not None) else "single GPU")},
         "roofline": roofline,
         "kernel_ms_per_step": main_run["kernel_ms_per_step"],
-        "survivors_rank0": int(res.mask_local.sum().item()),
-        "threshold": float(res.stats[2].item()),
+        "survivors_rank0": survivors_main,
+        "threshold": threshold_main,
     }
     if info is not None:
         out["grid"] = info
     if secondary is not None:
         out["secondary"] = secondary
+    if config3 is not None:
+        out["config3"] = config3
 
     if world == 1 and not args.no_cpu_baseline:
         # reported baseline, not the target: the reference's CPU path (cKDTree + numpy, restated in
@@ -323,7 +348,7 @@ def main():
         t0 = time.perf_counter()
         ref = osor.sor(main_run["xyz_host"], args.k, args.sigma, workers=workers)
         cpu_dt = time.perf_counter() - t0
-        same = bool(np.array_equal(ref["mask"], res.mask_local.cpu().numpy().astype(bool)))
+        same = bool(np.array_equal(ref["mask"], mask_main_host))
         out["cpu_baseline"] = {"value": round(args.n / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": workers,
                                "kind": "port", "sample": "the full %d-splat workload, once (%.2f s): "
                                "scipy cKDTree query workers=%d + numpy stats" % (args.n, cpu_dt, workers),
