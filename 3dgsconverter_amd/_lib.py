@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsx_hip.so")
+# GSX_LIB_PATH: an experiment build of build.py (GSX_EXTRA_FLAGS -> 3dgsconverter_amd/variants/), for A/B runs only
+LIB_PATH = os.environ.get("GSX_LIB_PATH") or os.path.join(_HERE, "libgsx_hip.so")
 
 KNN_AUTO, KNN_BRUTE, KNN_GRID = 0, 1, 2
 T_SOR_KNN, T_SOR_BIN, T_SOR_FALLBACK, T_SOR_STATS, T_DENSITY, T_KMEANS_ASSIGN, T_KMEANS_UPDATE, T_QUANTIZE = range(8)
@@ -533,6 +534,7 @@ class DeviceChain:
         self.spare = self.ctx.alloc(max(a.nbytes, 16))
         self.orig = None                    # None = identity
         self.orig_spare = None
+        self.empty = False                  # keep_none(): no survivor, whatever self.orig says
         self.mask = self.ctx.alloc(self.n0 + 16)
 
     def _xyz(self):
@@ -570,7 +572,10 @@ class DeviceChain:
         return self._compact()
 
     def keep_none(self):
+        """a filter removed every row (reference: ``self.data = self.data[:0]``, data_processor.py:54-57,91-93).
+        ``orig`` may still be None (= identity) when this is the first filter of the chain, so emptiness is its own flag."""
         self.n = 0
+        self.empty = True
 
     def bbox_keep(self, bounds6) -> int:
         """crop_by_bbox (data_processor.py:215-224): bounds as numpy would see them -- Python floats are weak scalars
@@ -610,6 +615,8 @@ class DeviceChain:
 
     def survivors(self) -> np.ndarray:
         """indices (ascending) of the surviving rows in the table the chain started from"""
+        if self.empty or self.n == 0:
+            return np.zeros(0, np.uint32)
         if self.orig is None:
             return np.arange(self.n0, dtype=np.uint32)
         return self.orig.download(np.uint32, self.n) if self.n else np.zeros(0, np.uint32)

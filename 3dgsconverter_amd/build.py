@@ -34,16 +34,37 @@ def newest_dep() -> float:
     return max(t, os.path.getmtime(__file__))
 
 
+def variant_paths(extra):
+    """Experiment builds (GSX_EXTRA_FLAGS, e.g. -DGSX_ABLATE or a tuning -D) never touch the product library: they get
+    their own object directory and their own output, named after the flag set -- a later plain build() cannot mistake an
+    ablation library for the product.  `GSX_LIB_PATH=<that file>` makes _lib load it."""
+    import hashlib
+    tag = os.environ.get("GSX_VARIANT_TAG") or hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10]
+    return os.path.join(OBJ, "variant_" + tag), os.path.join(HERE, "variants", "libgsx_hip_%s.so" % tag)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("GSX_EXTRA_FLAGS", "").split()  # experiment builds only (e.g. -DGSX_ABLATE); forces a rebuild
-    force = force or bool(extra)
+    extra = os.environ.get("GSX_EXTRA_FLAGS", "").split()  # experiment builds only: separate objects + output
+    OBJ, OUT = (globals()["OBJ"], globals()["OUT"]) if not extra else variant_paths(extra)
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     dep_t = newest_dep()
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= dep_t:
         return OUT
 
+    only = set(os.environ.get("GSX_VARIANT_ONLY", "").split()) if extra else set()   # e.g. "sor_grid.hip": the other
+    if only:                                                                          # objects come from the product build
+        _plain_env = dict(os.environ)
+        os.environ.pop("GSX_EXTRA_FLAGS")
+        try:
+            build(force=False, verbose=verbose)
+        finally:
+            os.environ.update(_plain_env)
+
     def compile_one(src):
+        if only and src not in only:
+            return os.path.join(globals()["OBJ"], src[:-4] + ".o")
         obj = os.path.join(OBJ, src[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_t:
             return obj

@@ -133,10 +133,13 @@ __device__ __forceinline__ void oe_sort(double *v)
     }
 }
 
+#ifndef GSX_NET_BS
+#define GSX_NET_BS 16
+#endif
 template <int L>
 struct TopNet {
     static_assert((L & (L - 1)) == 0 && L >= 8, "list length must be a power of two");
-    static constexpr int BS = L < 16 ? L : 16;
+    static constexpr int BS = L < GSX_NET_BS ? L : GSX_NET_BS;
     double a[L];  // ascending, +inf padded
 
     __device__ __forceinline__ void init()
@@ -147,6 +150,7 @@ struct TopNet {
     // j-th smallest (1-based, wave-uniform j <= L); same select chain as TopList::kth
     __device__ __forceinline__ double kth(int j) const
     {
+        if (j == L) return a[L - 1];  // wave-uniform: the power-of-two k of the headline configs skips the select chain
         double r = a[L - 1];
 #pragma unroll
         for (int i = 0; i < L - 1; ++i) {
@@ -179,15 +183,49 @@ struct TopNet {
     }
 };
 
+// Correctly rounded float64 square root for the squared distances of knn_brick's epilogue: the compiler's own
+// lowering of sqrt(double) (v_rsq_f64 seed, two Goldschmidt steps, two residual corrections) WITHOUT its range
+// scaling (inputs below 2^-767 are scaled by 2^256: squared differences of float32 coordinates are 0 or >= 2^-298)
+// and without the class test for 0 / inf: the seed is taken of max(x, 1e-300), so x = 0 (duplicate points) runs
+// through as g = 0 * y = 0 and every correction term stays 0.  Same instruction sequence otherwise, hence the same
+// bits (the GPU suite compares 10M mean distances with cKDTree's).  11 instead of ~18 instructions per root.
+__device__ __forceinline__ double sqrt_rn_dist2(double x)
+{
+#if defined(GSX_SQRT_LIB)
+    return __dsqrt_rn(x);
+#else
+    double xs;
+    asm("v_max_f64 %0, %1, %2" : "=v"(xs) : "v"(x), "v"(1e-300));
+    const double y = __builtin_amdgcn_rsq(xs);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+#endif
+}
+
 // epilogue for TopNet: entries 0..k-1 are the neighbours (the query was never inserted)
 template <int L>
 __device__ __forceinline__ float mean_from_net(const TopNet<L> &lst, int k)
 {
     double b[L];
 #pragma unroll
-    for (int j = 0; j < L; ++j) b[j] = __dsqrt_rn(lst.a[j]);
+    for (int j = 0; j < L; ++j) b[j] = sqrt_rn_dist2(lst.a[j]);
     double res;
-    if (k < 8) {
+    if (k == L) {  // wave-uniform; the headline k = 16 / 32: numpy's 8 accumulators over a multiple of 8, no scalar branches
+        double r[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r[t] = b[t];
+#pragma unroll
+        for (int j = 8; j < L; ++j) r[j & 7] = __dadd_rn(r[j & 7], b[j]);
+        res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                        __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    } else if (k < 8) {
         res = 0.0;
 #pragma unroll
         for (int j = 0; j < 7 && j < L; ++j)

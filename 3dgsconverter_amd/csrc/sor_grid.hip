@@ -776,6 +776,9 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
+#ifndef GSX_NET_WAVES9
+#define GSX_NET_WAVES9 5
+#endif
 #ifndef GSX_NET_WAVES17
 #define GSX_NET_WAVES17 3
 #endif
@@ -788,6 +791,9 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #ifndef GSX_NET_BF
 #define GSX_NET_BF 1
 #endif
+#ifndef GSX_NET_GS
+#define GSX_NET_GS 0   // skip the groups of a block that no lane has candidates for
+#endif
 #ifndef GSX_NET_DU
 #define GSX_NET_DU 0   // measured: 2.15 vs 2.07 ms at 10M -- the branch also skips finished lanes' work
 #endif
@@ -795,7 +801,7 @@ constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
     // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
-    if (net) return kcap <= 9 ? 5 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? GSX_NET_WAVES33 : 2));
+    if (net) return kcap <= 9 ? GSX_NET_WAVES9 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? GSX_NET_WAVES33 : 2));
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
@@ -1039,6 +1045,14 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                         double blk[BS];
 #pragma unroll
                         for (int h0 = 0; h0 < BS; h0 += HB) {
+#if GSX_NET_GS
+                            // a group no lane has a candidate for (the tail of a brick's last block): +inf, no walk
+                            if (h0 > 0 && !__any(m != 0 || nzw != 0)) {
+#pragma unroll
+                                for (int j = 0; j < HB; ++j) blk[h0 + j] = __builtin_inf();
+                                continue;
+                            }
+#endif
                             float4 pt[HB];
                             bool ok[HB];
 #pragma unroll

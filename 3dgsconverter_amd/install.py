@@ -3,8 +3,10 @@
 ``install()`` rebinds the three names the reference's orchestrator and SOG writer resolve
 at call time:
     gsconverter.converter.DataProcessor            (converter.py:10 -> used at :150; bound to ChainedDataProcessor,
-                                                    which keeps the coordinates in HBM across density -> SOR)
+                                                    which keeps the coordinates in HBM across density -> SOR and whose
+                                                    filter methods return None -- the orchestrator ignores them)
     gsconverter.processing.DataProcessor / gsconverter.processing.data_processor.DataProcessor
+                                                   (the EAGER class: every method returns self.data like the reference)
     gsconverter.formats.sog.gpu_ops                (sog.py:11 -> used at :402,443,524,544)
     gsconverter.processing.gpu_ops                 (data_processor.py:142 imports it lazily)
 so ``gsconverter``'s CLI (main.py) and every flag in SURVEY.md 8(b) keep working.
@@ -24,38 +26,44 @@ def install(sog_writer: bool = True):
     formats/compressed_ply_writer.py:write_compressed_ply (Morton order, chunk bounds and packers on the GPU)."""
     from . import processing
     from .processing import gpu_ops
-    from .processing.data_processor import ChainedDataProcessor as DataProcessor   # lazy: coordinates stay in HBM across filters
+    # the orchestrator ignores the filters' return values (converter.py:196-236), so ITS name gets the lazy class (coordinates
+    # stay in HBM across filters); the public names keep the eager class, whose methods return self.data like the reference's
+    from .processing.data_processor import ChainedDataProcessor, DataProcessor
     import gsconverter.processing as rp  # type: ignore  (raises ImportError if the reference is absent)
     import gsconverter.processing.data_processor as rdp  # type: ignore
     from .processing import data_processor as mine
-    if rdp.DataProcessor is not DataProcessor:
-        mine._REFERENCE_CLASS = rdp.DataProcessor  # non-hot-path methods are forwarded to it
+    if rdp.DataProcessor is not DataProcessor and rdp.DataProcessor.__module__.startswith("gsconverter"):
+        mine._REFERENCE_CLASS = rdp.DataProcessor  # methods with no device implementation are forwarded to it
     targets = [(rp, "DataProcessor", DataProcessor), (rdp, "DataProcessor", DataProcessor),
                (rp, "gpu_ops", gpu_ops)]
-    for modname, attr, val in (("gsconverter.converter", "DataProcessor", DataProcessor),
+    for modname, attr, val in (("gsconverter.converter", "DataProcessor", ChainedDataProcessor),
                                ("gsconverter.formats.sog", "gpu_ops", gpu_ops)):
         try:
             targets.append((importlib.import_module(modname), attr, val))
-        except Exception:
-            pass  # e.g. plyfile / pillow missing: that codec is not importable anyway
+        except ImportError:
+            pass  # plyfile / pillow missing: that module of the REFERENCE is not importable, nothing to rebind
     for mod, attr, val in targets:
         _saved.setdefault((mod.__name__, attr), getattr(mod, attr, None))
         setattr(mod, attr, val)
     if sog_writer:
+        # only the REFERENCE's module may be missing (pillow / plyfile absent: its own writer cannot run either);
+        # a failure importing this package's writers propagates -- no silent return to the CPU writer
         try:
             sogmod = importlib.import_module("gsconverter.formats.sog")
+        except ImportError:
+            sogmod = None
+        if sogmod is not None:
             from .formats.sog_writer import write_sog
             _saved.setdefault(("sogformat", "write"), sogmod.SogFormat.write)
             sogmod.SogFormat.write = lambda self, data, path, **kw: write_sog(data, path, **kw)
-        except Exception:
-            pass  # pillow missing: the reference's own writer is not importable either
         try:
             cpmod = importlib.import_module("gsconverter.formats.compressed_ply")
+        except ImportError:
+            cpmod = None
+        if cpmod is not None:
             from .formats.compressed_ply_writer import write_compressed_ply
             _saved.setdefault(("cplyformat", "write"), cpmod.CompressedPlyFormat.write)
             cpmod.CompressedPlyFormat.write = lambda self, data, path, **kw: write_compressed_ply(data, path, **kw)
-        except Exception:
-            pass
     _saved.setdefault(("sys.modules", "gsconverter.processing.gpu_ops"),
                       sys.modules.get("gsconverter.processing.gpu_ops"))
     sys.modules["gsconverter.processing.gpu_ops"] = gpu_ops

@@ -27,6 +27,9 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "large_cases.json")
 SOR_LARGE = [
     # the bench workload (BASELINE.json target config): 10M uniform splats, L=5, seed 0, k=16, sigma 1
     ("sor_u10m_L5_k16_s1", {"kind": "uniform", "n": 10_000_000, "extent": 5.0, "seed": 0}, 16, 1.0),
+    # BASELINE.json configs[3]: 50M uniform splats, L=10, seed 0, k=32, sigma 1 -- the whole cloud
+    # through the reference's own remove_flyers CPU branch (cKDTree over 50M points: minutes, ~15 GB)
+    ("sor_u50m_L10_k32_s1", {"kind": "uniform", "n": 50_000_000, "extent": 10.0, "seed": 0}, 32, 1.0),
 ]
 # BASELINE.json configs[2]: density sensitivity 0.5 on the same cloud, then SOR k=16 on the survivors
 CHAIN_LARGE = [

@@ -204,6 +204,26 @@ def test_converter_run_density_flag_goes_through_the_dropin(tmp_path, gsx, dropi
     assert got.equals(want)
 
 
+def test_install_binds_the_lazy_class_to_the_orchestrator_only(gsx, dropin):
+    """callers of the PUBLIC class use the filters' return values (the reference returns self.data),
+    so gsconverter.processing.DataProcessor stays the eager class; only converter.py's name -- whose return values are
+    ignored (converter.py:196-236) -- gets the lazy chain."""
+    import gsconverter.converter as conv
+    import gsconverter.processing as rp
+    import gsconverter.processing.data_processor as rdp
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    assert conv.DataProcessor is dp.ChainedDataProcessor
+    assert rp.DataProcessor is dp.DataProcessor and rdp.DataProcessor is dp.DataProcessor
+    xyz = datasets.uniform(4000, 3.0, 1)
+    arr = np.zeros(len(xyz), dtype=[("x", "f4"), ("y", "f4"), ("z", "f4")])
+    arr["x"], arr["y"], arr["z"] = xyz.T
+    proc = rp.DataProcessor(arr)
+    out = proc.apply_density_filter(voxel_size=1.0, threshold_percentage=0.5)
+    assert out is proc.data and len(out) > 0          # eager: returns the table, like data_processor.py:117
+    out2 = proc.remove_flyers(k=8, threshold_factor=1.0)
+    assert out2 is proc.data and 0 < len(out2) <= len(out)
+
+
 def test_converter_run_sor_flags_go_through_the_dropin(tmp_path, gsx, dropin):
     inp, _ = _write_input(tmp_path)
     got = _run(tmp_path, inp, "dropin", sor_k=12.0, sor_sigma=1.5)  # main.py parses --sor_k as float
