@@ -523,7 +523,7 @@ class DeviceChain:
     filter leaves its mask in HBM, ``gsx_compact_rows_dev`` compacts the rows there, and the composed survivor list comes
     back once -- the 248-byte host rows are compacted once, after the last filter."""
 
-    def __init__(self, xyz_rows: np.ndarray, device: int = 0):
+    def __init__(self, xyz_rows: np.ndarray, device: int = 0, keep_pristine: bool = False):
         a = np.ascontiguousarray(xyz_rows, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] != 3:
             raise ValueError("Requires 3D data")
@@ -532,10 +532,25 @@ class DeviceChain:
         self.n0 = self.n = int(a.shape[0])
         self.rows = self.ctx.alloc(max(a.nbytes, 16)).upload(a)
         self.spare = self.ctx.alloc(max(a.nbytes, 16))
+        # bench.py only: a second device copy of the uploaded rows, so that restart() can run the chain again without PCIe
+        self.pristine = self.ctx.alloc(max(a.nbytes, 16)) if keep_pristine else None
+        if self.pristine is not None:
+            check(self.ctx.lib.gsx_dev_copy(self.ctx.handle, self.pristine.ptr, self.rows.ptr, a.nbytes), "gsx_dev_copy")
         self.orig = None                    # None = identity
-        self.orig_spare = None
+        self._pool = []                     # survivor-list buffers not in use (4 n0 bytes each; at most two ever exist)
         self.empty = False                  # keep_none(): no survivor, whatever self.orig says
         self.mask = self.ctx.alloc(self.n0 + 16)
+        self._md = self._st = None          # SOR work buffers (mean distances, statistics), allocated on first use
+
+    def restart(self):
+        """back to the state right after the upload (needs keep_pristine): device-to-device copy, identity survivor list"""
+        if self.pristine is None:
+            raise ValueError("DeviceChain(keep_pristine=True) is needed for restart()")
+        check(self.ctx.lib.gsx_dev_copy(self.ctx.handle, self.rows.ptr, self.pristine.ptr, 12 * self.n0), "gsx_dev_copy")
+        if self.orig is not None:
+            self._pool.append(self.orig)
+        self.orig = None
+        self.n, self.empty = self.n0, False
 
     def _xyz(self):
         p = self.rows.ptr
@@ -554,13 +569,15 @@ class DeviceChain:
         return {"n_unique": int(nu.value), "dense_keys": keys[:m].copy(), "dense_counts": counts[:m].copy()}
 
     def _compact(self) -> int:
-        out = self.orig_spare if self.orig_spare is not None else self.ctx.alloc(4 * self.n0 + 16)
+        out = self._pool.pop() if self._pool else self.ctx.alloc(4 * self.n0 + 16)
         n_out = C.c_int64()
         check(self.ctx.lib.gsx_compact_rows_dev(self.ctx.handle, self.rows.ptr, self.orig.ptr if self.orig is not None else None,
                                                 self.mask.ptr, self.n, self.spare.ptr, out.ptr, C.byref(n_out)),
               "gsx_compact_rows_dev")
         self.rows, self.spare = self.spare, self.rows
-        self.orig, self.orig_spare = out, self.orig   # the previous list (None the first time) becomes the spare
+        if self.orig is not None:
+            self._pool.append(self.orig)    # the previous survivor list is free again
+        self.orig = out
         self.n = int(n_out.value)
         return self.n
 
@@ -600,16 +617,15 @@ class DeviceChain:
     def sor_keep(self, k: int, threshold_factor: float):
         numpy_reduction_selfcheck(self.ctx)
         n = self.n
-        md = self.ctx.alloc(4 * n + 16)
-        st = self.ctx.alloc(16)
+        if self._md is None:                # sized for the whole table once: no allocation in later calls
+            self._md, self._st = self.ctx.alloc(4 * self.n0 + 16), self.ctx.alloc(16)
+        md, st = self._md, self._st
         x, y, z, stride = self._xyz()
         self.ctx.sor_knn(x, y, z, stride, n, 0, n, int(k), md.ptr)
         self.ctx.sor_stats(md.ptr, n, float(threshold_factor), st.ptr)
         self.ctx.sor_mask(md.ptr, n, st.ptr + 8, self.mask.ptr)
         self.ctx.check()
         stats = st.download(np.float32, 3)
-        md.free()
-        st.free()
         kept = self._compact()
         return {"mean": stats[0], "std": stats[1], "threshold": stats[2], "kept": kept}
 
@@ -622,7 +638,7 @@ class DeviceChain:
         return self.orig.download(np.uint32, self.n) if self.n else np.zeros(0, np.uint32)
 
     def close(self):
-        for b in (self.rows, self.spare, self.orig, self.orig_spare, self.mask):
+        for b in (self.rows, self.spare, self.orig, self.mask, self.pristine, self._md, self._st, *self._pool):
             if b is not None:
                 b.free()
         self.ctx.close()

@@ -94,12 +94,13 @@ struct TopList {
 // times (~44 for ~30 candidates per lane at k = 16): 1500 of the ~4600 VALU instructions of a batch.
 // TopNet keeps the L smallest squared distances of the query's NEIGHBOURS -- the query itself is
 // excluded by its index, so L = k for the power-of-two k the headline configs use -- and takes
-// candidates in blocks of BS = min(L, 16): a block is sorted by Batcher's odd-even merge sort
-// (63 compare-exchanges for 16), merged into the list with the bitonic rule
-//     c[i] = min(a[i], b[L-1-i])   ->   c holds the L smallest and is bitonic
-// and log2(L) half-cleaner stages sort c again: (63 + 32) CE + 16 min = 206 ops per 16 candidates
-// at L = 16, i.e. 13 ops per candidate instead of 34.  All indices are compile-time constants:
-// the list and the block stay in VGPRs.
+// candidates in blocks of BS = min(L, 8): a block is sorted by Batcher's odd-even merge sort
+// (19 compare-exchanges for 8), merged into the list with the bitonic rule
+//     c[L-BS+i] = min(a[L-BS+i], b[BS-1-i])   ->   c holds the L smallest and is bitonic
+// and log2(L) half-cleaner stages sort c again: (19 + 32) CE + 8 min = 110 ops per 8 candidates
+// at L = 16, i.e. 14 ops per candidate instead of the bubble insert's 34.  (The merge rule with BS < L was
+// checked with the 0-1 principle for (L, BS) in {16,32,64} x {4,8,16}.)  All indices are compile-time
+// constants: the list and the block stay in VGPRs.
 __device__ __forceinline__ void ce_f64(double &lo, double &hi)  // compare-exchange, no NaNs ever
 {
     double a, b;
@@ -133,13 +134,12 @@ __device__ __forceinline__ void oe_sort(double *v)
     }
 }
 
-#ifndef GSX_NET_BS
-#define GSX_NET_BS 16
-#endif
 template <int L>
 struct TopNet {
     static_assert((L & (L - 1)) == 0 && L >= 8, "list length must be a power of two");
-    static constexpr int BS = L < GSX_NET_BS ? L : GSX_NET_BS;
+    // candidates per block.  8, not 16 (round 3): the same ~13 network ops per candidate, half the padding in a lane's
+    // last block, 16 fewer live VGPRs -> two more waves per SIMD; 4 costs more network ops than it saves
+    static constexpr int BS = L < 8 ? L : 8;
     double a[L];  // ascending, +inf padded
 
     __device__ __forceinline__ void init()
@@ -191,9 +191,6 @@ struct TopNet {
 // bits (the GPU suite compares 10M mean distances with cKDTree's).  11 instead of ~18 instructions per root.
 __device__ __forceinline__ double sqrt_rn_dist2(double x)
 {
-#if defined(GSX_SQRT_LIB)
-    return __dsqrt_rn(x);
-#else
     double xs;
     asm("v_max_f64 %0, %1, %2" : "=v"(xs) : "v"(x), "v"(1e-300));
     const double y = __builtin_amdgcn_rsq(xs);
@@ -206,7 +203,6 @@ __device__ __forceinline__ double sqrt_rn_dist2(double x)
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
-#endif
 }
 
 // epilogue for TopNet: entries 0..k-1 are the neighbours (the query was never inserted)

@@ -49,10 +49,7 @@ constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index roun
 constexpr int MAX_BUCKETS = 4096;         // LDS histogram bins of the coarse pass
 constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 KiB)
 constexpr int BUCKET_POINTS = 4096;       // target points per bucket
-#ifndef GSX_BIN_TILE
-#define GSX_BIN_TILE 8192
-#endif
-constexpr int BIN_TILE = GSX_BIN_TILE;    // points per workgroup tile in the coarse pass
+constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass (4096 / 16384: no better)
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
 constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of knn_heavy_scan covers (512 per lane: the
@@ -776,32 +773,17 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // of batches for one brick inside a dense cluster) is APPENDED to a list instead of being looped over
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
-#ifndef GSX_NET_WAVES9
-#define GSX_NET_WAVES9 5
-#endif
-#ifndef GSX_NET_WAVES17
-#define GSX_NET_WAVES17 3
-#endif
-#ifndef GSX_NET_WAVES33
-#define GSX_NET_WAVES33 2   // 50M k=32: 17.35 vs 17.72 ms at 3 (192 B of scratch per lane there)
-#endif
-#ifndef GSX_NET_HB
-#define GSX_NET_HB 4
-#endif
-#ifndef GSX_NET_BF
-#define GSX_NET_BF 1
-#endif
-#ifndef GSX_NET_GS
-#define GSX_NET_GS 0   // skip the groups of a block that no lane has candidates for
-#endif
-#ifndef GSX_NET_DU
-#define GSX_NET_DU 0   // measured: 2.15 vs 2.07 ms at 10M -- the branch also skips finished lanes' work
-#endif
+// Round 3 (profiles/r03_variants.txt): phase 2 takes the candidates in blocks of 8 (TopNet::BS) -- the list, one block and
+// four gathers in flight then need ~95 VGPRs and five waves per SIMD are resident for k <= 16 (three for k <= 32).  The
+// kernel is bound by latency as much as by issue: 3 -> 5 waves took knn_brick from 1.92 to 1.68 ms at 10M splats, the
+// setup code's spills (outside the loops) notwithstanding; six waves push spills into the loops (2.39 ms).
+constexpr int NET_WAVES9 = 5, NET_WAVES17 = 5, NET_WAVES33 = 3;
+constexpr int NET_HB = 4;   // candidate gathers in flight per lane (8: no change)
 constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
     // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
-    if (net) return kcap <= 9 ? GSX_NET_WAVES9 : (kcap <= 17 ? GSX_NET_WAVES17 : (kcap <= 33 ? GSX_NET_WAVES33 : 2));
+    if (net) return kcap <= 9 ? NET_WAVES9 : (kcap <= 17 ? NET_WAVES17 : (kcap <= 33 ? NET_WAVES33 : 2));
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
@@ -1039,39 +1021,16 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                     // for the query's own point), one sorting network orders the block and a bitonic merge folds
                     // it into the list.  The wave repeats while any lane has bits left.
                     using Net = TopNet<NET ? KCAP - 1 : 8>;
-                    constexpr int BS = Net::BS, HB = GSX_NET_HB < BS ? GSX_NET_HB : BS;
+                    constexpr int BS = Net::BS, HB = NET_HB < BS ? NET_HB : BS;
                     const unsigned self_w = __float_as_uint(qp.w);
                     for (;;) {
                         double blk[BS];
 #pragma unroll
                         for (int h0 = 0; h0 < BS; h0 += HB) {
-#if GSX_NET_GS
-                            // a group no lane has a candidate for (the tail of a brick's last block): +inf, no walk
-                            if (h0 > 0 && !__any(m != 0 || nzw != 0)) {
-#pragma unroll
-                                for (int j = 0; j < HB; ++j) blk[h0 + j] = __builtin_inf();
-                                continue;
-                            }
-#endif
                             float4 pt[HB];
                             bool ok[HB];
 #pragma unroll
                             for (int j = 0; j < HB; ++j) {
-#if GSX_NET_BF >= 2
-                                {   // branch-free word advance: every lane reads a word, only lanes that ran dry keep it
-                                    const bool adv = m == 0 && nzw != 0;
-                                    const int w = adv ? __builtin_ctz(nzw) : 0;
-                                    nzw = adv ? (nzw & (nzw - 1)) : nzw;
-                                    const unsigned mw = mask[w][lane];
-                                    m = adv ? mw : m;
-                                    base = adv ? (int)wbase[w] : base;
-                                    if constexpr (MF) {
-                                        const uint2 sg = wseg[w];
-                                        c1 = adv ? (int)sg.x : c1;
-                                        base2 = adv ? (int)sg.y : base2;
-                                    }
-                                }
-#else
                                 if (m == 0 && nzw != 0) {
                                     const int w = __builtin_ctz(nzw);
                                     nzw &= nzw - 1;
@@ -1083,31 +1042,16 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                                         base2 = (int)sg.y;
                                     }
                                 }
-#endif
                                 ok[j] = m != 0;
-#if GSX_NET_BF
                                 // branch-free: a lane that has run out (m == 0) re-reads candidate 0 of its last
                                 // word (a valid, cached address) and the result is discarded below
                                 const int i = ok[j] ? __builtin_clz(m) : 0;
                                 m &= ~(0x80000000u >> i);  // m == 0 stays 0
                                 pt[j] = refs[(MF && i >= c1 ? base2 : base) + i];
-#else
-                                pt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (ok[j]) {
-                                    const int i = __builtin_clz(m);
-                                    m &= ~(0x80000000u >> i);
-                                    pt[j] = refs[(MF && i >= c1 ? base2 : base) + i];
-                                }
-#endif
                             }
 #pragma unroll
                             for (int j = 0; j < HB; ++j) {
                                 double d = dist2_f64(qxd, qyd, qzd, pt[j].x, pt[j].y, pt[j].z);
-#if GSX_NET_DU
-                                // keep the distance UNCONDITIONAL: without the barrier the compiler sinks its 11 ops into
-                                // an `if (ok)` block, i.e. a divergent branch (exec save/restore + s_cbranch) per candidate
-                                asm volatile("" : "+v"(d));
-#endif
                                 blk[h0 + j] = (ok[j] && __float_as_uint(pt[j].w) != self_w) ? d : __builtin_inf();
                             }
                         }
@@ -1893,18 +1837,9 @@ static int launch_bricks(gsx_ctx *ctx, const BrickLaunch &a)
 // the dependent loads (list entry -> query -> row bounds -> candidates) of different queries.  The queries it cannot
 // finish (fewer than k+1 points within 1.9 cell edges, more than CAND inside r_t, heavy rings) go to a second list for
 // knn_ring -- appended per wave in batches, because same-address atomics cost ~11 ns each.
-#ifndef GSX_RING_FAST
-#define GSX_RING_FAST 1   // 0: knn_ring alone (A/B)
-#endif
-#ifndef GSX_RINGF_INFLIGHT
-#define GSX_RINGF_INFLIGHT 4
-#endif
-#ifndef GSX_RINGF_TARGET
-#define GSX_RINGF_TARGET 5.0   // candidates expected inside r_t, in units of k+1
-#endif
-#ifndef GSX_RINGF_WAVES
-#define GSX_RINGF_WAVES 6
-#endif
+constexpr int RINGF_INFLIGHT = 4;
+constexpr double RINGF_TARGET = 5.0;   // candidates expected inside r_t, in units of k+1 (3.5: +0.008 ms, 7: +0.05 ms)
+constexpr int RINGF_WAVES = 6;         // 5 waves (no scratch): no change; 4: +0.015 ms (profiles/r03_variants.txt)
 constexpr int RINGF_ROWS = 25;   // 5 x 5 rows of 5 cells
 constexpr int RINGF_LEFT = 32;   // leftovers a wave collects before it appends them to the second list
 // histogram bin of a float32 squared distance d <= thr: two roundings of monotone operations, hence monotone in d
@@ -1915,13 +1850,13 @@ __device__ __forceinline__ int ringf_bin(float d32, float inv_thr)
 }
 constexpr int ringf_cand(int kcap) { return kcap <= 17 ? 128 : (kcap <= 33 ? 256 : 512); }
 template <int KCAP>
-__global__ __launch_bounds__(BRICK_THREADS, KCAP <= 33 ? GSX_RINGF_WAVES : 3) void knn_ring_fast_kernel(
+__global__ __launch_bounds__(BRICK_THREADS, KCAP <= 33 ? RINGF_WAVES : 3) void knn_ring_fast_kernel(
     GridParams *__restrict__ gp, const float4 *__restrict__ refs, const unsigned *__restrict__ rstart,
     const float4 *__restrict__ qpts, const unsigned *__restrict__ faillist, unsigned *__restrict__ ring2, int k, int q_begin,
     int64_t n_ref, float *__restrict__ mean_out, double *__restrict__ kth_out)
 {
     constexpr int CAND = ringf_cand(KCAP);
-    constexpr int NF = GSX_RINGF_INFLIGHT;
+    constexpr int NF = RINGF_INFLIGHT;
     __shared__ double s_out[BRICK_THREADS / 64][KCAP];
     __shared__ int s_rs[BRICK_THREADS / 64][RINGF_ROWS];
     __shared__ int s_ro[BRICK_THREADS / 64][RINGF_ROWS + 1];
@@ -1945,7 +1880,7 @@ __global__ __launch_bounds__(BRICK_THREADS, KCAP <= 33 ? GSX_RINGF_WAVES : 3) vo
     // r_t: ~5(k+1) points expected inside at the cloud's mean density, at most 1.9 cell edges (2 cells certify 1.998)
     const double per_cell = (double)n_ref / (double)max(g.ncells, 1);
     const double rt_max = 1.9 * g.hprime;
-    const double rt_first = __builtin_fmin(::cbrt(GSX_RINGF_TARGET * kk / (4.18879 * per_cell)) * g.hprime, rt_max);
+    const double rt_first = __builtin_fmin(::cbrt(RINGF_TARGET * kk / (4.18879 * per_cell)) * g.hprime, rt_max);
 
     int nleft = 0;   // wave-uniform
     auto flush_left = [&]() __attribute__((always_inline)) {
@@ -2149,7 +2084,7 @@ static int launch_ring(gsx_ctx *ctx, const BrickLaunch &a)
         occ_fast = std::max(1, std::min(occ_fast, 8));
     }
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
-    const bool fast = GSX_RING_FAST && ctx->ring_fast;
+    const bool fast = ctx->ring_fast;
     if (fast)
         hipLaunchKernelGGL((knn_ring_fast_kernel<KCAP>), dim3(ctx->num_cu * occ_fast), dim3(BRICK_THREADS), 0, ctx->stream, a.gp, a.refs,
                            a.rstart, a.qpts, a.faillist, a.ring2, a.k, (int)a.q_begin, a.n_ref, a.mean_out, a.kth_out);

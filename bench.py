@@ -1,19 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- SOR (Statistical Outlier Removal) throughput on MI355X.
+"""bench.py -- the point-cloud filtering hot path of 3dgsconverter on MI355X, every BASELINE.json config on one line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n SPLATS_PER_GPU] [--k 16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python bench.py --workload kmeans        # BASELINE.json configs[4] (SOG palette K-Means), 1 GPU
+    python bench.py --workload kmeans [--gpus N]   # BASELINE.json configs[4] alone (strong scaling over the chunks)
 
-One SOR step = one pass of the hot path over one batch of synthetic splats whose xyz is already
-resident in HBM: grid binning -> exact KNN mean distance (knn_brick + knn_ring) -> numpy-exact
-mean/std/threshold -> survivor mask; with N > 1 the splats are sharded by index and the step is the slab
-exchange of 3dgsconverter_amd/dist_slab.py (RCCL all-to-all of xyz rows + halo, slab KNN, all-to-all of
-the mean distances back, all-gather of numpy's 8192-piece sums).  Workload at N=1: the configuration
-BASELINE.json's target is quoted on -- 10M uniform-random splats (L=5, seed 0: SURVEY.md 8(d)
-config 3's cloud), k=16, sigma=1.0; each extra GPU adds one more 10M-splat index shard (weak
-scaling).  The 1M-splat configs[1] cloud is timed in the same run and reported under "secondary".
-Prints ONE JSON line (rank 0).
+HEADLINE (the top-level fields; BASELINE.json's metric): one SOR step = one pass of the hot path over one batch of
+synthetic splats whose xyz is already resident in HBM: grid binning -> exact KNN mean distance (knn_brick +
+knn_ring_fast) -> numpy-exact mean/std/threshold -> survivor mask.  Workload at N=1: the configuration the target is
+quoted on -- 10M uniform-random splats (L=5, seed 0: SURVEY.md 8(d) config 3's cloud), k=16, sigma=1.0; with N > 1 each
+GPU adds one more 10M-splat index shard (weak scaling) and the step is the slab exchange of
+3dgsconverter_amd/dist_slab.py (RCCL from the C library).
+
+At N=1 the same run also times, and reports under "configs", every other BASELINE.json configuration and the clouds a
+uniform grid is bad at -- each with its own roofline and CPU baseline:
+    config1       1M splats SOR k=16 (configs[1])
+    config2       10M splats: density filter (sensitivity 0.5) -> SOR k=16 on the survivors, rows resident in HBM across
+                  both filters (configs[2]; the device chain `install()` gives the reference's orchestrator)
+    config4       10M-splat SOG SH-palette K-Means (configs[4]: 64 chunks x (156 250 x 45), K=1024, 10 iterations)
+    host_to_host  the 10M SOR call from a contiguous host xyz array to a host mask (gsx_sor_filter, PCIe included)
+    clustered_1m / floaters_10m   Gaussian blobs of very different density / a scene + 0.5 % far floaters (adaptive grid)
+The N=1 run does not import torch: device memory comes from gsx_dev_malloc / gsx_dev_upload (include/gsx_hip.h), the
+clock is time.perf_counter around gsx_ctx_synchronize.  With N > 1 torch.distributed hands out the RCCL unique id and
+provides the barrier around the timed region; the data path is the C library's.  Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -30,14 +39,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 EVENT_EVERY = 4              # steps of the timed region between two HIP-event pairs around the dominant kernel
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # G wave64 instructions per second (MI355X: 256 CUs, 4 SIMD16 each, 2.4 GHz)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_SLOTS_PER_S = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+N_SIMD = 256 * 4             # MI355X: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9
+# MI355X_MICROARCH.md "Per-instruction cycle constants": a wave64 VALU instruction issues over 2 cycles (f32 / int class,
+# v_fma_f32 = 2 cyc); float64 arithmetic runs at half that rate (78.6 vs 157.3 TFLOP/s vector peak) = 4 cycles; the
+# f64 transcendental seed (v_rsq_f64) at a quarter of the f64 rate = 16
+CYC_F32, CYC_F64, CYC_TRANS_F64 = 2.0, 4.0, 16.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 
-def synth_shard(n, extent, seed):
+# --------------------------------------------------------------------------------------------------- synthetic inputs
+# (bench.py owns its generators so that nothing outside the cpu_baseline legs touches oracle/; they restate
+#  oracle/datasets.py, which the golden fixtures are built from)
+def synth_uniform(n, extent, seed):
     """SURVEY.md 8(c) generator; shard r of the global cloud uses seed r."""
     return np.random.default_rng(seed).random((n, 3), dtype=np.float32) * np.float32(extent)
+
+
+def synth_clustered(n, seed=0):
+    """six Gaussian blobs (sigma 0.05 ... 1.5, peak densities 27 000 : 1) + 2 % far flyers"""
+    rng = np.random.default_rng(seed)
+    n_out = max(1, n // 50)
+    n_in = n - n_out
+    centers = rng.random((6, 3)) * 20.0 - 10.0
+    sigmas = np.array([0.05, 0.2, 0.5, 1.0, 1.5, 0.1])
+    which = rng.integers(0, 6, n_in)
+    pts = centers[which] + rng.standard_normal((n_in, 3)) * sigmas[which, None]
+    out = rng.random((n_out, 3)) * 80.0 - 40.0
+    xyz = np.concatenate([pts, out]).astype(np.float32)
+    return xyz[rng.permutation(n)]
+
+
+def synth_scene_with_floaters(n, seed=0, far=500.0):
+    """99.5 % of the splats in a 10^3 box, 0.5 % floaters spread over (2 far)^3: what SOR exists for"""
+    rng = np.random.default_rng(seed)
+    n_out = max(1, n // 200)
+    pts = rng.random((n - n_out, 3)) * 10.0
+    out = rng.random((n_out, 3)) * (2.0 * far) - far
+    xyz = np.concatenate([pts, out]).astype(np.float32)
+    return xyz[rng.permutation(n)]
 
 
 def load_pmc(kernel, n, k):
@@ -49,37 +90,433 @@ def load_pmc(kernel, n, k):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sor", choices=["sor", "kmeans"])
-    ap.add_argument("--n", type=int, default=10_000_000, help="splats per GPU")
-    ap.add_argument("--k", type=int, default=16)
-    ap.add_argument("--sigma", type=float, default=1.0)
-    ap.add_argument("--extent", type=float, default=5.0)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto (grid), 1 brute force, 2 grid")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-splat configs[1] line (N=1) / the 50M k=32 configs[3] line (N>1)")
-    ap.add_argument("--config3", action="store_true", help="N=1: also run the 50M-splat k=32 configs[3] workload on this one GPU")
-    ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
-                    help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
-                         "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------------------- rooflines
+def sor_roofline(n, k, knn_ms, algo=0, n_total=None, single=True):
+    """dominant kernel of a SOR step: knn_brick (or knn_brute with --algo 1)"""
+    if algo != 1:
+        # algorithmic bytes of ONE knn_brick launch (DESIGN.md section 5): every brick streams its 4x4x4-cell neighbourhood
+        # once (16 B/point, = 8x its own 2x2x2 cells on average), every query reads its own point (16 B) and writes one
+        # f32: (8*16 + 16 + 4) B per splat
+        bytes_per_splat = 8 * 16 + 16 + 4
+        kernel = "knn_brick_kernel"
+    else:
+        bytes_per_splat = 16.0 * ((n_total or n) / 512.0) + 20      # SURVEY.md 8(d): 16 B per reference point per 512-query WG
+        kernel = "knn_brute_kernel"
+    alg_bytes = bytes_per_splat * n
+    achieved = alg_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
+    pmc = load_pmc(kernel, n, k) if single else None
+    traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc and "fetch_bytes" in pmc else None
+    hbm = {"bound": "hbm", "kernel": kernel, "kernel_ms": round(knn_ms, 4), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(alg_bytes),
+           "algorithmic_bytes_per_splat": bytes_per_splat, "traffic": traffic,
+           "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json (fetch as "
+                            "counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
+           "note": "BASELINE.json's metric: algorithmic HBM bytes of one launch / its HIP-event duration vs 8 TB/s.  The kernel "
+                   "is bound by VALU issue and latency, not by HBM (see valu_issue)"}
+    if pmc and pmc.get("valu_insts") and knn_ms > 0:
+        # VALU issue cycles of one launch from the committed instruction counts (a property of build + cloud, labelled
+        # static) weighted with the guide's per-instruction cycles, against SIMDs x clock x this run's kernel duration
+        f64 = pmc.get("valu_f64_insts")
+        trans = pmc.get("valu_trans_f64_insts", 0)
+        if f64 is not None:
+            cycles = CYC_F64 * f64 + CYC_TRANS_F64 * trans + CYC_F32 * (pmc["valu_insts"] - f64 - trans)
+            mix = "measured split: %d float64-class + %d f64 transcendental + %d other wave-instructions" % (
+                f64, trans, pmc["valu_insts"] - f64 - trans)
+        else:
+            cycles = CYC_F32 * pmc["valu_insts"]
+            mix = "no f32/f64 split committed for this build: every instruction priced at the f32 rate (a lower bound)"
+        cap = N_SIMD * CLOCK_HZ * knn_ms * 1e-3
+        hbm["valu_issue"] = {"frac": round(cycles / cap, 4), "issue_cycles": int(cycles), "capacity_cycles": int(cap),
+                             "insts_per_launch": pmc["valu_insts"], "mix": mix, "busy_frac_pmc": pmc.get("valu_busy_frac"),
+                             "peak_note": "MI355X_MICROARCH.md cycle constants: f32/int wave64 VALU 2 cyc, f64 4 cyc, v_rsq_f64 16 cyc; "
+                                          "1024 SIMDs x 2.4 GHz nominal",
+                             "kind": "static instruction counts: rocprofv3 --pmc pass of this build (%s); live duration" % pmc.get("source", "pmc_latest.json")}
+    return hbm
 
-    # stdout carries exactly ONE JSON line: RCCL (banner, warnings) and other libraries print to the C stdout, so
-    # file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a private copy of the real one
-    sys.stdout.flush()
-    args.json_fd = os.dup(1)
-    os.dup2(2, 1)
 
-    if args.workload == "kmeans":
-        from importlib import import_module
-        return import_module("tools.bench_kmeans").main(args)
+def hbm_roofline(kernel, alg_bytes, ms, note):
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kernel, "kernel_ms": round(ms, 4), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(alg_bytes), "traffic": None, "note": note}
 
-    import torch  # first: its bundled HIP runtime (same SONAME) is the one the .so binds to
+
+# --------------------------------------------------------------------------------------------------- single GPU, no torch
+class SorBench:
+    """one cloud resident in HBM + the buffers of a SOR step (gsx_dev_malloc; nothing is allocated inside a step)"""
+
+    def __init__(self, L, ctx, xyz_host, k, sigma, algo=0):
+        self.L, self.ctx, self.k, self.sigma, self.algo = L, ctx, int(k), float(sigma), int(algo)
+        self.n = len(xyz_host)
+        self.xyz = ctx.alloc(max(xyz_host.nbytes, 16)).upload(xyz_host)
+        self.md = ctx.alloc(4 * self.n + 16)
+        self.stats = ctx.alloc(16)
+        self.mask = ctx.alloc(self.n + 16)
+
+    def step(self):
+        p, c = self.xyz.ptr, self.ctx
+        c.sor_knn(p, p + 4, p + 8, 3, self.n, 0, self.n, self.k, self.md.ptr, algo=self.algo)
+        c.sor_stats(self.md.ptr, self.n, self.sigma, self.stats.ptr)
+        c.sor_mask(self.md.ptr, self.n, self.stats.ptr + 8, self.mask.ptr)
+
+    def info(self):
+        p = self.xyz.ptr
+        return self.ctx.sor_knn(p, p + 4, p + 8, 3, self.n, 0, self.n, self.k, self.md.ptr, algo=self.algo, want_info=True)
+
+    def results(self):
+        self.ctx.check()
+        mask = self.mask.download(np.uint8, self.n).view(np.bool_)
+        return mask, self.stats.download(np.float32, 3)
+
+    def free(self):
+        for b in (self.xyz, self.md, self.stats, self.mask):
+            b.free()
+
+
+def time_steps(ctx, step, steps, warmup, event_slot=None, L=None):
+    """W untimed steps, then K steps between two synchronisations; HIP events around `event_slot`'s kernels on every
+    EVENT_EVERY-th timed step (an event pair leaves a ~10 us bubble on either side of the kernel it brackets)"""
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()
+    if event_slot is not None:
+        ctx.set_param("timing_mask", 1 << event_slot)
+        ctx.set_timing(True)
+        ctx.reset_timing()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if event_slot is not None:
+            ctx.set_timing(i % EVENT_EVERY == 0)
+        step()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"dt": dt, "ms_per_step": dt / steps * 1e3}
+    if event_slot is not None:
+        ctx.set_timing(True)
+        cnt, ms = ctx.timing(event_slot)
+        out["event_ms"] = ms / max(cnt, 1)
+        ctx.set_timing(False)
+    return out
+
+
+def kernel_groups(ctx, L, step, slots, steps):
+    """a short separate pass with every slot recording (not in a timed region)"""
+    ctx.set_param("timing_mask", 0xff)
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    out = {name: round(ctx.timing(slot)[1] / steps, 4) for name, slot in slots.items()}
+    ctx.set_timing(False)
+    return out
+
+
+def cpu_sor(xyz_host, k, sigma, gpu_mask):
+    """cpu_baseline leg: the reference's CPU path (cKDTree + numpy, restated in oracle/sor.py because the reference never
+    returns its mask) on the SAME cloud, host cores"""
+    from oracle import sor as osor
+    workers = max(1, (os.cpu_count() or 2) - 1)
+    t0 = time.perf_counter()
+    ref = osor.sor(xyz_host, k, sigma, workers=workers)
+    cpu_dt = time.perf_counter() - t0
+    n = len(xyz_host)
+    return {"value": round(n / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": workers, "kind": "port",
+            "sample": "the full %d-splat workload, once (%.2f s): scipy cKDTree query workers=%d + numpy stats" % (n, cpu_dt, workers),
+            "mask_identical_to_gpu": bool(np.array_equal(ref["mask"], gpu_mask))}
+
+
+def run_sor(L, ctx, xyz_host, k, sigma, steps, warmup, algo=0, groups=False, cpu=False, adaptive=False):
+    ctx.set_param("adaptive", 1 if adaptive else 0)
+    b = SorBench(L, ctx, xyz_host, k, sigma, algo)
+    try:
+        t = time_steps(ctx, b.step, steps, warmup, event_slot=L.T_SOR_KNN, L=L)
+        mask, stats = b.results()
+        n = b.n
+        out = {"value": round(n * steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(t["ms_per_step"], 4),
+               "steps": steps, "warmup": warmup, "knn_kernel_ms": round(t["event_ms"], 4), "survivors": int(mask.sum()),
+               "threshold": float(stats[2])}
+        if groups:
+            side = min(steps, 10)
+            g = kernel_groups(ctx, L, b.step, {"bin": L.T_SOR_BIN, "fallback": L.T_SOR_FALLBACK, "stats": L.T_SOR_STATS}, side)
+            out["kernel_ms_per_step"] = dict({"knn": round(t["event_ms"], 4)}, **g,
+                                             note="knn: HIP events inside the timed region (every %d-th step); the others: a "
+                                                  "separate pass of %d steps" % (EVENT_EVERY, side))
+        out["grid"] = b.info()
+        ctx.synchronize()
+        if cpu:
+            out["cpu_baseline"] = cpu_sor(xyz_host, k, sigma, mask)
+        return out
+    finally:
+        b.free()
+        ctx.set_param("adaptive", 0)
+
+
+def run_host_to_host(L, xyz_host, k, sigma, reps=3):
+    """SURVEY.md 8(d) "Metric": N / wall time of the filter call from contiguous host xyz to host mask (gsx_sor_filter:
+    upload over PCIe, the device pipeline, mask download) -- never the headline value"""
+    L.sor_filter(xyz_host, k, sigma, want_mean=False)   # warm: workspace allocation, first-touch of the pinned staging
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = L.sor_filter(xyz_host, k, sigma, want_mean=False)
+        ts.append(time.perf_counter() - t0)
+    n = len(xyz_host)
+    best = min(ts)
+    return {"workload": "gsx_sor_filter: %d splats, host (n,3) f32 array -> host mask, k=%d (PCIe both ways included)" % (n, k),
+            "ms_per_call": round(best * 1e3, 3), "ms_per_call_all": [round(t * 1e3, 3) for t in ts], "value": round(n / best / 1e6, 2),
+            "unit": "Msplats/s", "pcie_bytes": 12 * n + n, "survivors": int(res["mask"].sum())}
+
+
+def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup, cpu=False):
+    """BASELINE.json configs[2]: density filter -> SOR on rows that stay in HBM (what ChainedDataProcessor does between
+    `DataProcessor(data)` and `.data`; converter.py:205-236 order).  One step = restore the pristine rows (device copy),
+    voxel occupancy, host cluster selection (<= 181 dense voxels), membership mask + compaction, SOR + compaction."""
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    clusters = importlib.import_module("3dgsconverter_amd.processing.clusters")
+    voxel, thr = dp.density_params_from_sensitivity(sensitivity)
+    ch = L.DeviceChain(xyz_host, keep_pristine=True)
+    n = len(xyz_host)
+    last = {}
+
+    def step():
+        ch.restart()
+        min_points = int(ch.n * (thr / 100.0))
+        occ = ch.density_voxels(float(voxel), min_points)
+        comps = clusters.connected_clusters(map(tuple, occ["dense_keys"].tolist()))
+        kept, _, _ = clusters.select_clusters(comps, False)
+        last["after_density"] = ch.density_keep(float(voxel), np.array(sorted(kept), dtype=np.int64).reshape(-1, 3))
+        last["sor"] = ch.sor_keep(k, sigma)
+
+    try:
+        c = ch.ctx
+        t = time_steps(c, step, steps, warmup)
+        g = kernel_groups(c, L, step, {"density": L.T_DENSITY, "knn": L.T_SOR_KNN, "bin": L.T_SOR_BIN, "fallback": L.T_SOR_FALLBACK,
+                                       "stats": L.T_SOR_STATS}, min(steps, 5))
+        survivors = ch.survivors()
+        out = {"workload": "BASELINE.json configs[2]: %d uniform-random splats (L=5, seed 0), density sensitivity %.1f (voxel %.2f, "
+                           "%.2f %%) then SOR k=%d sigma=%g on the survivors, rows resident in HBM across both filters" % (n, sensitivity, voxel, thr, k, sigma),
+               "value": round(n * steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(t["ms_per_step"], 4), "steps": steps,
+               "after_density": int(last["after_density"]), "survivors": int(len(survivors)), "sor_threshold": float(last["sor"]["threshold"]),
+               "kernel_ms_per_step": g,
+               # density kernels: two passes over the rows (12 B each) + 1 B mask = 25 B/splat (SURVEY.md 8(d))
+               "roofline": hbm_roofline("voxel_count + voxel_collect + voxel_mask (density.hip)", 25.0 * n, g["density"],
+                                        "density stage: 25 algorithmic B/splat over the HIP-event time of its kernels; the SOR stage of "
+                                        "this chain has the headline's roofline"),
+               "note": "includes one host round trip per filter (dense-voxel list down, kept-voxel list up; statistics down) and "
+                       "two device compactions; the 248-byte host table is compacted once afterwards, outside this step"}
+        if cpu:
+            # cpu_baseline leg: the reference's apply_density_filter (pure numpy/Python, restated in oracle/density.py) on a
+            # bounded sample
+            from oracle import density as oden
+            m = min(n, 2_000_000)
+            t0 = time.perf_counter()
+            oden.density_filter(xyz_host[:m], float(voxel), float(thr))
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": "Msplats/s", "cores": 1, "kind": "port",
+                                   "sample": "density stage only, the first %d splats of the cloud, once (%.2f s): np.unique(axis=0) + "
+                                             "Python BFS as the reference does; the SOR stage's CPU baseline is the headline's" % (m, dt)}
+        return out
+    finally:
+        ch.close()
+
+
+def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
+    """BASELINE.json configs[4] with SURVEY.md 8(d) config-5 data: f_rest ~ N(0, 0.1^2) f32 from numpy's seed-0 generator,
+    initial centroids = random rows drawn like the reference's front door (np.random.seed(0); one np.random.choice per chunk,
+    gpu_ops.py:182).  One step = all chunks of the scene, SH rows resident in HBM."""
+    pal = importlib.import_module("3dgsconverter_amd.dist_palette")
+    d, iters, level = 45, 10, 2
+    plan = pal.palette_plan(n_scene, level)
+    nch, cs, k = plan["num_chunks"], plan["chunk_size"], plan["k_per_chunk"]
+    rng = np.random.default_rng(0)
+    np.random.seed(0)
+    chunks, inits, cents, labels, first_host = [], [], [], [], None
+    for i in range(nch):
+        rows = min(cs, n_scene - i * cs)
+        x = rng.standard_normal((rows, d), dtype=np.float32) * np.float32(0.1)
+        init = x[np.random.choice(rows, k, replace=False)]
+        if i == 0:
+            first_host = x
+        chunks.append((ctx.alloc(x.nbytes).upload(x), rows))
+        inits.append(ctx.alloc(init.nbytes).upload(np.ascontiguousarray(init)))
+        cents.append(ctx.alloc(init.nbytes))
+        labels.append(ctx.alloc(4 * rows + 16))
+    for name, val in params:
+        ctx.set_param(name, val)
+
+    def step():
+        for j in range(nch):
+            L.check(ctx.lib.gsx_dev_copy(ctx.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
+            L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
+                    "gsx_kmeans_lloyd_dev")
+
+    try:
+        t = time_steps(ctx, step, steps, warmup)
+        side = 1
+        ctx.set_param("timing_mask", (1 << L.T_KMEANS_ASSIGN) | (1 << L.T_KMEANS_UPDATE))
+        ctx.set_timing(True)
+        ctx.reset_timing()
+        step()
+        ctx.synchronize()
+        n_as, ms_as = ctx.timing(L.T_KMEANS_ASSIGN)
+        n_up, ms_up = ctx.timing(L.T_KMEANS_UPDATE)
+        ctx.set_timing(False)
+        assign_ms = ms_as / max(n_as, 1)            # one interval = operand prep + matrix-core assign + exact list, one chunk iteration
+        rows0 = chunks[0][1]
+        ktiles, ns = (k + 31) // 32, 3              # 32-centroid tiles, three 16-wide slices of the 45 (+3) dimensions
+        # three v_mfma_f32_32x32x16_bf16 per slice (xh.ch + xh.cl + xl.ch), 2*32*32*16 flops each, per (32 points x 32 centroids)
+        flops = -(-rows0 // 32) * ktiles * ns * 3 * 2 * 32 * 32 * 16
+        achieved = flops / (assign_ms * 1e-3) / 1e12 if assign_ms > 0 else 0.0
+        alg_bytes = rows0 * (4 * d + 4)             # SURVEY.md 8(d): read the rows once, write one label
+        out = {"workload": "BASELINE.json configs[4]: %d splats, degree-3 SH rows (45 f32 ~ N(0, 0.1^2), numpy seed 0), "
+                           "compression_level %d -> %d chunks of %d rows, K=%d per chunk, %d Lloyd iterations, rows resident in HBM"
+                           % (n_scene, level, nch, cs, k, iters),
+               "value": round(n_scene * steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(t["ms_per_step"], 3), "steps": steps,
+               "kernel_ms_per_step": {"assign (operands + mfma + exact list)": round(ms_as / side, 3),
+                                      "update (label sort + segmented reduce)": round(ms_up / side, 3)},
+               "roofline": {"bound": "mfma", "kernel": "kmeans_assign_mfma_cs_kernel<45> (+ operand prep and exact list kernel in the same interval)",
+                            "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(assign_ms, 4),
+                            "flops_per_launch": flops, "algorithmic_bytes": alg_bytes,
+                            "hbm_frac_of_8TBs": round(alg_bytes / (assign_ms * 1e-3) / 8e12, 5) if assign_ms > 0 else None,
+                            "note": "bf16 matrix-core flops actually issued (a FILTER: 9 MFMAs per 32x32 tile incl. the two cross terms of "
+                                    "the bf16 split); labels are certified exact, the uncertified ~0.3 % are rescanned in f32"}}
+        if cpu:
+            # cpu_baseline leg: the reference's CPU path for the same call (gpu_ops.py:48-52: MiniBatchKMeans, batch 16384,
+            # n_init auto), ONE chunk
+            from sklearn.cluster import MiniBatchKMeans
+            from oracle import kmeans as okm
+            t0 = time.perf_counter()
+            km = MiniBatchKMeans(n_clusters=k, max_iter=iters, batch_size=min(4096 * 4, rows0), n_init="auto", compute_labels=True)
+            km.fit(first_host)
+            cpu_dt = time.perf_counter() - t0
+            c0 = cents[0].download(np.float32, k * d).reshape(k, d)
+            l0 = labels[0].download(np.int32, rows0)
+            out["cpu_baseline"] = {"value": round(rows0 / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "one of the %d chunks (%d x %d, K=%d, max_iter=%d), once (%.2f s): sklearn MiniBatchKMeans "
+                                             "called as the reference's _kmeans_sklearn does" % (nch, rows0, d, k, iters, cpu_dt),
+                                   "inertia_cpu": round(okm.inertia(first_host, km.cluster_centers_, km.labels_), 2),
+                                   "inertia_gpu_same_chunk": round(okm.inertia(first_host, c0, l0), 2)}
+        return out
+    finally:
+        for b, _ in chunks:
+            b.free()
+        for b in inits + cents + labels:
+            b.free()
+
+
+def main_single(args):
+    gsx = importlib.import_module("3dgsconverter_amd")
+    L = gsx._lib
+    ctx = L.Context(0)
+    for kv in args.param:
+        name, val = kv.split("=")
+        ctx.set_param(name, float(val))
+    want_cpu = not args.no_cpu_baseline
+    small = max(3, min(args.steps, 5))
+    t_start = time.perf_counter()
+
+    if args.exchange == "slab":
+        return main_slab_one_rank(args, gsx, L, ctx)
+
+    xyz = synth_uniform(args.n, args.extent, 0)
+    head = run_sor(L, ctx, xyz, args.k, args.sigma, args.steps, args.warmup, algo=args.algo, groups=True, cpu=want_cpu)
+    roof = sor_roofline(args.n, args.k, head["knn_kernel_ms"], args.algo)
+    out = {
+        "metric": "Msplats/sec SOR k=%d" % args.k, "value": head["value"], "unit": "Msplats/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 select / f64 finalize", "data": "synthetic",
+        "config": {"workload": "%d uniform-random splats per GPU (L=%g, seed=rank), SOR k=%d sigma=%g, exact KNN, xyz resident in HBM"
+                               % (args.n, args.extent, args.k, args.sigma),
+                   "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma,
+                   "algo": "grid-binned exact KNN" if args.algo != 1 else "LDS-tiled brute force", "parallelism": "single GPU",
+                   "host_runtime": "numpy + ctypes on libgsx_hip.so (gsx_dev_malloc / gsx_dev_upload); torch is not imported"},
+        "roofline": roof, "kernel_ms_per_step": head["kernel_ms_per_step"], "survivors_rank0": head["survivors"],
+        "threshold": head["threshold"], "grid": head["grid"]}
+    if "cpu_baseline" in head:
+        out["cpu_baseline"] = head["cpu_baseline"]
+
+    if not args.no_secondary:
+        configs = {}
+
+        def attempt(name, fn):
+            try:
+                configs[name] = fn()
+            except Exception as e:   # noqa: BLE001 -- the headline line must survive a failure in a secondary configuration
+                configs[name] = {"error": repr(e)}
+
+        def config1():
+            x1 = synth_uniform(1_000_000, 10.0, 0)
+            r = run_sor(L, ctx, x1, args.k, args.sigma, max(args.steps, 50), max(args.warmup, 5), cpu=want_cpu)
+            r["workload"] = "BASELINE.json configs[1]: 1000000 uniform-random splats (L=10, seed 0), SOR k=%d sigma=%g" % (args.k, args.sigma)
+            r["roofline"] = sor_roofline(1_000_000, args.k, r["knn_kernel_ms"])
+            return r
+
+        def clustered():
+            xc = synth_clustered(1_000_000, 0)
+            r = run_sor(L, ctx, xc, args.k, args.sigma, small, 2, cpu=want_cpu, adaptive=True)
+            r["workload"] = "1000000 splats in six Gaussian blobs (sigma 0.05...1.5) + 2 %% far flyers, SOR k=%d, adaptive grid" % args.k
+            r["roofline"] = sor_roofline(1_000_000, args.k, r["knn_kernel_ms"], single=False)
+            r["roofline"]["note"] = "knn_brick launches of all refinement levels together; " + r["roofline"]["note"]
+            return r
+
+        def floaters():
+            xf = synth_scene_with_floaters(args.n, 0)
+            r = run_sor(L, ctx, xf, args.k, args.sigma, small, 2, cpu=want_cpu, adaptive=True)
+            r["workload"] = "%d splats: a 10^3 scene + 0.5 %% floaters in a 1000^3 box, SOR k=%d, adaptive grid" % (args.n, args.k)
+            r["roofline"] = sor_roofline(args.n, args.k, r["knn_kernel_ms"], single=False)
+            r["roofline"]["note"] = "knn_brick launches of all refinement levels together; " + r["roofline"]["note"]
+            return r
+
+        attempt("config1", config1)
+        attempt("host_to_host", lambda: run_host_to_host(L, xyz, args.k, args.sigma))
+        attempt("config2", lambda: run_chain(L, ctx, gsx, xyz, 0.5, args.k, args.sigma, small, 2, cpu=want_cpu))
+        attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu))
+        attempt("clustered_1m", clustered)
+        attempt("floaters_10m", floaters)
+        out["configs"] = configs
+        out["secondary"] = configs.get("config1")     # the name round 2's line used
+    out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+    os.write(args.json_fd, (json.dumps(out) + "\n").encode())
+
+
+def main_slab_one_rank(args, gsx, L, ctx):
+    """--exchange slab with one GPU: what ONE rank of an N-GPU job executes (partition, self-exchange through a one-rank
+    RCCL communicator, slab KNN, certificate, un-permute, piece-sum statistics) -- no torch either"""
+    gslab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    be = gslab.HipSlabBackend(ctx=ctx)
+    comm = gslab.RcclComm(ctx, 0, 1, gslab.RcclComm.unique_id())
+    xyz = synth_uniform(args.n, args.extent, 0)
+    dev = ctx.alloc(xyz.nbytes).upload(xyz)
+    res = {}
+
+    def step():
+        res["r"] = gslab.slab_sor(be, comm, gslab._View(dev.ptr), args.n, args.k, args.sigma)
+
+    step()
+    res["r"].check()
+    t = time_steps(ctx, step, args.steps, args.warmup, event_slot=L.T_SOR_KNN, L=L)
+    res["r"].check()
+    mask = be.to_host(res["r"]["mask"], np.uint8, args.n)
+    stats = be.to_host(res["r"]["stats"], np.float32, 3)
+    g = kernel_groups(ctx, L, step, {"bin": L.T_SOR_BIN, "fallback": L.T_SOR_FALLBACK, "stats": L.T_SOR_STATS}, min(args.steps, 10))
+    roof = sor_roofline(args.n, args.k, t["event_ms"], single=False)
+    out = {"metric": "Msplats/sec SOR k=%d" % args.k, "value": round(args.n * args.steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 select / f64 finalize", "data": "synthetic",
+           "config": {"workload": "%d uniform-random splats (L=%g, seed 0), SOR k=%d sigma=%g: the slab pipeline of one rank" % (args.n, args.extent, args.k, args.sigma),
+                      "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma, "parallelism": gslab.PARALLELISM + " -- one-rank communicator"},
+           "roofline": roof, "kernel_ms_per_step": dict({"knn": round(t["event_ms"], 4)}, **g), "survivors_rank0": int(mask.astype(bool).sum()),
+           "threshold": float(stats[2])}
+    ctx.check()
+    comm.close()
+    os.write(args.json_fd, (json.dumps(out) + "\n").encode())
+
+
+# --------------------------------------------------------------------------------------------------- N > 1 (torch.distributed)
+def main_multi(args):
+    import torch  # first: its bundled HIP runtime (same SONAME) is the one the .so binds to in this process
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,9 +526,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
 
     gsx = importlib.import_module("3dgsconverter_amd")
     gdist = importlib.import_module("3dgsconverter_amd.dist")
@@ -102,30 +538,26 @@ def main():
     for kv in args.param:
         name, val = kv.split("=")
         ctx.set_param(name, float(val))
-    # N > 1: spatial slabs, every collective of the data path is RCCL called from libgsx_hip.so on the library's
-    # stream (3dgsconverter_amd/dist_slab.py); torch.distributed only hands the 128-byte unique id out and times
+    # spatial slabs: every collective of the data path is RCCL called from libgsx_hip.so on the library's stream
+    # (3dgsconverter_amd/dist_slab.py); torch.distributed only hands the 128-byte unique id out and times
     slab_be = slab_comm = None
-    exchange = {"path": "single GPU"}
-    if (world > 1 and args.exchange != "replicated") or args.exchange == "slab":
+    exchange = {"path": "replicated (requested)"}
+    if args.exchange != "replicated":
         uid = [gslab.RcclComm.unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
+        dist.broadcast_object_list(uid, src=0)
         slab_be = gslab.HipSlabBackend(ctx=ctx)
         slab_comm = gslab.RcclComm(ctx, rank, world, uid[0])
         exchange["path"] = "slab"
-    elif world > 1:
-        exchange["path"] = "replicated (requested)"
 
     def barrier():
         ctx.synchronize()          # the library's stream (its RCCL calls too) is drained before torch's communicator runs
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n, extent, steps, warmup, side=True, k=None):
+    def run(n, extent, steps, warmup, k=None):
         """Time `steps` SOR steps on a fresh n-splat shard; returns a dict of raw measurements."""
         k = args.k if k is None else k
-        xyz_host = synth_shard(n, extent, rank)
+        xyz_host = synth_uniform(n, extent, rank)
         xyz_local = torch.from_numpy(xyz_host).to(dev)
         torch.cuda.synchronize()
         exchange.pop("certified", None)
@@ -151,20 +583,18 @@ def main():
                         exchange["certified"] = True
                     return _SlabRes(r)
                 except gslab.SlabUncertain as e:   # raised on every rank together (the count is all-reduced)
-                    exchange["path"] = "replicated (slab certificate failed: %s)" % e
+                    exchange["path"] = "replicated (slab exchange declined: %s)" % e
                     compute.set_adaptive(True)     # the clouds that get here are the ones the adaptive grid exists for
             return gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
 
-        if world > 1 and exchange["path"] == "slab" and not exchange.get("cross_checked"):
+        if exchange["path"] == "slab" and not exchange.get("cross_checked"):
             # the slab exchange and the replicated one (all-gather of the rows, every rank bins everything) must agree
             # bit for bit -- statistics and this rank's survivor mask -- before the slab path is what gets timed
             ref = gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
             ok = 1
             try:
                 got = step()
-                if not isinstance(got, _SlabRes):
-                    ok = 1   # the certificate already sent this cloud to the replicated path
-                else:
+                if isinstance(got, _SlabRes):
                     same_stats = bool(np.array_equal(got.stats.numpy().view(np.uint32), ref.stats.cpu().numpy().view(np.uint32)[:3]))
                     same_mask = bool(np.array_equal(got.mask_local.numpy().astype(bool), ref.mask_local.cpu().numpy().astype(bool)))
                     ok = 1 if (same_stats and same_mask) else 0
@@ -182,180 +612,100 @@ def main():
         for _ in range(warmup):
             res = step()
         barrier()
-        # HIP events around the dominant kernel only inside the timed region: each event pair costs stream
-        # time (all five slots = +0.04 ms on a 0.38 ms step, profiles/r01_timing_overhead.log)
         ctx.set_param("timing_mask", 1 << L.T_SOR_KNN)
         ctx.set_timing(True)
         ctx.reset_timing()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            # an event pair leaves a ~10 us bubble on either side of the kernel it brackets (6 % of the 1M-splat step):
-            # every fourth step of the timed region carries one, the kernel average below is over those steps
             ctx.set_timing(i % EVENT_EVERY == 0)
             res = step()
         barrier()
         dt = time.perf_counter() - t0
         ctx.set_timing(True)
         t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dt = float(t_max.item())
         if isinstance(res, _SlabRes):
             res.r.check()   # the certificate of the last timed step (same cloud every step)
         n_knn, ms_knn = ctx.timing(L.T_SOR_KNN)
-        out = {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "res": res, "xyz_host": xyz_host, "xyz_local": xyz_local}
-        if side:
-            # the other kernel groups: a short separate pass with every slot recording (not in the timed region)
-            ctx.set_param("timing_mask", 0xff)
-            ctx.reset_timing()
-            side_steps = min(steps, 10)
-            for _ in range(side_steps):
-                step()
-            barrier()
-            out["side_steps"] = side_steps
-            out["kernel_ms_per_step"] = {
-                "knn": round(ms_knn / max(n_knn, 1), 4),
-                "bin": round(ctx.timing(L.T_SOR_BIN)[1] / side_steps, 4),
-                "fallback": round(ctx.timing(L.T_SOR_FALLBACK)[1] / side_steps, 4),
-                "stats": round(ctx.timing(L.T_SOR_STATS)[1] / side_steps, 4),
-                "note": "knn: HIP events inside the timed region (every %d-th step); the others: a separate pass of %d steps" % (EVENT_EVERY, side_steps)}
         ctx.set_timing(False)
-        return out
+        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "res": res}
 
     main_run = run(args.n, args.extent, args.steps, args.warmup)
     res = main_run["res"]
-    # read the headline run's results NOW: later runs (secondary configurations) reuse the exchange's device buffers
     survivors_main = int(res.mask_local.sum().item())
     threshold_main = float(res.stats[2].item())
-    mask_main_host = res.mask_local.cpu().numpy().astype(bool) if (world == 1 and not args.no_cpu_baseline) else None
-    info = None
-    if world == 1 and slab_comm is None:
-        t = main_run["xyz_local"]
-        info = ctx.sor_knn(t.data_ptr(), t.data_ptr() + 4, t.data_ptr() + 8, 3, args.n, 0, args.n, args.k,
-                           res.mean_dists_local.data_ptr(), algo=args.algo, want_info=True)
-    secondary = None
-    if world == 1 and slab_comm is None and not args.no_secondary and args.n != 1_000_000:
-        r2 = run(1_000_000, 10.0, max(args.steps, 50), max(args.warmup, 5), side=False)
-        secondary = {"workload": "BASELINE.json configs[1]: 1000000 uniform-random splats (L=10, seed 0), SOR k=%d sigma=%g" % (args.k, args.sigma),
-                     "value": round(1_000_000 * max(args.steps, 50) / r2["dt"] / 1e6, 2), "unit": "Msplats/s",
-                     "ms_per_step": round(r2["dt"] / max(args.steps, 50) * 1e3, 4), "steps": max(args.steps, 50),
-                     "knn_kernel_ms": round(r2["knn_ms"], 4),
-                     "survivors": int(r2["res"].mask_local.sum().item())}
-        del r2
-
     config3 = None
-    if (world > 1 or args.config3) and not args.no_secondary:
+    if not args.no_secondary:
         # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
         # other N the same 50M are split N ways).  Reported next to the headline, never instead of it.
         try:
             n3 = max(8192, (50_000_000 // world) // 4 * 4)
             s3, w3 = max(3, min(args.steps, 10)), 2
-            r3 = run(n3, 10.0, s3, w3, side=False, k=32)
+            r3 = run(n3, 10.0, s3, w3, k=32)
             config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, seed=rank) over %d GPU(s), SOR k=32 "
-                                     "sigma=%g" % (n3 * world, world, args.sigma),
-                         "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
-                         "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
-                         "knn_kernel_ms": round(r3["knn_ms"], 4)}
+                                   "sigma=%g" % (n3 * world, world, args.sigma),
+                       "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
+                       "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
+                       "knn_kernel_ms": round(r3["knn_ms"], 4)}
             del r3
         except Exception as e:   # noqa: BLE001 -- the headline line must survive a failure here
             config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}
-
     if slab_comm is not None:
         ctx.check()
         slab_comm.close()
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    if rank == 0:
+        dt = main_run["dt"]
+        n_total = world * args.n
+        out = {
+            "metric": "Msplats/sec SOR k=%d" % args.k, "value": round(n_total * args.steps / dt / 1e6, 2), "unit": "Msplats/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 select / f64 finalize", "data": "synthetic",
+            "config": {"workload": "%d uniform-random splats per GPU (L=%g, seed=rank), SOR k=%d sigma=%g, exact KNN, xyz resident in HBM"
+                                   % (args.n, args.extent, args.k, args.sigma),
+                       "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma, "algo": "grid-binned exact KNN",
+                       "parallelism": gslab.PARALLELISM if exchange["path"] == "slab" else gdist.PARALLELISM + " -- " + exchange["path"]},
+            "roofline": sor_roofline(args.n, args.k, main_run["knn_ms"], args.algo, n_total=n_total, single=False),
+            "kernel_ms_per_step": {"knn": round(main_run["knn_ms"], 4)},
+            "survivors_rank0": survivors_main, "threshold": threshold_main}
+        if config3 is not None:
+            out["config3"] = config3
+        os.write(args.json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
 
-    dt = main_run["dt"]
-    n_total = world * args.n
-    ms_per_step = dt / args.steps * 1e3
-    value = n_total * args.steps / dt / 1e6  # Msplats/s, whole job
 
-    # ---- roofline of the dominant kernel (knn_brick, or knn_brute with --algo 1)
-    knn_ms = main_run["knn_ms"]
-    if args.algo != 1:
-        # algorithmic bytes of ONE knn_brick launch: every brick streams its
-        # 4x4x4-cell neighbourhood once (16 B/point, = 8x its own 2x2x2 cells on average), every
-        # query reads its own point (16 B) and writes one f32: (8*16 + 16 + 4) B per splat.
-        bytes_per_splat = 8 * 16 + 16 + 4
-        kernel = "knn_brick_kernel"
-    else:
-        # brute force, SURVEY.md 8(d): 16 B per reference point per 512-query workgroup + 20 B/query
-        bytes_per_splat = 16.0 * (n_total / 512.0) + 20
-        kernel = "knn_brute_kernel"
-    alg_bytes = bytes_per_splat * args.n
-    achieved = alg_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
-    pmc = load_pmc(kernel, args.n, args.k) if world == 1 else None
-    traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc and "fetch_bytes" in pmc else None
-    valu = None
-    if pmc and "valu_busy_frac" in pmc:
-        valu = {"busy_frac": pmc["valu_busy_frac"], "insts_per_launch": pmc.get("valu_insts"),
-                "kind": "static: rocprofv3 --pmc pass of this build committed under profiles/ (%s), not measured in this run" % pmc.get("source", "pmc_latest.json")}
-    hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-           "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_per_splat": bytes_per_splat, "traffic": traffic,
-           "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json "
-                            "(fetch as counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
-           "note": "the figures BASELINE.json's metric asks for: algorithmic HBM bytes of one launch / its HIP-event duration vs 8 TB/s"}
-    if valu and valu.get("insts_per_launch") and knn_ms > 0:
-        # the binding resource: VALU issue.  One wave64 instruction occupies its SIMD16 for
-        # >= 4 cycles, so the chip issues at most CUs x 4 SIMDs x clock / 4 wave-instructions per second.  The
-        # instruction count of a launch is a property of (build, cloud) -- taken from the committed PMC pass and labelled
-        # static -- the duration is this run's HIP-event average.
-        peak_ginst = VALU_PEAK_GINST
-        ach_ginst = valu["insts_per_launch"] / (knn_ms * 1e-3) / 1e9
-        roofline = {"bound": "valu", "kernel": kernel, "achieved": round(ach_ginst, 2), "peak": peak_ginst,
-                    "unit": "G wave-instructions/s", "frac": round(ach_ginst / peak_ginst, 4), "traffic": traffic,
-                    "kernel_ms": round(knn_ms, 4),
-                    "valu": dict(valu, name="VALU issue (f32 filter assembly + f64 exact distances, selection network, sqrt)",
-                                 peak_note="256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"),
-                    "hbm": hbm}
-    else:   # multi-GPU runs and configurations without a committed PMC pass: the HBM figures only
-        roofline = dict(hbm, bound="hbm", kernel=kernel, kernel_ms=round(knn_ms, 4),
-                        note="HBM figures only (no committed instruction count for this configuration); the kernel itself is "
-                             "bound by VALU issue, see the N=1 line of the default configuration")
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sor", choices=["sor", "kmeans"])
+    ap.add_argument("--n", type=int, default=10_000_000, help="splats per GPU")
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--extent", type=float, default=5.0)
+    ap.add_argument("--algo", type=int, default=0, help="0 auto (grid), 1 brute force, 2 grid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the other configurations (N=1) / the 50M k=32 configs[3] line (N>1)")
+    ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
+                    help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
+                         "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
+    args = ap.parse_args()
 
-    out = {
-        "metric": "Msplats/sec SOR k=%d" % args.k, "value": round(value, 2), "unit": "Msplats/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 select / f64 finalize",
-        "data": "synthetic",
-        "config": {"workload": "%d uniform-random splats per GPU (L=%g, seed=rank), SOR k=%d sigma=%g, "
-                               "exact KNN, xyz resident in HBM" % (args.n, args.extent, args.k, args.sigma),
-                   "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma,
-                   "algo": "grid-binned exact KNN" if args.algo != 1 else "LDS-tiled brute force",
-                   "parallelism": ((gslab.PARALLELISM if exchange["path"] == "slab" else gdist.PARALLELISM + " -- " + exchange["path"])
-                                   if (world > 1 or slab_comm is not None) else "single GPU")},
-        "roofline": roofline,
-        "kernel_ms_per_step": main_run["kernel_ms_per_step"],
-        "survivors_rank0": survivors_main,
-        "threshold": threshold_main,
-    }
-    if info is not None:
-        out["grid"] = info
-    if secondary is not None:
-        out["secondary"] = secondary
-    if config3 is not None:
-        out["config3"] = config3
+    # stdout carries exactly ONE JSON line: RCCL (banner, warnings) and other libraries print to the C stdout, so
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a private copy of the real one
+    sys.stdout.flush()
+    args.json_fd = os.dup(1)
+    os.dup2(2, 1)
 
-    if world == 1 and not args.no_cpu_baseline:
-        # reported baseline, not the target: the reference's CPU path (cKDTree + numpy, restated in
-        # oracle/sor.py because the reference never returns its mask) on the SAME cloud, host cores.
-        from oracle import sor as osor
-        workers = max(1, (os.cpu_count() or 2) - 1)
-        t0 = time.perf_counter()
-        ref = osor.sor(main_run["xyz_host"], args.k, args.sigma, workers=workers)
-        cpu_dt = time.perf_counter() - t0
-        same = bool(np.array_equal(ref["mask"], mask_main_host))
-        out["cpu_baseline"] = {"value": round(args.n / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": workers,
-                               "kind": "port", "sample": "the full %d-splat workload, once (%.2f s): "
-                               "scipy cKDTree query workers=%d + numpy stats" % (args.n, cpu_dt, workers),
-                               "mask_identical_to_gpu": same}
-    os.write(args.json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
-        dist.destroy_process_group()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload == "kmeans":
+        return importlib.import_module("tools.bench_kmeans").main(args)
+    if world > 1 or args.gpus > 1:
+        return main_multi(args)
+    return main_single(args)
 
 
 if __name__ == "__main__":
