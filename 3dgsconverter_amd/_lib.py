@@ -60,6 +60,10 @@ SIGNATURES = {
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
+    "gsx_host_zero_columns": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I]),
+    "gsx_host_append_columns": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64]),
+    "gsx_rgb_from_sh": (_I, [_P, _I64, _P, _P]),
+    "gsx_rgb_from_sh_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
     "gsx_mask_bbox_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_mask_ge_dev": (_I, [_P, _P, _P, _I64, _D, _P]),
@@ -86,15 +90,25 @@ SIGNATURES = {
     "gsx_density_mask": (_I, [_P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_kmeans_lloyd": (_I, [_P, _I64, _I, _I, _I, _P, _P, _P]),
     "gsx_quantize_sorted_codebook": (_I, [_P, _I64, _P, _I, _P]),
+    "gsx_kmeans_pp": (_I, [_P, _I64, _I, _I, _P, _I, _P]),
+    "gsx_kmeans_pp_dev": (_I, [_P, _P, _I64, _I, _I, _P, _I, _P]),
+    "gsx_kmeans1d": (_I, [_P, _I64, _I, _I, _P, _P, _P]),
+    "gsx_kmeans1d_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     "gsx_lexsort3": (_I, [_P, _P, _P, _I64, _P]),
     "gsx_lexsort3_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
     "gsx_sog_quats": (_I, [_P, _I64, _P]),
+    "gsx_sog_positions": (_I, [_P, _I64, C.c_float, C.c_float, _P, _P]),
+    "gsx_sog_positions_dev": (_I, [_P, _P, _I64, C.c_float, C.c_float, _P, _P]),
+    "gsx_sog_alpha": (_I, [_P, _I64, _P, _P]),
+    "gsx_sog_alpha_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_sog_quats_dev": (_I, [_P, _P, _I64, _P]),
     "gsx_morton_order_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, C.POINTER(_I)]),
     "gsx_cply_pack_dev": (_I, [_P, _P, _P, _I64, _P, _P]),
     "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
+    "gsx_density_hist_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, C.POINTER(_I64), _P, _P]),
+    "gsx_density_merge_dev": (_I, [_P, _P, _P, _I64, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
     "gsx_quantize_sorted_codebook_dev": (_I, [_P, _P, _I64, _P, _I, _P]),
 }
@@ -203,6 +217,61 @@ def host_compact_rows(rows: np.ndarray, mask: np.ndarray) -> np.ndarray:
     return out
 
 
+def host_zero_columns(rows: np.ndarray, names) -> None:
+    """rows[name] = 0.0 for every float32 field in `names`, in place (data_processor.py:310-313), one threaded pass"""
+    fields = rows.dtype.fields or {}
+    names = [nm for nm in names if nm in fields]
+    if not names or len(rows) == 0:
+        return
+    ok = rows.ndim == 1 and rows.flags.c_contiguous and rows.flags.writeable and all(fields[nm][0].itemsize == 4 for nm in names)
+    if not ok:
+        for nm in names:
+            rows[nm] = 0.0
+        return
+    offs = (_I64 * len(names))(*[int(fields[nm][1]) for nm in names])
+    check(load().gsx_host_zero_columns(rows.ctypes.data, rows.dtype.itemsize, len(rows), offs, len(names)), "gsx_host_zero_columns")
+
+
+def host_append_u8_columns(rows: np.ndarray, names, columns: np.ndarray) -> np.ndarray:
+    """a new structured array = every field of `rows` + the u1 fields `names` filled from columns (n, len(names)) uint8
+    (data_processor.py:262-274), one threaded pass over the rows"""
+    new_dtype = np.dtype(rows.dtype.descr + [(nm, "u1") for nm in names])
+    cols = np.ascontiguousarray(columns, dtype=np.uint8).reshape(len(rows), len(names))
+    out = np.empty(len(rows), dtype=new_dtype)
+    tail_ok = all(new_dtype.fields[nm][1] == rows.dtype.itemsize + i for i, nm in enumerate(names))
+    if rows.ndim != 1 or not rows.flags.c_contiguous or rows.dtype.hasobject or not tail_ok or len(rows) == 0:
+        for nm in rows.dtype.names:
+            out[nm] = rows[nm]
+        for i, nm in enumerate(names):
+            out[nm] = cols[:, i]
+        return out
+    check(load().gsx_host_append_columns(rows.ctypes.data, rows.dtype.itemsize, len(rows), cols.ctypes.data, len(names),
+                                         out.ctypes.data, new_dtype.itemsize), "gsx_host_append_columns")
+    return out
+
+
+def rgb_from_sh(f_dc: np.ndarray, stats: dict | None = None) -> np.ndarray:
+    """one channel of data_processor.py:316-343 -> u8[n], byte-identical to numpy (C ABI gsx_rgb_from_sh: float64 power on
+    the GPU + rounding certificate; numpy's own expression for the flagged elements)"""
+    lib = require_hip()
+    v = np.ascontiguousarray(f_dc, dtype=np.float32)
+    n = len(v)
+    out = np.empty(n, dtype=np.uint8)
+    if n == 0:
+        return out
+    unc = np.empty(n, dtype=np.uint8)
+    check(lib.gsx_rgb_from_sh(v.ctypes.data, n, out.ctypes.data, unc.ctypes.data), "gsx_rgb_from_sh")
+    idx = np.flatnonzero(unc)
+    if len(idx):
+        with np.errstate(all="ignore"):
+            lin = np.clip(0.5 + v[idx] * 0.28209479177387814, 0.0, 1.0)
+            out[idx] = (np.power(lin, 1.0 / 2.2) * 255).astype(np.uint8)
+    if stats is not None:
+        stats["uncertain"] = stats.get("uncertain", 0) + int(len(idx))
+        stats["n"] = stats.get("n", 0) + n
+    return out
+
+
 _numpy_reduction_checked = None
 
 
@@ -308,6 +377,46 @@ def kmeans_lloyd(data: np.ndarray, init_centroids: np.ndarray, max_iter: int):
     return cent, labels
 
 
+def kmeans_pp_trials(k: int) -> int:
+    """scikit-learn's n_local_trials (_kmeans_plusplus)"""
+    return 2 + int(np.log(k))
+
+
+def kmeans_pp(data: np.ndarray, k: int, uniforms: np.ndarray, n_local_trials: int | None = None) -> np.ndarray:
+    """greedy k-means++ seeding on the GPU (C ABI gsx_kmeans_pp); uniforms: 1 + (k-1) * n_local_trials numbers in [0,1)
+    (np.random.random_sample) -> initial centroids f32[k, d]"""
+    lib = require_hip()
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    n, d = data.shape
+    L = kmeans_pp_trials(k) if n_local_trials is None else int(n_local_trials)
+    u = np.ascontiguousarray(uniforms, dtype=np.float64)
+    if u.shape != (1 + (int(k) - 1) * L,):
+        raise ValueError("expected 1 + (k-1) * n_local_trials uniform numbers")
+    cent = np.empty((int(k), d), dtype=np.float32)
+    check(lib.gsx_kmeans_pp(data.ctypes.data, n, d, int(k), u.ctypes.data, L, cent.ctypes.data), "gsx_kmeans_pp")
+    return cent
+
+
+def kmeans1d(vals: np.ndarray, k: int, iters: int = 50, want_labels: bool = False, want_inertia: bool = False):
+    """Scalar K-Means codebook (C ABI gsx_kmeans1d: sort + prefix sums + Lloyd on run boundaries from two companded starts).
+    -> centroids f32[k] ascending (, labels i32[n]) (, inertia f64[3]: chosen, start A, start B).  Deterministic."""
+    lib = require_hip()
+    v = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1)
+    if not 1 <= int(k) <= 1024:
+        raise ValueError("kmeans1d: 1 <= k <= 1024")
+    cent = np.empty(int(k), dtype=np.float32)
+    labels = np.empty(len(v), dtype=np.int32) if want_labels else None
+    inertia = np.zeros(3, dtype=np.float64)
+    check(lib.gsx_kmeans1d(v.ctypes.data, len(v), int(k), int(iters), cent.ctypes.data,
+                           labels.ctypes.data if want_labels else None, inertia.ctypes.data), "gsx_kmeans1d")
+    out = (cent,)
+    if want_labels:
+        out += (labels,)
+    if want_inertia:
+        out += (inertia,)
+    return out[0] if len(out) == 1 else out
+
+
 def quantize_sorted_codebook(vals: np.ndarray, codebook: np.ndarray) -> np.ndarray:
     lib = require_hip()
     vals = np.ascontiguousarray(vals, dtype=np.float32)
@@ -340,6 +449,62 @@ def sog_quats(rot_rows: np.ndarray) -> np.ndarray:
     out = np.empty((len(q), 4), dtype=np.uint8)
     if len(q):
         check(lib.gsx_sog_quats(q.ctypes.data, len(q), out.ctypes.data), "gsx_sog_quats")
+    return out
+
+
+def _log_transform(v):
+    return np.sign(v) * np.log(np.abs(v) + 1.0)          # formats/sog.py:280-281, numpy's own float32 arithmetic
+
+
+def sog_positions(v: np.ndarray, stats: dict | None = None):
+    """formats/sog.py:279-309 for one axis -> (u16[n], np.float32 min, np.float32 max of the log-transformed axis), byte-identical
+    to the reference's numpy expression.  The transcendental runs on the GPU (C ABI gsx_sog_positions, rounding certificate);
+    numpy evaluates (i) the few values next to the extremes of v -- the transform is monotone, a relative window of 1e-3
+    around min / max of v holds every candidate for np.min / np.max of the transformed axis -- and (ii) the flagged texels."""
+    lib = require_hip()
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    n = len(v)
+    if n == 0:
+        return np.zeros(0, np.uint16), np.float32(0), np.float32(0)
+    vmin, vmax = np.min(v), np.max(v)
+    span = np.float32(1e-3) * np.maximum(np.abs(vmin), np.abs(vmax)) + np.float32(1e-30)
+    lo_c, hi_c = v[v <= vmin + span], v[v >= vmax - span]
+    if not (np.isfinite(vmin) and np.isfinite(vmax)) or len(lo_c) + len(hi_c) > max(4096, n // 8):
+        t = _log_transform(v)                              # degenerate input: the reference's expression as is
+        mn, mx = np.min(t), np.max(t)
+    else:
+        mn, mx = np.min(_log_transform(lo_c)), np.max(_log_transform(hi_c))
+    out = np.empty(n, dtype=np.uint16)
+    unc = np.empty(n, dtype=np.uint8)
+    check(lib.gsx_sog_positions(v.ctypes.data, n, float(mn), float(mx), out.ctypes.data, unc.ctypes.data), "gsx_sog_positions")
+    idx = np.flatnonzero(unc)
+    if len(idx):
+        with np.errstate(all="ignore"):
+            t = (_log_transform(v[idx]) - mn) / (mx - mn)
+            out[idx] = np.clip(t * 65535, 0, 65535).astype(np.uint16)
+    if stats is not None:
+        stats["uncertain"] = stats.get("uncertain", 0) + int(len(idx))
+        stats["n"] = stats.get("n", 0) + n
+    return out, mn, mx
+
+
+def sog_alpha(opacity: np.ndarray, stats: dict | None = None) -> np.ndarray:
+    """formats/sog.py:457-459 -> u8[n], byte-identical to numpy (C ABI gsx_sog_alpha + numpy for the flagged texels)"""
+    lib = require_hip()
+    o = np.ascontiguousarray(opacity, dtype=np.float32)
+    n = len(o)
+    out = np.empty(n, dtype=np.uint8)
+    if n == 0:
+        return out
+    unc = np.empty(n, dtype=np.uint8)
+    check(lib.gsx_sog_alpha(o.ctypes.data, n, out.ctypes.data, unc.ctypes.data), "gsx_sog_alpha")
+    idx = np.flatnonzero(unc)
+    if len(idx):
+        with np.errstate(all="ignore"):
+            out[idx] = np.clip(1.0 / (1.0 + np.exp(-o[idx])) * 255, 0, 255).astype(np.uint8)
+    if stats is not None:
+        stats["uncertain"] = stats.get("uncertain", 0) + int(len(idx))
+        stats["n"] = stats.get("n", 0) + n
     return out
 
 
@@ -555,6 +720,17 @@ class DeviceChain:
     def _xyz(self):
         p = self.rows.ptr
         return p, p + 4, p + 8, 3
+
+    def bbox(self):
+        """per-axis (min, max) of the surviving rows (gsx_slab_bbox_dev: the multi-GPU path's box kernel) -> ([3], [3]) float32"""
+        out = self.ctx.alloc(32)
+        try:
+            x, y, z, st = self._xyz()
+            check(self.ctx.lib.gsx_slab_bbox_dev(self.ctx.handle, x, y, z, st, self.n, out.ptr), "gsx_slab_bbox_dev")
+            b = out.download(np.float32, 7)
+        finally:
+            out.free()
+        return [-b[0], -b[1], -b[2]], [b[3], b[4], b[5]]
 
     def density_voxels(self, voxel_size: float, min_points: int):
         n = self.n

@@ -87,6 +87,9 @@ int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
 int launch_sor_mask(gsx_ctx *, const float *, int64_t, const float *, uint8_t *);
 int density_voxels_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int64_t,
                        int64_t *, int64_t *, int64_t *, int64_t *);
+int density_hist_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int64_t *, int64_t *,
+                     int64_t *);
+int density_merge_dev(gsx_ctx *, const int64_t *, const int64_t *, int64_t, int64_t, int64_t, int64_t *, int64_t *, int64_t *, int64_t *);
 int density_mask_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, const int64_t *,
                      int64_t, uint8_t *);
 int kmeans_lloyd_dev(gsx_ctx *, const float *, int64_t, int, int, int, float *, int32_t *);
@@ -449,6 +452,26 @@ int gsx_density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const flo
                               dense_keys_out, dense_counts_out);
 }
 
+int gsx_density_hist_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                         int64_t cap, int64_t *n_unique_out, int64_t *keys3_dev, int64_t *counts_dev)
+{
+    if (!c || !x || !y || !z || !n_unique_out || !keys3_dev || !counts_dev) GSX_FAIL("gsx_density_hist_dev: null argument");
+    if (n <= 0) GSX_FAIL("gsx_density_hist_dev: empty cloud");
+    GSX_HIP(hipSetDevice(c->device));
+    return density_hist_dev(c, x, y, z, stride, n, voxel_size, cap, n_unique_out, keys3_dev, counts_dev);
+}
+
+int gsx_density_merge_dev(gsx_ctx *c, const int64_t *keys3_dev, const int64_t *counts_dev, int64_t m, int64_t min_points,
+                          int64_t dense_cap, int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
+                          int64_t *dense_counts_out)
+{
+    if (!c || !n_unique_out || !n_dense_out || !dense_keys_out || !dense_counts_out || (m > 0 && (!keys3_dev || !counts_dev)))
+        GSX_FAIL("gsx_density_merge_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    return density_merge_dev(c, keys3_dev, counts_dev, m, min_points, dense_cap, n_unique_out, n_dense_out, dense_keys_out,
+                             dense_counts_out);
+}
+
 int gsx_density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
                          double voxel_size, const int64_t *kept_keys, int64_t n_kept, uint8_t *mask_out_dev)
 {
@@ -525,6 +548,42 @@ int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter, c
     return 0;
 }
 
+int gsx_kmeans_pp(const float *data, int64_t n, int d, int k, const double *uniforms, int n_local_trials, float *centroids_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!data || !uniforms || !centroids_out) GSX_FAIL("gsx_kmeans_pp: null argument");
+    if (n <= 0 || d <= 0 || k <= 0) GSX_FAIL("gsx_kmeans_pp: bad shape");
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    const size_t nd = (size_t)n * d, kd = (size_t)k * d;
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * nd));
+    GSX_CHECK(c->scratch2.reserve(sizeof(float) * kd));
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, data, sizeof(float) * nd, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_kmeans_pp_dev(c, c->scratch.as<float>(), n, d, k, uniforms, n_local_trials, c->scratch2.as<float>()));
+    GSX_HIP(hipMemcpyAsync(centroids_out, c->scratch2.p, sizeof(float) * kd, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_kmeans1d(const float *vals, int64_t n, int k, int iters, float *centroids_out, int32_t *labels_out, double *inertia3_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!vals || !centroids_out) GSX_FAIL("gsx_kmeans1d: null argument");
+    if (n <= 0 || k <= 0) GSX_FAIL("gsx_kmeans1d: bad shape");
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch2.reserve(sizeof(float) * (size_t)k));
+    if (labels_out) GSX_CHECK(c->scratch4.reserve(sizeof(int32_t) * (size_t)n));
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, vals, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_kmeans1d_dev(c, c->scratch.as<float>(), n, k, iters, 3, c->scratch2.as<float>(),
+                               labels_out ? c->scratch4.as<int32_t>() : nullptr, inertia3_out));
+    GSX_HIP(hipMemcpyAsync(centroids_out, c->scratch2.p, sizeof(float) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    if (labels_out) GSX_HIP(hipMemcpyAsync(labels_out, c->scratch4.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int gsx_quantize_sorted_codebook_dev(gsx_ctx *c, const float *vals_dev, int64_t n, const float *codebook_dev, int kcb,
                                      uint8_t *idx_out_dev)
 {
@@ -571,6 +630,61 @@ int gsx_lexsort3(const float *k0, const float *k1, const float *k2, int64_t n, u
     for (int a = 0; a < 3; ++a) GSX_HIP(hipMemcpyAsync(base + (size_t)a * n, src[a], sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     GSX_CHECK(gsx_lexsort3_dev(c, base, base + n, base + 2 * (size_t)n, 1, n, c->scratch4.as<uint32_t>()));
     GSX_HIP(hipMemcpyAsync(perm_out, c->scratch4.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_rgb_from_sh(const float *f_dc, int64_t n, uint8_t *out, uint8_t *uncertain_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!f_dc || !out || !uncertain_out) GSX_FAIL("gsx_rgb_from_sh: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve(2 * (size_t)n + 16));
+    uint8_t *d_out = c->scratch4.as<uint8_t>(), *d_unc = d_out + (size_t)n;
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, f_dc, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_rgb_from_sh_dev(c, c->scratch.as<float>(), n, d_out, d_unc));
+    GSX_HIP(hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipMemcpyAsync(uncertain_out, d_unc, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_sog_positions(const float *v, int64_t n, float log_min, float log_max, uint16_t *out, uint8_t *uncertain_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!v || !out || !uncertain_out) GSX_FAIL("gsx_sog_positions: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve(3 * (size_t)n + 16));
+    uint16_t *d_out = c->scratch4.as<uint16_t>();
+    uint8_t *d_unc = c->scratch4.as<uint8_t>() + 2 * (size_t)n;
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, v, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_sog_positions_dev(c, c->scratch.as<float>(), n, log_min, log_max, d_out, d_unc));
+    GSX_HIP(hipMemcpyAsync(out, d_out, 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipMemcpyAsync(uncertain_out, d_unc, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gsx_sog_alpha(const float *opacity, int64_t n, uint8_t *out, uint8_t *uncertain_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!opacity || !out || !uncertain_out) GSX_FAIL("gsx_sog_alpha: null argument");
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve(2 * (size_t)n + 16));
+    uint8_t *d_out = c->scratch4.as<uint8_t>(), *d_unc = d_out + (size_t)n;
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, opacity, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_sog_alpha_dev(c, c->scratch.as<float>(), n, d_out, d_unc));
+    GSX_HIP(hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipMemcpyAsync(uncertain_out, d_unc, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -5,6 +5,8 @@
 // across density -> SOR (BASELINE.json configs[2]) removes the second gather + upload and lets the host compact its
 // 248-byte rows ONCE, by the composed survivor list: SURVEY.md 8(f) rank 1, device half.
 //   rows_out / orig_out = the rows with mask != 0, order kept; orig = index into the table the chain started from
+#include <algorithm>
+
 #include "gsx_common.h"
 
 namespace gsx {
@@ -106,9 +108,59 @@ __global__ __launch_bounds__(256) void mask_ge_kernel(const float *__restrict__ 
     mask[i] = (double)vals[orig ? orig[i] : (unsigned)i] >= thr;   // data_processor.py:210
 }
 
+// data_processor.py:316-343 (_compute_rgb_from_sh) for one channel: u8((clip(0.5 + f_dc * C0, 0, 1) ** (1/2.2)) * 255).
+// The linear part is numpy's float32 arithmetic exactly (weak Python scalars: C0 and the exponent are rounded to float32);
+// np.power on float32 is a libm / SVML routine whose bits a device cannot reproduce, so -- as in csrc/sog.hip -- the power
+// is evaluated in float64, numpy's possible float32 result is bracketed by +-3 ulp, both ends go through the float32
+// `* 255` and the truncation, and the element is flagged for the host when they disagree (about 1e-4 of the values).
+__device__ __forceinline__ float chain_ulp_step(float a, int steps)
+{
+    int b = (int)__float_as_uint(a);
+    b = b < 0 ? (int)0x80000000u - b : b;
+    b += steps;
+    b = b < 0 ? (int)0x80000000u - b : b;
+    return __uint_as_float((unsigned)b);
+}
+
+__global__ __launch_bounds__(256) void rgb_from_sh_kernel(const float *__restrict__ f_dc, int64_t n, uint8_t *__restrict__ out,
+                                                          uint8_t *__restrict__ uncertain)
+{
+    const float c0 = 0.28209479177387814f;            // np.float32(SH_C0)
+    const double e = (double)(float)(1.0 / 2.2);       // the exponent numpy uses: float32(1.0 / 2.2)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = f_dc[i];
+        float lin = __fadd_rn(0.5f, __fmul_rn(v, c0));
+        lin = fminf(fmaxf(lin, 0.0f), 1.0f);           // np.clip (NaN propagates: flagged below)
+        bool ok = v == v;
+        unsigned q[2];
+        if (lin == 0.0f || lin == 1.0f) {              // pow(0, e) = 0 and pow(1, e) = 1 exactly in any libm
+            q[0] = q[1] = lin == 0.0f ? 0u : 255u;
+        } else {
+            const float a = (float)::pow((double)lin, e);
+            const float b[2] = {chain_ulp_step(a, -3), chain_ulp_step(a, 3)};   // libm / SVML powf: <= 1 ulp (measured 0.999)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) q[s] = (unsigned)__fmul_rn(fminf(b[s], 1.0f), 255.0f);
+        }
+        ok = ok && q[0] == q[1];
+        out[i] = (uint8_t)q[0];
+        uncertain[i] = ok ? 0 : 1;
+    }
+}
+
 }  // namespace gsx
 
 using namespace gsx;
+
+extern "C" int gsx_rgb_from_sh_dev(gsx_ctx *c, const float *f_dc_dev, int64_t n, uint8_t *out_dev, uint8_t *uncertain_dev)
+{
+    if (!c || (n > 0 && (!f_dc_dev || !out_dev || !uncertain_dev))) GSX_FAIL("gsx_rgb_from_sh_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(rgb_from_sh_kernel, dim3(blocks), dim3(256), 0, c->stream, f_dc_dev, n, out_dev, uncertain_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int gsx_mask_bbox_dev(gsx_ctx *c, const float *rows_dev, int64_t n, const double *bounds6, uint8_t *mask_dev)
 {

@@ -317,63 +317,62 @@ static int compute_frame(gsx_ctx *c, const float *x, const float *y, const float
     return 0;
 }
 
-int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
-                       double voxel_size, int64_t min_points, int64_t dense_cap, int64_t *n_unique_out,
-                       int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
-{
-    const float voxel = (float)voxel_size;  // python float is a weak scalar next to the f32 array
-    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
-    if (dense_cap < 0) GSX_FAIL("density: bad dense_cap");
-    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
-    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + 64));
-    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
-    VoxelFrame hvf;
-    GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+// ---- the voxel table of one call: keys | counts | second key word (wide) in scratch2, then room for `cap` exported entries
+struct VoxTable {
+    bool wide;
+    uint64_t tsize;
+    unsigned long long *tkeys;
+    unsigned *tcnt, *tkb;
+    char *out_base;      // 16-byte aligned area behind the table (cap x (8 + 4 + 4) bytes + 16)
+    size_t table_bytes;  // bytes to zero before inserting
+};
 
-    // table size: power of two >= 2 x min(n, number of voxels in the frame)
-    const bool wide = hvf.ok == 2;
-    double space = (double)hvf.dim[0] * hvf.dim[1] * hvf.dim[2];
-    uint64_t need = (uint64_t)std::min<double>((double)n, space);
+static int alloc_table(gsx_ctx *c, const VoxelFrame &hvf, int64_t n_items, size_t out_bytes, VoxTable *t)
+{
+    // table size: power of two >= 2 x min(items, number of voxels in the frame)
+    t->wide = hvf.ok == 2;
+    const double space = (double)hvf.dim[0] * hvf.dim[1] * hvf.dim[2];
+    const uint64_t need = (uint64_t)std::min<double>((double)n_items, space);
     uint64_t tsize = 1024;
     while (tsize < 2 * need) tsize <<= 1;
     if (tsize > (1ull << 31)) GSX_FAIL("density: too many points for the voxel table");
-    const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
-    // layout in one buffer: keys[tsize] | cnt[tsize] | kb[tsize] (wide) | out_keys[cap] | out_cnt[cap] | out_kb[cap] | counters[2]
-    size_t off_cnt = sizeof(unsigned long long) * tsize;
-    size_t off_kb = off_cnt + sizeof(unsigned) * tsize;
-    size_t off_ok = off_kb + (wide ? sizeof(unsigned) * tsize : 0);
-    off_ok = (off_ok + 15) & ~(size_t)15;
-    size_t off_oc = off_ok + sizeof(unsigned long long) * cap;
-    size_t off_ob = off_oc + sizeof(unsigned) * cap;
-    size_t off_ctr = (off_ob + sizeof(unsigned) * cap + 15) & ~(size_t)15;
-    GSX_CHECK(c->scratch2.reserve(off_ctr + 16));
+    t->tsize = tsize;
+    const size_t off_cnt = sizeof(unsigned long long) * tsize;
+    const size_t off_kb = off_cnt + sizeof(unsigned) * tsize;
+    size_t off_out = off_kb + (t->wide ? sizeof(unsigned) * tsize : 0);
+    off_out = (off_out + 15) & ~(size_t)15;
+    GSX_CHECK(c->scratch2.reserve(off_out + out_bytes + 64));
     char *base = c->scratch2.as<char>();
-    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(base);
-    unsigned *tcnt = reinterpret_cast<unsigned *>(base + off_cnt);
-    unsigned *tkb = wide ? reinterpret_cast<unsigned *>(base + off_kb) : nullptr;
-    unsigned long long *okeys = reinterpret_cast<unsigned long long *>(base + off_ok);
-    unsigned *ocnt = reinterpret_cast<unsigned *>(base + off_oc);
-    unsigned *okb = reinterpret_cast<unsigned *>(base + off_ob);
-    unsigned *ctr = reinterpret_cast<unsigned *>(base + off_ctr);
-    GSX_HIP(hipMemsetAsync(base, 0, off_ok, c->stream));
+    t->tkeys = reinterpret_cast<unsigned long long *>(base);
+    t->tcnt = reinterpret_cast<unsigned *>(base + off_cnt);
+    t->tkb = t->wide ? reinterpret_cast<unsigned *>(base + off_kb) : nullptr;
+    t->out_base = base + off_out;
+    t->table_bytes = off_out;
+    GSX_HIP(hipMemsetAsync(base, 0, off_out, c->stream));
+    return 0;
+}
+
+// voxels with count >= min_points, in np.unique(axis=0) row order, as absolute int64 triples (host arrays)
+static int collect_dense(gsx_ctx *c, const VoxelFrame &hvf, const VoxTable &t, int64_t min_points, int64_t dense_cap,
+                         int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
+    unsigned long long *okeys = reinterpret_cast<unsigned long long *>(t.out_base);
+    unsigned *ocnt = reinterpret_cast<unsigned *>(t.out_base + sizeof(unsigned long long) * cap);
+    unsigned *okb = ocnt + cap;
+    unsigned *ctr = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(okb + cap) + 15) & ~(uintptr_t)15);
     GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
-    if (wide)
-        hipLaunchKernelGGL((voxel_count_kernel<true>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
-                           voxel, dvf, tkeys, tkb, tcnt, (unsigned)(tsize - 1));
-    else
-        hipLaunchKernelGGL((voxel_count_kernel<false>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
-                           voxel, dvf, tkeys, tkb, tcnt, (unsigned)(tsize - 1));
-    unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
-    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)tsize, 1024)), dim3(256), 0, c->stream, tkeys, tkb,
-                       tcnt, (unsigned)tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
+    const unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
+    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)t.tsize, 1024)), dim3(256), 0, c->stream, t.tkeys, t.tkb,
+                       t.tcnt, (unsigned)t.tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
     GSX_HIP(hipGetLastError());
     unsigned hctr[2];
     GSX_HIP(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));
-    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
     if ((int64_t)hctr[1] > dense_cap)
         GSX_FAIL("density: %u dense voxels exceed dense_cap=%lld", hctr[1], (long long)dense_cap);
     const size_t m = hctr[1];
+    const bool wide = t.wide;
     std::vector<unsigned long long> hk(m);
     std::vector<unsigned> hc(m), hb(m, 0u);
     if (m) {
@@ -401,6 +400,182 @@ int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *
     *n_unique_out = hctr[0];
     *n_dense_out = (int64_t)m;
     return 0;
+}
+
+static int count_points(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, float voxel,
+                        const VoxelFrame *dvf, const VoxTable &t)
+{
+    if (t.wide)
+        hipLaunchKernelGGL((voxel_count_kernel<true>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
+                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1));
+    else
+        hipLaunchKernelGGL((voxel_count_kernel<false>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
+                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1));
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int density_voxels_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                       double voxel_size, int64_t min_points, int64_t dense_cap, int64_t *n_unique_out,
+                       int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    const float voxel = (float)voxel_size;  // python float is a weak scalar next to the f32 array
+    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
+    if (dense_cap < 0) GSX_FAIL("density: bad dense_cap");
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + 64));
+    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
+    VoxelFrame hvf;
+    GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+    VoxTable t;
+    const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
+    GSX_CHECK(alloc_table(c, hvf, n, 16 * cap + 64, &t));
+    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t));
+    const int rc = collect_dense(c, hvf, t, min_points, dense_cap, n_unique_out, n_dense_out, dense_keys_out, dense_counts_out);
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    return rc;
+}
+
+// ---- multi-GPU density: per-rank voxel histograms -> merged counts -----------------------------
+// every occupied voxel of the table as an absolute int64 key triple + int64 count (arbitrary order)
+__global__ __launch_bounds__(256) void voxel_export_kernel(const unsigned long long *__restrict__ tkeys, const unsigned *__restrict__ tkb,
+                                                           const unsigned *__restrict__ tcnt, unsigned tsize, VoxelFrame f, unsigned cap,
+                                                           long long *__restrict__ keys3, long long *__restrict__ counts,
+                                                           unsigned *__restrict__ counter)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < tsize; i += gridDim.x * blockDim.x) {
+        const unsigned long long kk = tkeys[i];
+        const unsigned c = tcnt[i];
+        if (kk == 0ull || c == 0u) continue;
+        const unsigned slot = atomicAdd(counter, 1u);
+        if (slot >= cap) continue;
+        const unsigned long long k = kk - 1ull;
+        long long kx, ky, kz;
+        if (tkb) {
+            kx = (long long)(k >> 32);
+            ky = (long long)(k & 0xffffffffull);
+            kz = (long long)(tkb[i] - 1u);
+        } else {
+            kx = (long long)(k >> 42);
+            ky = (long long)((k >> 21) & 0x1fffff);
+            kz = (long long)(k & 0x1fffff);
+        }
+        keys3[3 * (size_t)slot + 0] = kx + f.kmin[0];
+        keys3[3 * (size_t)slot + 1] = ky + f.kmin[1];
+        keys3[3 * (size_t)slot + 2] = kz + f.kmin[2];
+        counts[slot] = (long long)c;
+    }
+}
+
+int density_hist_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                     int64_t cap, int64_t *n_unique_out, int64_t *keys3_dev, int64_t *counts_dev)
+{
+    const float voxel = (float)voxel_size;
+    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
+    if (cap < 1) GSX_FAIL("density: bad cap");
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + 64));
+    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
+    VoxelFrame hvf;
+    GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+    VoxTable t;
+    GSX_CHECK(alloc_table(c, hvf, n, 64, &t));
+    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t));
+    unsigned *ctr = reinterpret_cast<unsigned *>(t.out_base);
+    GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
+    hipLaunchKernelGGL(voxel_export_kernel, dim3(blocks_for(c, (int64_t)t.tsize, 1024)), dim3(256), 0, c->stream, t.tkeys, t.tkb, t.tcnt,
+                       (unsigned)t.tsize, hvf, (unsigned)std::min<int64_t>(cap, 0xffffffffll), reinterpret_cast<long long *>(keys3_dev),
+                       reinterpret_cast<long long *>(counts_dev), ctr);
+    GSX_HIP(hipGetLastError());
+    unsigned h = 0;
+    GSX_HIP(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    *n_unique_out = h;
+    if ((int64_t)h > cap) GSX_FAIL("density: %u occupied voxels exceed cap=%lld", h, (long long)cap);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void merge_minmax_kernel(const long long *__restrict__ keys3, int64_t m, long long *__restrict__ mm)
+{
+    long long mn[3] = {0x7fffffffffffffffll, 0x7fffffffffffffffll, 0x7fffffffffffffffll};
+    long long mx[3] = {-0x7fffffffffffffffll, -0x7fffffffffffffffll, -0x7fffffffffffffffll};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const long long v = keys3[3 * i + a];
+            mn[a] = v < mn[a] ? v : mn[a];
+            mx[a] = v > mx[a] ? v : mx[a];
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long o1 = __shfl_xor(mn[a], off), o2 = __shfl_xor(mx[a], off);
+            mn[a] = o1 < mn[a] ? o1 : mn[a];
+            mx[a] = o2 > mx[a] ? o2 : mx[a];
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[a], mn[a]);
+            atomicMax(&mm[3 + a], mx[a]);
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void merge_insert_kernel(const long long *__restrict__ keys3, const long long *__restrict__ counts,
+                                                           int64_t m, VoxelFrame f, unsigned long long *__restrict__ tkeys,
+                                                           unsigned *__restrict__ tkb, unsigned *__restrict__ tcnt, unsigned tmask)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const VKey key = pack_key<WIDE>(f, (int)keys3[3 * i], (int)keys3[3 * i + 1], (int)keys3[3 * i + 2]);
+        table_add<WIDE>(tkeys, tkb, tcnt, tmask, key, (unsigned)counts[i]);
+    }
+}
+
+// G all-gathered (key, count) lists concatenated in device memory -> what gsx_density_voxels would have returned for the
+// whole cloud: the counts of equal keys are added in a hash table, the dense voxels come back in np.unique row order
+int density_merge_dev(gsx_ctx *c, const int64_t *keys3_dev, const int64_t *counts_dev, int64_t m, int64_t min_points, int64_t dense_cap,
+                      int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out, int64_t *dense_counts_out)
+{
+    if (dense_cap < 0 || m < 0) GSX_FAIL("density: bad sizes");
+    *n_unique_out = *n_dense_out = 0;
+    if (m == 0) return 0;
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(64));
+    long long *mm = c->scratch5.as<long long>();
+    const long long init[6] = {0x7fffffffffffffffll, 0x7fffffffffffffffll, 0x7fffffffffffffffll,
+                               -0x7fffffffffffffffll, -0x7fffffffffffffffll, -0x7fffffffffffffffll};
+    GSX_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const long long *k3 = reinterpret_cast<const long long *>(keys3_dev);
+    hipLaunchKernelGGL(merge_minmax_kernel, dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, m, mm);
+    long long h[6];
+    GSX_HIP(hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    VoxelFrame hvf;
+    hvf.ok = 1;
+    hvf.pad = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (h[a] < -1000000000ll || h[3 + a] > 1000000000ll) GSX_FAIL("density: voxel keys out of range");
+        const long long d = h[3 + a] - h[a] + 1;
+        if (d > (1 << 21) - 1) hvf.ok = 2;
+        hvf.kmin[a] = (int)h[a];
+        hvf.dim[a] = (int)d;
+    }
+    VoxTable t;
+    const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
+    GSX_CHECK(alloc_table(c, hvf, m, 16 * cap + 64, &t));
+    const long long *cn = reinterpret_cast<const long long *>(counts_dev);
+    if (t.wide)
+        hipLaunchKernelGGL((merge_insert_kernel<true>), dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, cn, m, hvf, t.tkeys, t.tkb,
+                           t.tcnt, (unsigned)(t.tsize - 1));
+    else
+        hipLaunchKernelGGL((merge_insert_kernel<false>), dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, cn, m, hvf, t.tkeys, t.tkb,
+                           t.tcnt, (unsigned)(t.tsize - 1));
+    GSX_HIP(hipGetLastError());
+    const int rc = collect_dense(c, hvf, t, min_points, dense_cap, n_unique_out, n_dense_out, dense_keys_out, dense_counts_out);
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    return rc;
 }
 
 int density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,

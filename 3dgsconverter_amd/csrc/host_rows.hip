@@ -118,3 +118,61 @@ extern "C" int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_
     });
     return 0;
 }
+
+// data_processor.py:310-313 (cap_sh_degree): self.data[f_rest_i] = 0.0 for the columns above the kept degree -- up to 45
+// strided single-thread column fills in numpy; one threaded pass over the rows here.  offsets: byte offsets of the
+// 4-byte columns to zero.
+extern "C" int gsx_host_zero_columns(void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets, int ncols)
+{
+    if (!rows || !offsets) GSX_FAIL("gsx_host_zero_columns: null argument");
+    if (n < 0 || row_bytes <= 0 || ncols < 0 || ncols > 4096) GSX_FAIL("gsx_host_zero_columns: bad shape");
+    for (int c = 0; c < ncols; ++c)
+        if (offsets[c] < 0 || offsets[c] + 4 > row_bytes) GSX_FAIL("gsx_host_zero_columns: column %d outside the row", c);
+    if (ncols == 0 || n == 0) return 0;
+    // contiguous runs of columns become one memset per row
+    std::vector<std::pair<int64_t, int64_t>> runs;   // (offset, bytes)
+    std::vector<int64_t> off(offsets, offsets + ncols);
+    std::sort(off.begin(), off.end());
+    for (int64_t o : off) {
+        if (!runs.empty() && runs.back().first + runs.back().second == o) runs.back().second += 4;
+        else if (runs.empty() || runs.back().first + runs.back().second < o) runs.emplace_back(o, 4);
+    }
+    const int nt = worker_count(n * row_bytes);
+    char *base = static_cast<char *>(rows);
+    run_threads(nt, [&](int t) {
+        const int64_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+        for (int64_t r = r0; r < r1; ++r)
+            for (const auto &ru : runs) memset(base + r * row_bytes + ru.first, 0, (size_t)ru.second);
+    });
+    return 0;
+}
+
+// data_processor.py:264-274 (add_rgb_from_sh): a new structured array = every old field + three u1 fields.  numpy copies
+// field by field (62 strided passes over a 10M-row table); here every output row is the old row followed by `extra_bytes`
+// bytes of `extra` (row-major n x extra_bytes), one threaded pass.  out_row_bytes >= row_bytes + extra_bytes (numpy's
+// itemsize of the widened dtype; any padding in between is zeroed).
+extern "C" int gsx_host_append_columns(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *extra, int64_t extra_bytes,
+                                       void *out, int64_t out_row_bytes)
+{
+    if (!rows || !extra || !out) GSX_FAIL("gsx_host_append_columns: null argument");
+    if (n < 0 || row_bytes <= 0 || extra_bytes <= 0 || out_row_bytes < row_bytes + extra_bytes) GSX_FAIL("gsx_host_append_columns: bad shape");
+    const int nt = worker_count(2 * n * out_row_bytes);
+    const char *src = static_cast<const char *>(rows);
+    char *dst = static_cast<char *>(out);
+    {
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + (size_t)n * (size_t)out_row_bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    const int64_t pad = out_row_bytes - row_bytes - extra_bytes;
+    run_threads(nt, [&](int t) {
+        const int64_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+        for (int64_t r = r0; r < r1; ++r) {
+            char *d = dst + r * out_row_bytes;
+            memcpy(d, src + r * row_bytes, (size_t)row_bytes);
+            memcpy(d + row_bytes, extra + r * extra_bytes, (size_t)extra_bytes);
+            if (pad) memset(d + row_bytes + extra_bytes, 0, (size_t)pad);
+        }
+    });
+    return 0;
+}

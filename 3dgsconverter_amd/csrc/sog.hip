@@ -3,11 +3,17 @@
 //   formats/sog.py:264      indices = np.lexsort((z, y, x))        -> gsx_lexsort3: three stable radix-sort passes
 //   formats/sog.py:315-386  quaternion normalise + smallest-three  -> gsx_sog_quats: one elementwise pass, byte-exact
 //
-// NOT here, on purpose: the log-transformed positions (:279-309) and the sigmoid of the opacity (:457-459) go through
-// numpy's float32 log / exp, which are SIMD routines of up to 3 ulp error (measured: 16 % / 39 % of the values differ
-// from the correctly rounded result).  A device log/exp cannot reproduce them bit for bit, and one ulp flips the u16 / u8
-// texel in 3e-4 / 3e-6 of the splats -- so those two stay numpy on the host (they ARE the reference's arithmetic) and
-// the writer stays byte-identical.  HBM-bound: 16 B in, 4 B out per splat (quats); 3 x (8 B + 8 B) per splat (sort).
+//   formats/sog.py:279-309  sign(v) log(|v| + 1) -> u16 texels       -> gsx_sog_positions: float64 log + rounding certificate
+//   formats/sog.py:457-459  255 / (1 + exp(-opacity)) -> u8 texels   -> gsx_sog_alpha: float64 exp + rounding certificate
+//
+// The last two go through numpy's float32 `log` / `exp`, SIMD routines up to ~4 ulp off the correctly rounded value
+// (measured in round 2: 16 % / 39 % of the values differ from it), so a device log/exp cannot reproduce their BITS.  But the
+// outputs are u16 / u8 quantised and every step after the transcendental is a monotone float32 operation: the kernels
+// evaluate the transcendental in float64, bracket numpy's possible float32 result (+-5 ulp for log, +-4 for exp),
+// push BOTH ends of the bracket through numpy's exact float32 sequence (sub, div, mul by 65535, clip, truncate) and emit
+// the texel when the two agree -- otherwise the element is flagged and the host evaluates numpy's own expression for it
+// (~1.4 % of the positions of a typical scene, 1e-4 of the opacities).  Byte-identical textures.
+// HBM-bound: 16 B in, 4 B out per splat (quats); 3 x (8 B + 8 B) per splat (sort); 4 B in, 3 B out (positions), 4 in 2 out (alpha).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -77,6 +83,74 @@ __global__ __launch_bounds__(256) void sog_quats_kernel(const float *__restrict_
     }
 }
 
+// float32 value `steps` ulps above (steps > 0) or below a finite float, crossing zero correctly
+__device__ __forceinline__ float ulp_step(float a, int steps)
+{
+    int b = (int)__float_as_uint(a);
+    b = b < 0 ? (int)0x80000000u - b : b;   // ordered integer: monotone in the float value
+    b += steps;
+    b = b < 0 ? (int)0x80000000u - b : b;
+    return __uint_as_float((unsigned)b);
+}
+
+// numpy's float32 SIMD routines: log max error 3.83 ulp, exp 2.52 ulp (their documented bounds; measured here on 28M values
+// each: 3.01 and 2.52).  The brackets add the half ulp of rounding the float64 value to float32 and a margin.
+constexpr int SOG_ULPS_LOG = 5, SOG_ULPS_EXP = 4;
+constexpr float SOG_ABS = 2.0e-7f;   // absolute slack of the log bracket for |result| < 1e-4 (|v| + 1 is within an ulp of 1)
+
+// sog.py:279-309 for one axis: v -> sign(v) log(|v| + 1) -> (l - mn) / (mx - mn) * 65535 -> clip -> u16
+__global__ __launch_bounds__(256) void sog_positions_kernel(const float *__restrict__ v, int64_t n, float mn, float mx,
+                                                            uint16_t *__restrict__ out, uint8_t *__restrict__ uncertain)
+{
+    const float range = __fsub_rn(mx, mn);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = v[i];
+        const float t = __fadd_rn(fabsf(x), 1.0f);                       // np.abs(v) + 1.0 in float32
+        const float sg = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);    // np.sign
+        const double lt = (double)sg * ::log((double)t);
+        const float a = (float)lt;
+        const float slack = fabsf(a) < 1.0e-4f ? SOG_ABS : 0.0f;
+        float lo = ulp_step(a, -SOG_ULPS_LOG) - slack, hi = ulp_step(a, SOG_ULPS_LOG) + slack;
+        if (sg == 0.0f) lo = hi = 0.0f;                                   // 0 * log(1) is exactly 0 whatever log returns
+        unsigned q[2];
+        const float e[2] = {lo, hi};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r = __fdiv_rn(__fsub_rn(e[s], mn), range);
+            r = __fmul_rn(r, 65535.0f);
+            r = fminf(fmaxf(r, 0.0f), 65535.0f);
+            q[s] = (unsigned)r;
+        }
+        const bool ok = q[0] == q[1] && (x == x) && fabsf(x) <= 3.0e38f && range > 0.0f;
+        out[i] = (uint16_t)q[0];
+        uncertain[i] = ok ? 0 : 1;
+    }
+}
+
+// sog.py:457-459: 1 / (1 + exp(-o)) * 255 -> clip -> u8
+__global__ __launch_bounds__(256) void sog_alpha_kernel(const float *__restrict__ o, int64_t n, uint8_t *__restrict__ out,
+                                                        uint8_t *__restrict__ uncertain)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = o[i];
+        const double et = ::exp(-(double)x);
+        bool ok = (x == x) && fabsf(x) < 80.0f;                          // outside: exp over/underflows in float32 -> host
+        const float a = ok ? (float)et : 1.0f;
+        const float e[2] = {ulp_step(a, -SOG_ULPS_EXP), ulp_step(a, SOG_ULPS_EXP)};
+        unsigned q[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r = __fdiv_rn(1.0f, __fadd_rn(1.0f, e[s]));
+            r = __fmul_rn(r, 255.0f);
+            r = fminf(fmaxf(r, 0.0f), 255.0f);
+            q[s] = (unsigned)r;
+        }
+        ok = ok && q[0] == q[1];
+        out[i] = (uint8_t)q[0];
+        uncertain[i] = ok ? 0 : 1;
+    }
+}
+
 static int lexsort3_dev(gsx_ctx *c, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n, uint32_t *perm_out)
 {
     // buffers: keys A/B, vals A/B (4 x n x u32) + rocprim temporary storage
@@ -125,6 +199,28 @@ int gsx_sog_quats_dev(gsx_ctx *c, const float *rot_rows_dev, int64_t n, uint8_t 
     if (n <= 0) return 0;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
     hipLaunchKernelGGL(sog_quats_kernel, dim3(blocks), dim3(256), 0, c->stream, rot_rows_dev, n, reinterpret_cast<uchar4 *>(out4_dev));
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int gsx_sog_positions_dev(gsx_ctx *c, const float *v_dev, int64_t n, float log_min, float log_max, uint16_t *out_dev, uint8_t *uncertain_dev)
+{
+    if (!c || !v_dev || !out_dev || !uncertain_dev) GSX_FAIL("gsx_sog_positions_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(sog_positions_kernel, dim3(blocks), dim3(256), 0, c->stream, v_dev, n, log_min, log_max, out_dev, uncertain_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int gsx_sog_alpha_dev(gsx_ctx *c, const float *opacity_dev, int64_t n, uint8_t *out_dev, uint8_t *uncertain_dev)
+{
+    if (!c || !opacity_dev || !out_dev || !uncertain_dev) GSX_FAIL("gsx_sog_alpha_dev: null argument");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(sog_alpha_kernel, dim3(blocks), dim3(256), 0, c->stream, opacity_dev, n, out_dev, uncertain_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

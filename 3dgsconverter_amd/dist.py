@@ -1,9 +1,9 @@
 """Multi-GPU SOR: one process per GPU, RCCL over xGMI.
 
 The reference is single-process; this is the MI355X-native scale-out of
-its SOR path.  Rank r holds the contiguous index range
-[r*n_local, (r+1)*n_local) of the cloud in its own HBM as (n_local,3) rows (how a loader would
-hand out a file), and gets the survivor mask of exactly that range back.
+its SOR path.  Rank r holds a contiguous index range of the cloud (ranges in rank
+order, any sizes) in its own HBM as (n_local,3) rows (how a loader would hand out a file), and gets the
+survivor mask of exactly that range back.
 
 One step:
   1. all-gather of the xyz rows -> every GPU holds the full reference set (the only data every
@@ -95,37 +95,42 @@ class HipCompute:
         return out
 
 
-_equal_shards_checked = set()  # (group id, n_local): the size check costs two collectives + a host sync, do it once
-
-
 def sharded_sor(xyz_local, k: int, threshold_factor: float, compute, group=None, algo: int = 0) -> ShardedSorResult:
-    """xyz_local: (n_local,3) float32 tensor, same n_local on every rank (index shard `rank`)."""
+    """xyz_local: (n_local,3) float32 tensor: index shard `rank` of the cloud (consecutive index ranges in rank order; the
+    shards may have different sizes, also zero -- they are padded to the longest for the all-gather)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_local = xyz_local.shape[0]
+    start = 0
     if world > 1:
-        key = (id(group), n_local, world)
-        if key not in _equal_shards_checked:
-            sizes = torch.tensor([n_local], dtype=torch.int64, device=xyz_local.device)
-            lo, hi = sizes.clone(), sizes.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-            if int(lo) != int(hi):
-                raise ValueError("sharded_sor needs equally sized index shards (got %d..%d)" % (int(lo), int(hi)))
-            _equal_shards_checked.add(key)
-        xyz_all = torch.empty((world * n_local, 3), dtype=xyz_local.dtype, device=xyz_local.device)
-        dist.all_gather_into_tensor(xyz_all, xyz_local.contiguous(), group=group)
+        sizes = torch.zeros(world, dtype=torch.int64, device=xyz_local.device)
+        sizes[rank] = n_local
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+        sizes = [int(v) for v in sizes.tolist()]
+        nmax, n_total, start = max(sizes), sum(sizes), sum(sizes[:rank])
+        if n_total == 0:
+            raise ValueError("sor: empty cloud")
+        if min(sizes) == nmax:
+            xyz_all = torch.empty((world * n_local, 3), dtype=xyz_local.dtype, device=xyz_local.device)
+            dist.all_gather_into_tensor(xyz_all, xyz_local.contiguous(), group=group)
+        else:
+            padded = torch.zeros((nmax, 3), dtype=xyz_local.dtype, device=xyz_local.device)
+            padded[:n_local] = xyz_local
+            gathered = torch.empty((world * nmax, 3), dtype=xyz_local.dtype, device=xyz_local.device)
+            dist.all_gather_into_tensor(gathered, padded, group=group)
+            xyz_all = torch.cat([gathered[q * nmax:q * nmax + sizes[q]] for q in range(world)]).contiguous()
     else:
+        n_total = n_local
         xyz_all = xyz_local.contiguous()
     if world > 1:
         md_all = compute.knn_share(xyz_all, k, rank, world, algo)
         dist.all_reduce(md_all, op=dist.ReduceOp.SUM, group=group)
-        md_local = md_all[rank * n_local:(rank + 1) * n_local].clone()  # own, aligned storage for the mask kernel
+        md_local = md_all[start:start + n_local].clone()  # own, aligned storage for the mask kernel
     else:
         md_all = md_local = compute.knn(xyz_all, 0, n_local, k, algo)
     stats = compute.stats(md_all, threshold_factor)
-    mask = compute.mask(md_local, stats)
-    return ShardedSorResult(mask, md_local, stats, world * n_local)
+    mask = compute.mask(md_local, stats) if n_local else torch.zeros(0, dtype=torch.uint8, device=xyz_local.device)
+    return ShardedSorResult(mask, md_local, stats, n_total)

@@ -53,6 +53,12 @@ class SlabUncertain(RuntimeError):
     the caller re-runs the step with the replicated exchange)"""
 
 
+class SlabUnsupported(SlabUncertain):
+    """the shard sizes cannot be served by the slab exchange (a shard below numpy's 8192-element reduction piece, an empty
+    cloud).  Decided from the all-gathered histograms, i.e. raised by EVERY rank in the same step, and a SlabUncertain: the
+    caller's fallback to the replicated exchange of dist.py -- exact for any shard sizes -- covers it."""
+
+
 # ------------------------------------------------------------------------------------------ communicators
 class RcclComm:
     """RCCL through the C ABI (gsx_comm_*), on the backend context's stream.  Buffers: anything with ``.ptr``."""
@@ -236,6 +242,41 @@ class HipSlabBackend:
     def mask(self, md, n, stats, out):
         self.ctx.sor_mask(md.ptr, int(n), stats.ptr + 8, out.ptr)
 
+    # ---- multi-GPU density (dist_density.py)
+    def density_hist(self, rows, n, voxel, cap, keys, counts) -> int:
+        p = rows.ptr
+        nu = C.c_int64()
+        self._chk(self.lib.gsx_density_hist_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), float(voxel), int(cap), C.byref(nu),
+                                                keys.ptr, counts.ptr), "gsx_density_hist_dev")
+        return int(nu.value)
+
+    def pad_density_list(self, keys, counts, used, upto):
+        """entries [used, upto): count 0 (and any valid key: zeros)"""
+        self._chk(self.lib.gsx_dev_memset(self.ctx.handle, keys.ptr + 24 * int(used), 0, 24 * int(upto - used)), "gsx_dev_memset")
+        self._chk(self.lib.gsx_dev_memset(self.ctx.handle, counts.ptr + 8 * int(used), 0, 8 * int(upto - used)), "gsx_dev_memset")
+
+    def density_merge(self, keys, counts, m, min_points, dense_cap):
+        dk = np.empty((max(int(dense_cap), 1), 3), dtype=np.int64)
+        dc = np.empty(max(int(dense_cap), 1), dtype=np.int64)
+        nu, nd = C.c_int64(), C.c_int64()
+        self._chk(self.lib.gsx_density_merge_dev(self.ctx.handle, keys.ptr, counts.ptr, int(m), int(min_points), int(dense_cap),
+                                                 C.byref(nu), C.byref(nd), dk.ctypes.data, dc.ctypes.data), "gsx_density_merge_dev")
+        k = int(nd.value)
+        return {"n_unique": int(nu.value), "dense_keys": dk[:k].copy(), "dense_counts": dc[:k].copy()}
+
+    def density_mask(self, rows, n, voxel, kept_keys, mask):
+        p = rows.ptr
+        kk = np.ascontiguousarray(kept_keys, dtype=np.int64).reshape(-1, 3)
+        self._chk(self.lib.gsx_density_mask_dev(self.ctx.handle, p, p + 4, p + 8, 3, int(n), float(voxel), kk.ctypes.data, len(kk),
+                                                mask.ptr), "gsx_density_mask_dev")
+
+    def compact_rows(self, rows, mask, n, rows_out, orig_out) -> int:
+        """rows[mask != 0] (order kept) -> rows_out, their local indices -> orig_out (gsx_compact_rows_dev)"""
+        n_out = C.c_int64()
+        self._chk(self.lib.gsx_compact_rows_dev(self.ctx.handle, rows.ptr, None, mask.ptr, int(n), rows_out.ptr, orig_out.ptr,
+                                                C.byref(n_out)), "gsx_compact_rows_dev")
+        return int(n_out.value)
+
     def check(self):
         self.ctx.check()
 
@@ -291,30 +332,37 @@ class SlabResult(dict):
 
 
 def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 1.5, want_host: bool = False):
-    """rows: backend buffer holding this rank's (n_local,3) float32 index shard (same n_local on every rank).
+    """rows: backend buffer holding this rank's (n_local,3) float32 index shard -- consecutive index ranges of the cloud in
+    rank order, of ANY sizes >= 8192 (round 3: unequal shards, e.g. what a density filter leaves behind on every rank).
     -> SlabResult(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info).
     ONE host synchronisation inside the step (the histograms, from which every size follows).
     halo_cells: halo width in KNN cell edges h of the global density.  On uniform data a query's k-th neighbour is at
     ~0.82 h and beyond 1.3 h with probability < 1e-13; the certificate catches whatever the halo does not cover."""
     G, r = comm.world, comm.rank
     n_local = int(n_local)
-    if G > 1 and not (n_local % 4 == 0 and n_local >= NP_PIECE):
-        raise ValueError("slab_sor: index shards must hold a multiple of 4 and at least 8192 points (got %d)" % n_local)
     # ---- 1. bounding box (device-resident), 2. histogram of the longest axis; all-gathered: cuts AND every row count.
     # Box and histograms share one buffer, so the step's host synchronisation is ONE download.
     plan_in = be.buf("plan_in", 32 + 4 * BINS * G)
     b7 = be.at(plan_in, 0)
-    be.bbox(rows, n_local, b7)
+    if n_local:
+        be.bbox(rows, n_local, b7)
+    else:   # an empty shard still takes part in the collectives (and then declines with every other rank, below)
+        be.from_host(b7, np.array([-np.inf] * 6 + [0.0], dtype=np.float32))
     if G > 1:
         comm.all_reduce(b7, 7, KIND_F32_MAX)
         hist = be.buf("hist", 4 * BINS)
-        be.hist(rows, n_local, b7, hist)
+        if n_local:
+            be.hist(rows, n_local, b7, hist)
+        else:
+            be.zero(hist, 4 * BINS)
         comm.all_gather(hist, be.at(plan_in, 32), 4 * BINS)
     else:
         be.hist(rows, n_local, b7, be.at(plan_in, 32))
     words = be.to_host(plan_in, np.uint32, 8 + BINS * G)                       # <- the step's host synchronisation
     hb = words[:7].view(np.float32)
     allhist = words[8:].reshape(G, BINS)
+    if int(allhist.sum()) == 0:
+        raise SlabUnsupported("empty cloud")
     if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
         raise ValueError("sor: coordinates are not finite (NaN/inf)")
     ext = hb[3:6] + hb[:3]                                                     # float32, like the device (slab_axis)
@@ -324,12 +372,18 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     if ext[2] > max(ext[0], ext[1]):
         axis = 2
     lo, hi = np.float32(-hb[axis]), np.float32(hb[3 + axis])
+    sizes = allhist.sum(1).astype(np.int64)          # every rank's shard size: the histograms hold every point once
     cut, n_total = plan_slabs(allhist.sum(0), G)
-    if n_total != G * n_local:
-        raise ValueError("slab_sor needs equally sized index shards (%d points in total, %d x %d expected)" % (n_total, G, n_local))
+    if int(sizes[r]) != n_local:
+        raise ValueError("slab_sor: %d rows given, %d binned" % (n_local, int(sizes[r])))
+    if G > 1 and int(sizes.min()) < NP_PIECE:
+        raise SlabUnsupported("index shards of %s points: the slab exchange needs >= %d per rank" % (sizes.tolist(), NP_PIECE))
+    if n_total == 0:
+        raise SlabUnsupported("empty cloud")
+    starts = np.concatenate([[0], np.cumsum(sizes)])  # global index of every shard's first row
     ext64 = ext.astype(np.float64)
     nd = int((ext64 > 0).sum())
-    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k, n_total // max(G, 1)) / max(n_total, 1) if nd else 0.0
+    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k, n_total // max(G, 1)) / max(n_total, 1) if nd else 0.0   # (slabs are equal-COUNT)
     h_est = per ** (1.0 / nd) if nd else 0.0
     bw = (float(hi) - float(lo)) / BINS if hi > lo else 0.0
     halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS
@@ -372,23 +426,31 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     be.unpermute(ret, send_src, n_local, md)
     # ---- 7. numpy-exact statistics from 8192-element piece sums
     stats = be.buf("stats", 16)
-    heads = [(-(q * n_local)) % NP_PIECE for q in range(G)] + [0]              # leading elements owed to the left neighbour
+    heads = [(-int(starts[q])) % NP_PIECE for q in range(G)] + [0]              # leading elements owed to the left neighbour
     head, nxt_head = heads[r], heads[r + 1]
+    # the piece sums read 16 bytes at a time: where the shard's first own piece does not start on a 16-byte boundary
+    # (shard starts that are not multiples of 4) the elements are first moved to an aligned buffer (4 B/point, device copy)
+    if head % 4 == 0:
+        st_in, st_tail = be.at(md, 4 * head), be.at(md, 4 * n_local)
+    else:
+        st_buf = be.buf("md_stats", 4 * (n_local + NP_PIECE + 4))
+        be.copy(st_buf, be.at(md, 4 * head), 4 * (n_local - head))
+        st_in, st_tail = st_buf, be.at(st_buf, 4 * (n_local - head))
     if G > 1:
         s_off, s_cnt, r_off, r_cnt = [0] * G, [0] * G, [0] * G, [0] * G
         if r > 0:
             s_cnt[r - 1] = head
         if r + 1 < G:
-            r_off[r + 1], r_cnt[r + 1] = n_local, nxt_head
-        comm.all_to_all_v(md, s_off, s_cnt, md, r_off, r_cnt, 4)
+            r_cnt[r + 1] = nxt_head
+        comm.all_to_all_v(md, s_off, s_cnt, st_tail, r_off, r_cnt, 4)
     n_mine = n_local - head + nxt_head
-    counts = [-(-(n_local - heads[q] + heads[q + 1]) // NP_PIECE) for q in range(G)]
+    counts = [-(-(int(sizes[q]) - heads[q] + heads[q + 1]) // NP_PIECE) for q in range(G)]
     max_pieces = max(counts)
     pieces = be.buf("pieces", 4 * max_pieces)
     allp = be.buf("allpieces", 4 * max_pieces * G)
     packed = be.buf("packed", 4 * max_pieces * G)
     for mode in (0, 1):
-        be.piece_sums(be.at(md, 4 * head), n_mine, stats if mode else None, pieces)
+        be.piece_sums(st_in, n_mine, stats if mode else None, pieces)
         if G > 1:
             comm.all_gather(pieces, allp, 4 * max_pieces)
             o = 0

@@ -5,15 +5,20 @@ Same bundle layout and the same bytes wherever the reference is deterministic; w
   | step (formats/sog.py)                         | here                                                        |
   |-----------------------------------------------|-------------------------------------------------------------|
   | :264 spatial order ``np.lexsort((z, y, x))``   | ``gsx_lexsort3`` (three stable radix passes on the GPU)     |
-  | :279-309 log-transformed u16 positions        | numpy on the host -- numpy's float32 ``log`` is a SIMD       |
-  | :457-459 sigmoid of the opacity                | routine (up to 3 ulp off the correctly rounded value); a     |
-  |                                               | device log/exp cannot reproduce it, see csrc/sog.hip         |
+  | :279-309 log-transformed u16 positions        | ``gsx_sog_positions`` / ``gsx_sog_alpha``: float64 log / exp |
+  | :457-459 sigmoid of the opacity                | on the GPU + a rounding certificate; numpy (whose float32    |
+  |                                               | SIMD log/exp bits a device cannot reproduce) only evaluates  |
+  |                                               | the ~1 % of texels next to a rounding boundary: same bytes    |
   | :315-386 quaternion smallest-three packing    | ``gsx_sog_quats``, byte-exact                                |
-  | :392-449 scale / colour codebooks + quantiser | ``gpu_ops.kmeans`` (HIP Lloyd) + ``gsx_quantize_sorted_codebook`` |
+  | :392-449 scale / colour codebooks + quantiser | ``gpu_ops.kmeans(init="k-means++")`` -> ``gsx_kmeans1d`` (sorted-run |
+  |                                               | solver: the quality of the reference's scikit-learn path, not |
+  |                                               | of its random-init Taichi path) + ``gsx_quantize_sorted_codebook`` |
   | :496-552 SH palette, 64 independent chunks    | ``dist_palette.palette_kmeans`` (matrix-core assign; one GPU |
   |                                               | or dealt out across the GPUs of a node)                     |
-  | :561 256-scalar codebook of the centroids     | sklearn ``MiniBatchKMeans`` as in the reference (hard-wired  |
-  |                                               | there on every path), quantised on the GPU                  |
+  | :561 256-scalar codebook of the centroids     | ``gsx_kmeans1d`` over the flattened palette (the reference is |
+  |                                               | hard-wired to sklearn ``MiniBatchKMeans`` there, unseeded: any |
+  |                                               | codebook of at least that quality is admissible), quantised  |
+  |                                               | on the GPU                                                   |
   | :269-276, 566-639 WebP textures, meta, zip     | pillow / zipfile, as the reference (out of scope: packaging) |
 
 ``install(sog_writer=True)`` rebinds ``gsconverter.formats.sog.SogFormat.write`` to this function, which also makes the
@@ -47,11 +52,13 @@ def _webp(zf, name, pixels_rgba, w, h):
 
 
 def _positions(ds):
-    """:279-309 -- host numpy (module docstring)"""
-    logs = [np.sign(ds[a]) * np.log(np.abs(ds[a]) + 1.0) for a in "xyz"]
-    mins = [np.min(v) for v in logs]
-    maxs = [np.max(v) for v in logs]
-    u16 = [np.clip((v - lo) / (hi - lo) * 65535, 0, 65535).astype(np.uint16) for v, lo, hi in zip(logs, mins, maxs)]
+    """:279-309 -- GPU transcendental + certificate, numpy for the texels next to a rounding boundary (_lib.sog_positions)"""
+    u16, mins, maxs = [], [], []
+    for a in "xyz":
+        u, mn, mx = _lib.sog_positions(ds[a])
+        u16.append(u)
+        mins.append(mn)
+        maxs.append(mx)
     return u16, mins, maxs
 
 
@@ -62,7 +69,9 @@ def _scalar_codebook(columns, ds, label):
     fit = flat
     if len(flat) > 50000:
         fit = flat[np.random.choice(len(flat), 50000, replace=False)]
-    cent, _ = gpu_ops.kmeans(fit.reshape(-1, 1), 256, max_iter=20)
+    # the reference calls gpu_ops.kmeans(fit.reshape(-1, 1), 256, max_iter=20): random-row init with Taichi, k-means++-seeded
+    # sklearn without.  The scalar solver gives the better of the two qualities deterministically.
+    cent, _ = gpu_ops.kmeans(fit.reshape(-1, 1), 256, max_iter=20, init="k-means++")
     codebook = np.array(sorted(cent.flatten()))
     idx = [gpu_ops.quantize_to_codebook(np.ascontiguousarray(ds[c]), codebook) if len(codebook) > 1
            else np.zeros(len(ds), np.uint8) for c in columns]
@@ -122,7 +131,7 @@ def write_sog(data: np.ndarray, path: str, comm=None, be=None, **kwargs):
     color_cb, (d0, d1, d2) = _scalar_codebook(("f_dc_0", "f_dc_1", "f_dc_2"), ds, "Clustering Colors...")
     sh0 = np.zeros((texels, 4), np.uint8)
     sh0[:n, 0], sh0[:n, 1], sh0[:n, 2] = d0, d1, d2
-    sh0[:n, 3] = np.clip(1.0 / (1.0 + np.exp(-ds["opacity"])) * 255, 0, 255).astype(np.uint8)   # :457-459, host numpy
+    sh0[:n, 3] = _lib.sog_alpha(ds["opacity"])                                                 # :457-459
     _webp(zf, "sh0.webp", sh0, width, height)
 
     # SH-N palette (:496-600)
@@ -141,9 +150,11 @@ def write_sog(data: np.ndarray, path: str, comm=None, be=None, **kwargs):
         centroids, labels = dist_palette.palette_kmeans(sh, level, 10, comm=comm, be=be)
         palette = len(centroids)
         status_print("Clustering SH Centroids into Codebook...")
-        from sklearn.cluster import MiniBatchKMeans
-        km = MiniBatchKMeans(n_clusters=256, n_init="auto").fit(centroids.flatten().reshape(-1, 1))      # :561
-        codebook = np.array(sorted(km.cluster_centers_.flatten()))
+        flat = np.ascontiguousarray(centroids, dtype=np.float32).reshape(-1)
+        if len(flat) > 256:                                                                               # :561
+            codebook = _lib.kmeans1d(flat, 256, iters=100).astype(np.float64)
+        else:   # fewer scalars than codebook entries (sklearn would raise): every scalar is its own entry
+            codebook = np.array(sorted(flat.tolist()))
         cidx = gpu_ops.quantize_to_codebook(centroids.flatten(), codebook)
         w_c, h_c = 64 * coeffs, int(np.ceil(palette / 64))
         cimg = np.full((w_c * h_c, 4), 255, np.uint8)

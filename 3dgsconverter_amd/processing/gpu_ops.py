@@ -6,8 +6,9 @@
     ``HAS_HIP`` is the honest alias.
   * ``kmeans``  (reference :27-52, Lloyd kernels :57-96, driver :178-191): exactly
     ``max_iter`` x (assign, update) on the GPU from a random-sample init drawn like the
-    reference does (np.random.choice, unseeded unless the caller seeds numpy); ``tolerance``
-    is accepted and unused, as in the reference.  No sklearn fallback.
+    reference does (np.random.choice, unseeded unless the caller seeds numpy); ``use_gpu=False``
+    selects the quality of the reference's scikit-learn path (k-means++ seeding) -- still on the GPU.
+    No sklearn fallback.
   * ``filter_sor_gpu`` (reference :193-263): returns the boolean survivor mask; exact KNN
     (not the 27-cell / K<=50 approximation), statistics with numpy's exact f32 arithmetic.
 """
@@ -23,11 +24,35 @@ HAS_TAICHI = HAS_HIP  # the capability flag callers test (see module docstring)
 
 
 def kmeans(data: np.ndarray, k: int, max_iter=10, tolerance=1e-4, use_gpu=True, verbose=False,
-           init_centroids=None):
+           init_centroids=None, init=None):
+    """reference :27-52.  Two paths, like the reference, both on the GPU here:
+
+    * ``use_gpu=True`` (default; the reference's Taichi path :178-191): uniformly random rows as initial centroids
+      (np.random.choice, :182), exactly ``max_iter`` x (assign, update), labels one step older than the centroids;
+    * ``use_gpu=False`` or ``init="k-means++"`` (the reference's scikit-learn path :48-52, MiniBatchKMeans with k-means++
+      seeding -- what it runs on a machine without Taichi): k-means++ seeding + ``max_iter`` full-batch Lloyd steps +
+      labels of the returned centroids; for D == 1 (the scalar codebooks of formats/sog.py:402,443,561) the sorted-array
+      solver of csrc/kmeans1d.hip (deterministic, centroids ascending).  Unseeded in the reference: the contract is
+      quality (inertia <= sklearn's), see tests/test_kmeans_gpu.py.
+    ``tolerance`` is accepted and unused, as in the reference."""
     N, D = data.shape
     if k >= N:  # reference :30-31 (returns the input dtype, not forced to f32)
         return data.copy(), np.arange(N, dtype=np.int32)
     data32 = np.ascontiguousarray(data, dtype=np.float32)
+    quality = (not use_gpu) or (init is not None and str(init).lower() in ("k-means++", "kmeans++", "quality"))
+    if init_centroids is None and quality:
+        if D == 1 and k <= 1024:
+            if verbose:
+                status_print(f"[GPU_OPS] scalar K-Means on HIP gfx950 (sorted runs): N={N}, K={k}")
+            cent, labels = _lib.kmeans1d(data32.reshape(-1), int(k), iters=max(int(max_iter), 50), want_labels=True)
+            return cent.reshape(-1, 1), labels
+        if verbose:
+            status_print(f"[GPU_OPS] k-means++ seeding + Lloyd on HIP gfx950: N={N}, D={D}, K={k}, iters={max_iter}")
+        trials = _lib.kmeans_pp_trials(int(k))
+        seeds = _lib.kmeans_pp(data32, int(k), np.random.random_sample(1 + (int(k) - 1) * trials), trials)
+        cent, _ = _lib.kmeans_lloyd(data32, seeds, int(max_iter))
+        _, labels = _lib.kmeans_lloyd(data32, cent, 1)     # labels OF the returned centroids (compute_labels=True, :50)
+        return cent, labels
     if init_centroids is None:
         init_centroids = data32[np.random.choice(N, k, replace=False)]  # reference :182
     if verbose:

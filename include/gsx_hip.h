@@ -130,6 +130,25 @@ int gsx_compact_rows_dev(gsx_ctx *ctx, const float *rows_dev, const uint32_t *or
                          float *rows_out_dev, uint32_t *orig_out_dev, int64_t *n_out);
 
 /*
+ * data_processor.py:233-274,316-343 (add_rgb_from_sh / _compute_rgb_from_sh) for ONE colour channel:
+ * u8((clip(0.5 + f_dc * C0, 0, 1) ** (1/2.2)) * 255) in numpy's float32 arithmetic.  The power is evaluated in float64 on
+ * the device with a rounding certificate (see gsx_sog_positions): uncertain_out[i] = 1 marks the (~1e-4) elements the
+ * CALLER evaluates with numpy's own expression.  Byte-identical colours.
+ */
+int gsx_rgb_from_sh(const float *f_dc, int64_t n, uint8_t *out, uint8_t *uncertain_out);
+int gsx_rgb_from_sh_dev(gsx_ctx *ctx, const float *f_dc_dev, int64_t n, uint8_t *out_dev, uint8_t *uncertain_dev);
+/*
+ * Host row helpers of the two table-shaping methods (threaded, no device code):
+ *   gsx_host_zero_columns   -- data_processor.py:276-314 cap_sh_degree: `self.data[f_rest_i] = 0.0` for the columns above the
+ *                              kept degree, ONE pass over the rows instead of up to 45 strided column fills;
+ *   gsx_host_append_columns -- data_processor.py:262-274: the table widened by (red, green, blue) u1 fields, one pass instead
+ *                              of one strided copy per field.  extra: n x extra_bytes row-major.
+ */
+int gsx_host_zero_columns(void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets, int ncols);
+int gsx_host_append_columns(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *extra, int64_t extra_bytes,
+                            void *out, int64_t out_row_bytes);
+
+/*
  * The O(N) row filters that run before density / SOR (converter.py:196-203), as device masks over the chain's rows --
  * SURVEY.md 8(f) rank 4.  gsx_mask_bbox_dev replaces crop_by_bbox's six comparisons (data_processor.py:217-224);
  * bounds6 = {min_x,min_y,min_z,max_x,max_y,max_z} on the host, compared in f64 (pass float32-rounded values for Python
@@ -260,6 +279,19 @@ int gsx_density_voxels_dev(gsx_ctx *ctx, const float *x, const float *y, const f
                            int64_t n, double voxel_size, int64_t min_points, int64_t dense_cap,
                            int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
                            int64_t *dense_counts_out);
+/*
+ * Multi-GPU density filter (the reference is single-process): rank r counts the voxels of ITS index
+ * shard and exports every occupied voxel as an absolute int64 key triple + int64 count into DEVICE buffers
+ * (gsx_density_hist_dev; cap entries each, arbitrary order; *n_unique_out = entries written), the lists are all-gathered
+ * (gsx_comm_*), and gsx_density_merge_dev adds the counts of equal keys of the m gathered entries in a hash table and
+ * returns what gsx_density_voxels would have returned for the whole cloud: data_processor.py:43-52 with
+ * min_points = int(N_global * thr / 100) (:48).  The host BFS (:59-108) and gsx_density_mask_dev on the local rows follow.
+ */
+int gsx_density_hist_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                         double voxel_size, int64_t cap, int64_t *n_unique_out, int64_t *keys3_dev, int64_t *counts_dev);
+int gsx_density_merge_dev(gsx_ctx *ctx, const int64_t *keys3_dev, const int64_t *counts_dev, int64_t m, int64_t min_points,
+                          int64_t dense_cap, int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
+                          int64_t *dense_counts_out);
 int gsx_density_mask_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
                          int64_t n, double voxel_size, const int64_t *kept_keys, int64_t n_kept,
                          uint8_t *mask_out_dev);
@@ -277,6 +309,32 @@ int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter,
 int gsx_quantize_sorted_codebook(const float *vals, int64_t n, const float *codebook, int kcb,
                                  uint8_t *idx_out);
 
+/*
+ * Scalar (D = 1) K-Means codebook -- replaces the two places where the reference fits a 1-D codebook with scikit-learn's
+ * k-means++-seeded MiniBatchKMeans: formats/sog.py:561 (MiniBatchKMeans(n_clusters=256, n_init='auto') over the flattened
+ * SH palette, hard-wired) and processing/gpu_ops.py:48-52 (_kmeans_sklearn, what gpu_ops.kmeans runs for
+ * formats/sog.py:402,443 when Taichi is absent or use_gpu=False).  Both are unseeded in the reference: the contract is
+ * quality (inertia <= sklearn's on the same data), not bits.  Deterministic: sort + float64 prefix sums + `iters` Lloyd
+ * steps on run boundaries from two companded starts (csrc/kmeans1d.hip).  centroids_out: k floats, ASCENDING;
+ * labels_out (may be NULL): nearest centroid per value, ties to the lower index (gpu_ops.py:66-70);
+ * inertia3_out (may be NULL): {chosen, uniform-bin start, equal-count-bin start}.  1 <= k <= 1024, values finite.
+ */
+int gsx_kmeans1d(const float *vals, int64_t n, int k, int iters, float *centroids_out, int32_t *labels_out,
+                 double *inertia3_out);
+/* start_mask: bit 0 = uniform-bin start, bit 1 = equal-count-bin start (0 = both); inertia3_host is a HOST array */
+int gsx_kmeans1d_dev(gsx_ctx *ctx, const float *vals_dev, int64_t n, int k, int iters, int start_mask,
+                     float *centroids_dev, int32_t *labels_dev, double *inertia3_host);
+
+/*
+ * Greedy k-means++ seeding (D^2 sampling, n_local_trials candidates per centroid, the one that lowers the potential most
+ * wins) -- the initialisation of the reference's CPU path, scikit-learn's MiniBatchKMeans (processing/gpu_ops.py:48-52;
+ * sklearn uses n_local_trials = 2 + int(ln k)).  The host draws the 1 + (k-1) * n_local_trials uniform numbers in [0,1)
+ * (numpy's global stream, like sklearn); the device does the O(n d) passes (csrc/kmeans_pp.hip).  Follow with gsx_kmeans_lloyd.
+ */
+int gsx_kmeans_pp(const float *data, int64_t n, int d, int k, const double *uniforms, int n_local_trials, float *centroids_out);
+int gsx_kmeans_pp_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, int k, const double *uniforms_host,
+                      int n_local_trials, float *centroids_dev);
+
 /* device-resident variants: centroids_dev holds the init on entry and the result on exit */
 int gsx_kmeans_lloyd_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, int k, int max_iter,
                          float *centroids_dev, int32_t *labels_dev);
@@ -289,6 +347,21 @@ int gsx_quantize_sorted_codebook_dev(gsx_ctx *ctx, const float *vals_dev, int64_
 int gsx_lexsort3(const float *k0, const float *k1, const float *k2, int64_t n, uint32_t *perm_out);
 int gsx_lexsort3_dev(gsx_ctx *ctx, const float *k0, const float *k1, const float *k2, int64_t stride, int64_t n,
                      uint32_t *perm_out_dev);
+/*
+ * formats/sog.py:279-309 for ONE axis: v -> sign(v) log(|v| + 1) -> (l - log_min) / (log_max - log_min) * 65535 -> clip ->
+ * uint16, and formats/sog.py:457-459: 255 / (1 + exp(-opacity)) -> clip -> uint8.  The reference evaluates log / exp with
+ * numpy's float32 SIMD routines (not correctly rounded), so the device computes them in float64, brackets numpy's possible
+ * float32 result (+-5 ulp for log, +-4 for exp) and emits the texel only when both ends of the bracket quantise to the same integer through
+ * numpy's exact float32 sequence; uncertain_out[i] = 1 marks the (~1 %) elements the CALLER must evaluate with numpy's
+ * own expression.  log_min / log_max: numpy's np.min / np.max of the transformed axis (the host obtains them from the few
+ * values next to the extremes of v: the transform is monotone).  Result: byte-identical textures.
+ */
+int gsx_sog_positions(const float *v, int64_t n, float log_min, float log_max, uint16_t *out, uint8_t *uncertain_out);
+int gsx_sog_positions_dev(gsx_ctx *ctx, const float *v_dev, int64_t n, float log_min, float log_max, uint16_t *out_dev,
+                          uint8_t *uncertain_dev);
+int gsx_sog_alpha(const float *opacity, int64_t n, uint8_t *out, uint8_t *uncertain_out);
+int gsx_sog_alpha_dev(gsx_ctx *ctx, const float *opacity_dev, int64_t n, uint8_t *out_dev, uint8_t *uncertain_dev);
+
 /* formats/sog.py:315-386: normalise the (n,4) float32 quaternion rows, flip to the positive hemisphere of the largest
  * component, scale by sqrt(2), quantise the three others to bytes; out4[i] = (c0, c1, c2, 252 + argmax), byte-exact */
 int gsx_sog_quats(const float *rot_rows, int64_t n, uint8_t *out4);

@@ -109,3 +109,117 @@ def sog_sh_plan(n: int, compression_level: int = 0):
     k_per_chunk = max(16, int(np.ceil(target_k / num_chunks)))
     return {"target_k": int(target_k), "num_chunks": int(num_chunks), "chunk_size": chunk_size,
             "k_per_chunk": k_per_chunk}
+
+
+# ---- round 3: the reference's scikit-learn path (gpu_ops.py:48-52, sog.py:561) and the device's scalar solver --------
+def sklearn_minibatch(data: np.ndarray, k: int, max_iter: int = 10):
+    """processing/gpu_ops.py:48-52 verbatim: the reference's CPU path (unseeded; k-means++ seeding inside sklearn)"""
+    from sklearn.cluster import MiniBatchKMeans
+    N = len(data)
+    km = MiniBatchKMeans(n_clusters=k, max_iter=max_iter, batch_size=min(4096 * 4, N), n_init="auto", compute_labels=True)
+    km.fit(data)
+    return km.cluster_centers_.astype(np.float32), km.labels_.astype(np.int32)
+
+
+def sklearn_codebook_561(flat: np.ndarray, k: int = 256):
+    """formats/sog.py:561-562 verbatim: MiniBatchKMeans(n_clusters=256, n_init='auto').fit(centroids_flat); sorted"""
+    from sklearn.cluster import MiniBatchKMeans
+    km = MiniBatchKMeans(n_clusters=k, n_init="auto").fit(np.asarray(flat, dtype=np.float32).reshape(-1, 1))
+    return np.array(sorted(km.cluster_centers_.flatten()), dtype=np.float32)
+
+
+def inertia_1d(vals: np.ndarray, centroids: np.ndarray) -> float:
+    """sum of squared distances to the nearest centroid (float64)"""
+    c = np.sort(np.asarray(centroids, dtype=np.float64).reshape(-1))
+    x = np.asarray(vals, dtype=np.float64).reshape(-1)
+    i = np.clip(np.searchsorted(c, x), 0, len(c) - 1)
+    left = np.maximum(i - 1, 0)
+    d = np.minimum(np.abs(x - c[i]), np.abs(x - c[left]))
+    return float((d * d).sum())
+
+
+K1_BINS = 1024
+
+
+def _k1_start(xs: np.ndarray, k: int, mode: int) -> np.ndarray:
+    """companded start of csrc/kmeans1d.hip:k1_lloyd_kernel: mode 0 = count^(1/3) over uniform bins of [min, max],
+    mode 1 = width^(2/3) over equal-count bins"""
+    n = len(xs)
+    lo, hi = float(xs[0]), float(xs[-1])
+    b = np.arange(K1_BINS + 1)
+    if mode == 0:
+        edges = lo + (hi - lo) * (b / K1_BINS)
+        edges[-1] = hi
+        pos = np.searchsorted(xs.astype(np.float64), edges, side="right")
+        pos[0], pos[-1] = 0, n
+        w = np.cbrt(np.diff(pos).astype(np.float64))
+    else:
+        edges = xs[(b * (n - 1)) // K1_BINS].astype(np.float64)
+        width = np.diff(edges)
+        w = np.cbrt(width * width)
+    W = np.concatenate([[0.0], np.cumsum(w)])
+    if not W[-1] > 0:
+        return np.full(k, lo, dtype=np.float32)
+    t = (np.arange(k) + 0.5) / k * W[-1]
+    b0 = np.clip(np.searchsorted(W, t, side="right") - 1, 0, K1_BINS - 1)
+    wb = W[b0 + 1] - W[b0]
+    frac = np.where(wb > 0, (t - W[b0]) / np.where(wb > 0, wb, 1.0), 0.5)
+    return (edges[b0] + frac * (edges[b0 + 1] - edges[b0])).astype(np.float32)
+
+
+def kmeans1d_sorted(vals: np.ndarray, k: int, iters: int = 50):
+    """numpy restatement of csrc/kmeans1d.hip (the device's replacement for the scikit-learn scalar codebooks): sort,
+    float64 prefix sums, Lloyd on run boundaries (ties to the lower centroid) from both companded starts, lower
+    inertia wins.  -> (centroids f32[k] ascending, inertia[3] = chosen, start 0, start 1)"""
+    xs = np.sort(np.asarray(vals, dtype=np.float32).reshape(-1))
+    n = len(xs)
+    x64 = xs.astype(np.float64)
+    p1 = np.concatenate([[0.0], np.cumsum(x64)])
+    p2 = np.concatenate([[0.0], np.cumsum(x64 * x64)])
+    best, out = None, [0.0, 0.0, 0.0]
+    for mode in (0, 1):
+        c = _k1_start(xs, k, mode)
+        for it in range(iters + 1):
+            mid = (c[:-1].astype(np.float64) + c[1:].astype(np.float64)) * 0.5
+            b = np.concatenate([[0], np.searchsorted(x64, mid, side="right"), [n]])
+            b = np.maximum.accumulate(b)
+            cnt = np.diff(b)
+            s1 = p1[b[1:]] - p1[b[:-1]]
+            if it == iters:
+                s2 = p2[b[1:]] - p2[b[:-1]]
+                cd = c.astype(np.float64)
+                inertia = float(np.where(cnt > 0, s2 - 2.0 * cd * s1 + cnt * cd * cd, 0.0).sum())
+                break
+            c = np.where(cnt > 0, s1 / np.maximum(cnt, 1), c).astype(np.float32)
+        out[1 + mode] = inertia
+        if best is None or inertia < best[0]:
+            best = (inertia, c)
+    out[0] = best[0]
+    return best[1], np.array(out)
+
+
+def kmeans_pp_restated(data: np.ndarray, k: int, uniforms: np.ndarray, n_local_trials: int | None = None) -> np.ndarray:
+    """csrc/kmeans_pp.hip == sklearn's _kmeans_plusplus (greedy): row floor(u0 n), then for every further centroid
+    n_local_trials candidates -- the rows where cumsum(min squared distance) first exceeds u * total -- of which the one
+    with the smallest potential sum_i min(mind_i, d_i) wins (first minimum).  float64 arithmetic (the device uses float32
+    fma chains: picks agree except where a cumulative sum is within rounding of its target).  -> chosen row indices"""
+    x = np.asarray(data, dtype=np.float64)
+    n = len(x)
+    L = 2 + int(np.log(k)) if n_local_trials is None else int(n_local_trials)
+    u = np.asarray(uniforms, dtype=np.float64)
+    assert u.shape == (1 + (k - 1) * L,)
+    idx = [min(int(u[0] * n), n - 1)]
+    mind = ((x - x[idx[0]]) ** 2).sum(1)
+    for t in range(1, k):
+        ut = u[1 + (t - 1) * L: 1 + t * L]
+        cs = np.cumsum(mind)
+        if not cs[-1] > 0:
+            cand = np.minimum((ut * n).astype(np.int64), n - 1)
+        else:
+            cand = np.minimum(np.searchsorted(cs, ut * cs[-1], side="right"), n - 1)
+        dist = ((x[None, :, :] - x[cand][:, None, :]) ** 2).sum(2)
+        pots = np.minimum(mind[None, :], dist).sum(1)
+        b = int(np.argmin(pots))
+        idx.append(int(cand[b]))
+        mind = np.minimum(mind, dist[b])
+    return np.asarray(idx)

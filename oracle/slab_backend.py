@@ -169,6 +169,43 @@ class NumpySlabBackend:
     def mask(self, md, n, stats, out):
         out.view(np.uint8, n)[:] = md.view(np.float32, n) < stats.view(np.float32, 3)[2]
 
+    # ---- multi-GPU density (3dgsconverter_amd/dist_density.py): the reference's own expressions (data_processor.py:38-52)
+    def density_hist(self, rows, n, voxel, cap, keys, counts):
+        from . import density as oden
+        x = rows.view(np.float32, 3 * n).reshape(n, 3)
+        uniq, cnt = np.unique(oden.voxel_keys(x, voxel), axis=0, return_counts=True)
+        keys.view(np.int64, 3 * len(uniq))[:] = uniq.reshape(-1)
+        counts.view(np.int64, len(uniq))[:] = cnt
+        return len(uniq)
+
+    def pad_density_list(self, keys, counts, used, upto):
+        keys.view(np.int64, 3 * upto)[3 * used:] = 0
+        counts.view(np.int64, upto)[used:] = 0
+
+    def density_merge(self, keys, counts, m, min_points, dense_cap):
+        k = keys.view(np.int64, 3 * m).reshape(m, 3)
+        c = counts.view(np.int64, m)
+        live = c > 0
+        uniq, inv = np.unique(k[live], axis=0, return_inverse=True)
+        tot = np.bincount(inv.reshape(-1), weights=c[live].astype(np.float64), minlength=len(uniq)).astype(np.int64)
+        dense = tot >= min_points
+        return {"n_unique": len(uniq), "dense_keys": uniq[dense], "dense_counts": tot[dense]}
+
+    def density_mask(self, rows, n, voxel, kept_keys, mask):
+        from . import density as oden
+        x = rows.view(np.float32, 3 * n).reshape(n, 3)
+        kept = set(map(tuple, np.asarray(kept_keys).reshape(-1, 3).tolist()))
+        keys = oden.voxel_keys(x, voxel)
+        mask.view(np.uint8, n)[:] = np.fromiter((tuple(k) in kept for k in keys.tolist()), dtype=np.uint8, count=n)
+
+    def compact_rows(self, rows, mask, n, rows_out, orig_out):
+        x = rows.view(np.float32, 3 * n).reshape(n, 3)
+        keep = mask.view(np.uint8, n).astype(bool)
+        m = int(keep.sum())
+        rows_out.view(np.float32, 3 * m)[:] = x[keep].reshape(-1)
+        orig_out.view(np.uint32, m)[:] = np.nonzero(keep)[0]
+        return m
+
     def check(self):
         pass
 

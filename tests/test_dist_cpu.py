@@ -162,6 +162,159 @@ def test_slab_sor_equals_single_process(world, kind, n_local, tmp_path):
             assert np.float32(got).tobytes() == np.float32(ref[key]).tobytes(), (r, key)
 
 
+def _unequal_worker(rank, world, port, sizes, k, sigma, mode, out_dir):
+    """shards of different sizes: `mode` slab = dist_slab.slab_sor, replicated = dist.sharded_sor (the fallback)"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import datasets
+    full = datasets.uniform(sum(sizes), 10.0, 42)
+    lo = sum(sizes[:rank])
+    mine = full[lo:lo + sizes[rank]]
+    if mode == "slab":
+        slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+        from oracle.slab_backend import NumpySlabBackend
+        be = NumpySlabBackend()
+        try:
+            res = slab.slab_sor(be, slab.TorchHostComm(be), be.rows_buffer(mine), sizes[rank], k, sigma, want_host=True)
+            np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+            np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
+            np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
+        except slab.SlabUnsupported as e:
+            with open(os.path.join(out_dir, "unsupported_%d.txt" % rank), "w") as f:
+                f.write(str(e))
+    else:
+        gdist = importlib.import_module("3dgsconverter_amd.dist")
+        res = gdist.sharded_sor(torch.from_numpy(mine.copy()), k, sigma, OracleCompute())
+        np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res.mask_local.numpy())
+        np.save(os.path.join(out_dir, "md_%d.npy" % rank), res.mean_dists_local.numpy())
+        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res.stats.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,sizes", [("slab", (16384, 9001)), ("slab", (12000, 8192, 20003)), ("replicated", (7001, 3000)),
+                                        ("replicated", (5000, 0, 6001))])
+def test_unequal_index_shards_equal_single_process(mode, sizes, tmp_path):
+    """round 3: shards of different sizes (what a per-rank density filter leaves behind), starts that are not multiples of
+    4 (unaligned piece sums) -- mean distances, statistics and masks == the un-sharded oracle, bit for bit; the replicated
+    exchange also takes an EMPTY shard"""
+    import torch.multiprocessing as mp
+    from oracle import datasets, sor as osor
+    world, k, sigma = len(sizes), 16, 1.0
+    mp.spawn(_unequal_worker, args=(world, _free_port(), list(sizes), k, sigma, mode, str(tmp_path)), nprocs=world, join=True)
+    assert not list(tmp_path.glob("unsupported_*"))
+    ref = osor.sor(datasets.uniform(sum(sizes), 10.0, 42), k, sigma, workers=2)
+    md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(world)])
+    np.testing.assert_array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
+    masks = np.concatenate([np.load(tmp_path / ("mask_%d.npy" % r)) for r in range(world)]).astype(bool)
+    np.testing.assert_array_equal(masks, ref["mask"])
+    for r in range(world):
+        st = np.load(tmp_path / ("stats_%d.npy" % r))
+        assert np.float32(st[2]).tobytes() == np.float32(ref["threshold"]).tobytes()
+
+
+def test_slab_sor_declines_small_shards_on_every_rank(tmp_path):
+    """a shard below numpy's 8192-element piece: SlabUnsupported (a SlabUncertain) from EVERY rank in the same step --
+    decided from the all-gathered histograms, so nobody is left waiting in a collective"""
+    import importlib
+    import torch.multiprocessing as mp
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    assert issubclass(slab.SlabUnsupported, slab.SlabUncertain)
+    sizes = [9000, 5000, 0]
+    mp.spawn(_unequal_worker, args=(3, _free_port(), sizes, 8, 1.0, "slab", str(tmp_path)), nprocs=3, join=True)
+    assert len(list(tmp_path.glob("unsupported_*"))) == 3 and not list(tmp_path.glob("mask_*"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-GPU density (3dgsconverter_amd/dist_density.py): per-rank voxel histograms -> merged counts -> host clusters ->
+# per-rank mask; then BASELINE.json configs[2] sharded: density -> (unequal survivors per rank) -> slab SOR
+def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    dd = importlib.import_module("3dgsconverter_amd.dist_density")
+    from oracle import datasets
+    from oracle.slab_backend import NumpySlabBackend
+    full = datasets.make(spec)
+    lo = sum(sizes[:rank])
+    mine = full[lo:lo + sizes[rank]]
+    be = NumpySlabBackend()
+    comm = slab.TorchHostComm(be)
+    rows = be.rows_buffer(mine) if len(mine) else be.buf("rows_empty", 16)
+    res = dd.sharded_density(be, comm, rows, sizes[rank], **kwargs)
+    mask = np.zeros(sizes[rank], bool) if res["empty"] else be.to_host(res["mask"], np.uint8, sizes[rank]).astype(bool)
+    np.save(os.path.join(out_dir, "dmask_%d.npy" % rank), mask)
+    with open(os.path.join(out_dir, "dinfo_%d.json" % rank), "w") as f:
+        import json
+        json.dump({k: res[k] for k in ("n_total", "min_points", "n_unique", "kept_clusters", "max_len", "kept", "empty")}, f)
+    if then_sor and not res["empty"]:
+        n2 = res["kept"]
+        rows2, orig2 = be.buf("rows2", 12 * max(n2, 1)), be.buf("orig2", 4 * max(n2, 1))
+        assert be.compact_rows(rows, res["mask"], sizes[rank], rows2, orig2) == n2
+        r2 = slab.slab_sor(be, comm, rows2, n2, then_sor[0], then_sor[1], want_host=True)
+        final = np.zeros(sizes[rank], bool)
+        final[be.to_host(orig2, np.uint32, n2)[r2["mask_host"]]] = True
+        np.save(os.path.join(out_dir, "final_%d.npy" % rank), final)
+        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), r2["stats_host"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes,spec,kwargs", [
+    ((30000, 20001), {"kind": "uniform", "n": 50001, "extent": 5.0, "seed": 3}, {"sensitivity": 0.5}),
+    ((9000, 0, 21000), {"kind": "two_blobs", "n": 30000, "seed": 2}, {"voxel_size": 0.5, "threshold_percentage": 0.05, "keep_multicluster": True}),
+    ((15000, 15000), {"kind": "clustered", "n": 30000, "seed": 5}, {"voxel_size": 1.0, "threshold_percentage": 0.32}),
+    ((10000, 10000), {"kind": "uniform", "n": 20000, "extent": 10.0, "seed": 4}, {"sensitivity": 0.5}),        # removes everything
+])
+def test_sharded_density_equals_the_reference_filter(sizes, spec, kwargs, tmp_path):
+    """masks of the index shards (unequal, one EMPTY) == oracle/density.py (pinned to the reference's own
+    apply_density_filter) on the whole cloud; min_points comes from the GLOBAL size (data_processor.py:48)"""
+    import json
+    import torch.multiprocessing as mp
+    from oracle import datasets, density as oden
+    world = len(sizes)
+    mp.spawn(_density_worker, args=(world, _free_port(), list(sizes), spec, kwargs, None, str(tmp_path)), nprocs=world, join=True)
+    full = datasets.make(spec)
+    kw = dict(kwargs)
+    if "sensitivity" in kw:
+        kw["voxel_size"], kw["threshold_percentage"] = oden.params_from_sensitivity(kw.pop("sensitivity"))
+    ref = oden.density_filter(full, **kw)
+    got = np.concatenate([np.load(tmp_path / ("dmask_%d.npy" % r)) for r in range(world)])
+    np.testing.assert_array_equal(got, ref["mask"])
+    for r in range(world):
+        info = json.load(open(tmp_path / ("dinfo_%d.json" % r)))
+        assert info["n_total"] == len(full) and info["min_points"] == ref["min_points"] and info["n_unique"] == ref["unique_voxels"]
+        assert info["empty"] == (not ref["mask"].any())
+
+
+def test_sharded_density_then_slab_sor_is_the_reference_chain(tmp_path):
+    """BASELINE.json configs[2] sharded: density (sensitivity 0.5) leaves a different number of survivors on every rank; the
+    slab SOR of those unequal shards == the reference chain on the whole cloud (oracle density -> oracle SOR)"""
+    import torch.multiprocessing as mp
+    from oracle import datasets, density as oden, sor as osor
+    spec = {"kind": "uniform", "n": 60000, "extent": 5.0, "seed": 9}
+    sizes = [32000, 28000]
+    mp.spawn(_density_worker, args=(2, _free_port(), sizes, spec, {"sensitivity": 0.5}, (16, 1.0), str(tmp_path)), nprocs=2, join=True)
+    full = datasets.make(spec)
+    v, t = oden.params_from_sensitivity(0.5)
+    dref = oden.density_filter(full, v, t)
+    assert 0 < dref["mask"].sum() < len(full)
+    sref = osor.sor(full[dref["mask"]], 16, 1.0, workers=2)
+    want = np.zeros(len(full), bool)
+    want[np.nonzero(dref["mask"])[0][sref["mask"]]] = True
+    got = np.concatenate([np.load(tmp_path / ("final_%d.npy" % r)) for r in range(2)])
+    np.testing.assert_array_equal(got, want)
+    for r in range(2):
+        assert np.float32(np.load(tmp_path / ("stats_%d.npy" % r))[2]).tobytes() == np.float32(sref["threshold"]).tobytes()
+
+
 def test_slab_sor_refuses_what_it_cannot_certify(tmp_path):
     """far floaters have their neighbours beyond any halo: every rank raises SlabUncertain (the caller then uses the
     replicated exchange, which is exact for any cloud) -- never a silently wrong result"""

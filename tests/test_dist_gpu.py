@@ -133,3 +133,121 @@ def test_slab_path_on_shared_gpu_equals_the_unsharded_result(world, kind, n_loca
 def test_slab_path_refuses_floaters_on_every_rank(tmp_path):
     _spawn(_worker, 2, (_free_port(), 40000, 16, 1.0, "floaters", str(tmp_path)))
     assert len(list(tmp_path.glob("uncertain_*"))) == 2 and not list(tmp_path.glob("mask_*"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: multi-GPU density (dist_density.py) and BASELINE.json configs[2] sharded, with the REAL device entry points
+def test_sharded_density_world1_through_rccl_matches_the_golden_masks(gsx, golden_cases, golden_arrays):
+    """one rank, RCCL communicator: gsx_density_hist_dev -> gsx_density_merge_dev -> host clusters -> gsx_density_mask_dev
+    == the masks the reference's own apply_density_filter produced (tests/golden)"""
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    dd = importlib.import_module("3dgsconverter_amd.dist_density")
+    be = slab.HipSlabBackend(0)
+    comm = slab.RcclComm(be.ctx, 0, 1, slab.RcclComm.unique_id())
+    for name in ("dens_u1m_L5_s0p5", "dens_blobs_multi", "dens_clustered_default", "dens_u200k_L10_s0p5_none"):
+        case = golden_cases["density"][name]
+        xyz = datasets.make(case["dataset"])
+        rows = be.buf("rows", xyz.nbytes)
+        be.from_host(rows, xyz)
+        res = dd.sharded_density(be, comm, rows, len(xyz), **case["kwargs"])
+        mask = np.zeros(len(xyz), bool) if res["empty"] else be.to_host(res["mask"], np.uint8, len(xyz)).astype(bool)
+        np.testing.assert_array_equal(np.packbits(mask), golden_arrays[name + "__mask"])
+        assert res["kept"] == case["kept"] == int(mask.sum())
+    be.check()
+    comm.close()
+
+
+def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (first: see _spawn)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    dd = importlib.import_module("3dgsconverter_amd.dist_density")
+    full = datasets.make(spec)
+    lo = sum(sizes[:rank])
+    mine = full[lo:lo + sizes[rank]]
+    be = slab.HipSlabBackend(0)
+    comm = slab.TorchHostComm(be)
+    rows = be.buf("rows", 12 * max(sizes[rank], 1))
+    if sizes[rank]:
+        be.from_host(rows, mine)
+    res = dd.sharded_density(be, comm, rows, sizes[rank], **kwargs)
+    mask = np.zeros(sizes[rank], bool) if res["empty"] else be.to_host(res["mask"], np.uint8, sizes[rank]).astype(bool)
+    np.save(os.path.join(out_dir, "dmask_%d.npy" % rank), mask)
+    if then_sor and not res["empty"]:
+        n2 = res["kept"]
+        rows2, orig2 = be.buf("rows2", 12 * max(n2, 1)), be.buf("orig2", 4 * max(n2, 1))
+        assert be.compact_rows(rows, res["mask"], sizes[rank], rows2, orig2) == n2
+        r2 = slab.slab_sor(be, comm, rows2, n2, then_sor[0], then_sor[1], want_host=True)
+        final = np.zeros(sizes[rank], bool)
+        final[be.to_host(orig2, np.uint32, n2)[r2["mask_host"]]] = True
+        np.save(os.path.join(out_dir, "final_%d.npy" % rank), final)
+        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), r2["stats_host"])
+    be.check()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes,name", [((600000, 400000), "dens_u1m_L5_s0p5"), ((90001, 0, 59999), "dens_clustered_default")])
+def test_sharded_density_on_shared_gpu_equals_the_reference_masks(sizes, name, golden_cases, golden_arrays, tmp_path):
+    """world 2 / 3 (unequal index shards, one EMPTY), histograms merged on the device == the reference's own masks"""
+    case = golden_cases["density"][name]
+    assert sum(sizes) == case["dataset"]["n"]
+    _spawn(_density_worker, len(sizes), (_free_port(), list(sizes), case["dataset"], case["kwargs"], None, str(tmp_path)))
+    got = np.concatenate([np.load(tmp_path / ("dmask_%d.npy" % r)) for r in range(len(sizes))])
+    np.testing.assert_array_equal(np.packbits(got), golden_arrays[name + "__mask"])
+
+
+def test_config2_sharded_density_then_slab_sor_equals_the_reference_chain(tmp_path):
+    """BASELINE.json configs[2] on shards: density leaves unequal survivor counts per rank, the slab SOR of those shards ==
+    oracle density (pinned to the reference) -> oracle SOR on the whole cloud; threshold bits included"""
+    from oracle import density as oden
+    spec = {"kind": "uniform", "n": 1_000_000, "extent": 5.0, "seed": 0}
+    sizes = [520000, 480000]
+    _spawn(_density_worker, 2, (_free_port(), sizes, spec, {"sensitivity": 0.5}, (16, 1.0), str(tmp_path)))
+    full = datasets.make(spec)
+    v, t = oden.params_from_sensitivity(0.5)
+    dref = oden.density_filter(full, v, t)
+    assert int(dref["mask"].sum()) == 959954                                # SURVEY 8(c) DENS-1M
+    sref = osor.sor(full[dref["mask"]], 16, 1.0)
+    want = np.zeros(len(full), bool)
+    want[np.nonzero(dref["mask"])[0][sref["mask"]]] = True
+    got = np.concatenate([np.load(tmp_path / ("final_%d.npy" % r)) for r in range(2)])
+    np.testing.assert_array_equal(got, want)
+    for r in range(2):
+        assert np.float32(np.load(tmp_path / ("stats_%d.npy" % r))[2]).tobytes() == np.float32(sref["threshold"]).tobytes()
+
+
+def _unequal_worker(rank, world, port, sizes, k, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    full = datasets.uniform(sum(sizes), 10.0, 42)
+    lo = sum(sizes[:rank])
+    be = slab.HipSlabBackend(0)
+    rows = be.buf("rows", 12 * sizes[rank])
+    be.from_host(rows, full[lo:lo + sizes[rank]])
+    res = slab.slab_sor(be, slab.TorchHostComm(be), rows, sizes[rank], k, 1.0, want_host=True)
+    np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+    np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
+    np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [(300001, 199999), (100003, 250000, 8192)])
+def test_slab_path_unequal_shards_on_shared_gpu(sizes, tmp_path):
+    """shards of different sizes whose starts are not multiples of 4 (piece sums from an aligned copy)"""
+    _spawn(_unequal_worker, len(sizes), (_free_port(), list(sizes), 16, str(tmp_path)))
+    ref = osor.sor(datasets.uniform(sum(sizes), 10.0, 42), 16, 1.0)
+    md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(len(sizes))])
+    np.testing.assert_array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
+    masks = np.concatenate([np.load(tmp_path / ("mask_%d.npy" % r)) for r in range(len(sizes))]).astype(bool)
+    np.testing.assert_array_equal(masks, ref["mask"])
+    for r in range(len(sizes)):
+        assert np.float32(np.load(tmp_path / ("stats_%d.npy" % r))[2]).tobytes() == np.float32(ref["threshold"]).tobytes()

@@ -107,6 +107,10 @@ def dropin(gsx, monkeypatch):
         def survivors(self):
             return self.idx.astype(np.uint32)
 
+        def bbox(self):
+            hits.append(("gsx_slab_bbox_dev", self.n))
+            return self.xyz.min(0).tolist(), self.xyz.max(0).tolist()
+
         def close(self):
             pass
 
@@ -121,6 +125,31 @@ def dropin(gsx, monkeypatch):
         for c in range(4):
             ds["rot_%d" % c] = rows[:, c]
         return osog.quats(ds)
+
+    def sog_positions(v, stats=None):
+        hits.append(("gsx_sog_positions", len(v)))
+        t = np.sign(v) * np.log(np.abs(v) + 1.0)                      # formats/sog.py:280-295 on one axis
+        mn, mx = np.min(t), np.max(t)
+        return np.clip((t - mn) / (mx - mn) * 65535, 0, 65535).astype(np.uint16), mn, mx
+
+    def sog_alpha(o, stats=None):
+        hits.append(("gsx_sog_alpha", len(o)))
+        return np.clip(1.0 / (1.0 + np.exp(-o)) * 255, 0, 255).astype(np.uint8)   # formats/sog.py:457-459
+
+    def rgb_from_sh(f_dc, stats=None):
+        hits.append(("gsx_rgb_from_sh", len(f_dc)))
+        lin = np.clip(0.5 + np.asarray(f_dc, np.float32) * 0.28209479177387814, 0.0, 1.0)   # data_processor.py:332-342
+        return (np.power(lin, 1.0 / 2.2) * 255).astype(np.uint8)
+
+    def kmeans1d(vals, k, iters=50, want_labels=False, want_inertia=False):
+        hits.append(("gsx_kmeans1d", len(vals), int(k), int(iters)))
+        cent, inertia = okm.kmeans1d_sorted(vals, int(k), int(iters))
+        out = (cent,)
+        if want_labels:
+            out += (okm.assign(np.asarray(vals, np.float32).reshape(-1, 1), cent.reshape(-1, 1)),)
+        if want_inertia:
+            out += (inertia,)
+        return out[0] if len(out) == 1 else out
 
     def morton_order(x, y, z, ctx=None, keep_device=False):
         from oracle import cply as ocply
@@ -155,7 +184,9 @@ def dropin(gsx, monkeypatch):
 
     for name, fn in (("morton_order", morton_order), ("cply_pack", cply_pack), ("Context", FakeCtx), ("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
                      ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
-                     ("lexsort3", lexsort3), ("sog_quats", sog_quats)):
+                     ("lexsort3", lexsort3), ("sog_quats", sog_quats),
+                     ("sog_positions", sog_positions), ("sog_alpha", sog_alpha), ("kmeans1d", kmeans1d),
+                     ("rgb_from_sh", rgb_from_sh), ("require_hip", lambda: None)):
         monkeypatch.setattr(lib, name, fn)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_HIP", True)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_TAICHI", True)
@@ -276,6 +307,30 @@ def test_converter_run_all_four_filters_are_one_chain(tmp_path, gsx, dropin):
     assert got.reset_index(drop=True).equals(pre[cap["mask"]].reset_index(drop=True))
 
 
+def test_converter_run_sh_cap_and_rgb_are_the_dropins_own(tmp_path, gsx, dropin):
+    """--sh_level 1 --rgb through the orchestrator (converter.py:188,252): cap_sh_degree and add_rgb_from_sh are methods of the
+    drop-in, not forwarded to the reference class; same table as the un-patched reference writes --
+    also combined with filters, where the lazy class defers the column fill until the table has been compacted"""
+    inp, _ = _write_input(tmp_path)
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    for attr in ("cap_sh_degree", "add_rgb_from_sh", "apply_auto_bbox", "_compute_rgb_from_sh"):
+        assert attr in vars(dp.DataProcessor), attr
+    got = _run(tmp_path, inp, "dropin", sh_level=1, rgb=True, auto_bbox=True)
+    assert [h[0] for h in dropin] == ["gsx_rgb_from_sh"] * 3
+    del dropin[:]
+    got_f = _run(tmp_path, inp, "dropin_f", sh_level=0, rgb=True, density_sensitivity=0.3, auto_bbox=True)
+    assert [h[0] for h in dropin if h[0].endswith("_dev") or "rgb" in h[0]] == \
+        ["gsx_density_voxels_dev", "gsx_density_mask_dev", "gsx_slab_bbox_dev"] + ["gsx_rgb_from_sh"] * 3
+    gsx.uninstall()
+    want = _run(tmp_path, inp, "reference", sh_level=1, rgb=True, auto_bbox=True)
+    zero_cols = int((want.filter(regex="_sh").abs().sum() == 0).sum())     # the parquet codec's r/g/b_sh* columns
+    assert {"red", "green", "blue"} <= set(want.columns) and zero_cols == 36   # f_rest_9..44 zeroed, 3 DC + 9 AC kept
+    assert got.equals(want)
+    want_f = _run(tmp_path, inp, "reference_f", sh_level=0, rgb=True, density_sensitivity=0.3, auto_bbox=True)
+    assert 0 < len(want_f) < 6000 and int((want_f.filter(regex="_sh").abs().sum() == 0).sum()) == 45
+    assert got_f.equals(want_f)
+
+
 def test_compressed_ply_writer_goes_through_the_dropin(tmp_path, gsx, dropin):
     """install() rebinds CompressedPlyFormat.write: Morton order, chunk bounds and packers reach the product's entry points;
     the file holds exactly the elements the reference's own writer produces (with its argsort made stable)"""
@@ -325,14 +380,17 @@ def test_sog_writer_goes_through_the_dropin(tmp_path, gsx, dropin):
     np.random.seed(1)
     sogmod.SogFormat().write(data, a, compression_level=2)
     names = [h[0] for h in dropin]
-    assert names[0] == "gsx_lexsort3" and names[1] == "gsx_sog_quats"
+    assert names[0] == "gsx_lexsort3" and names[1:4] == ["gsx_sog_positions"] * 3 and names[4] == "gsx_sog_quats"
+    assert names.count("gsx_sog_alpha") == 1
     plan = okm.sog_sh_plan(n, 2)
     km = [h for h in dropin if h[0] == "gsx_kmeans_lloyd"]
-    # two scalar codebooks (sog.py:402,443) + one call per SH chunk (:544); the K >= N shortcut never reaches the device
-    assert [h[1:] for h in km[:2]] == [((3 * n, 1), 256, 20)] * 2
+    k1 = [h for h in dropin if h[0] == "gsx_kmeans1d"]
     sizes = [min(plan["chunk_size"], n - i * plan["chunk_size"]) for i in range(plan["num_chunks"])]
+    # two scalar codebooks (sog.py:402,443) and the palette's codebook (:561) through the scalar solver ...
+    assert [h[1:3] for h in k1] == [(3 * n, 256), (3 * n, 256), (45 * sum(min(s, plan["k_per_chunk"]) for s in sizes), 256)]
+    # ... and one Lloyd call per SH chunk (:544); the K >= N shortcut never reaches the device
     want_chunks = [((s, 45), min(s, plan["k_per_chunk"]), 10) for s in sizes if min(s, plan["k_per_chunk"]) < s]
-    assert [h[1:] for h in km[2:]] == want_chunks
+    assert [h[1:] for h in km] == want_chunks
     # the quantiser is reachable now: 3 scale columns + 3 colour columns + the palette's centroid scalars
     qz = [h for h in dropin if h[0] == "gsx_quantize_sorted_codebook"]
     assert [h[1] for h in qz[:6]] == [n] * 6 and len(qz) == 7 and qz[6][1] == 45 * sum(min(s, plan["k_per_chunk"]) for s in sizes)
@@ -360,6 +418,8 @@ def test_sog_writer_goes_through_the_dropin(tmp_path, gsx, dropin):
     # every splat's palette label points at a valid centroid; labels of a chunk stay inside the chunk's slice of the palette
     lab = ta["shN_labels"][:n, 0].astype(np.int64) + 256 * ta["shN_labels"][:n, 1].astype(np.int64)
     assert lab.max() < ma["shN"]["count"]
-    # (codebook QUALITY is not compared here: the un-patched run used the reference's sklearn fallback, whose
-    # k-means++ init beats the random-sample init of the reference's own GPU path on 1-D data -- see
-    # tests/test_kmeans_gpu.py::test_scalar_codebook_quality_is_the_taichi_paths_not_sklearns)
+    # codebook QUALITY: the un-patched run used the reference's sklearn path (k-means++-seeded MiniBatchKMeans); the drop-in's
+    # scalar solver must not be worse on any of the three codebooks
+    for tex, cols in (("scales", ["scale_0", "scale_1", "scale_2"]), ("sh0", ["f_dc_0", "f_dc_1", "f_dc_2"])):
+        flat = np.concatenate([ds[c] for c in cols])
+        assert okm.inertia_1d(flat, ma[tex]["codebook"]) <= 1.02 * okm.inertia_1d(flat, mb[tex]["codebook"]), tex

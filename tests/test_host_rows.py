@@ -109,3 +109,34 @@ def test_alpha_and_bbox_filters_match_the_reference_expressions():
     w = np.zeros(5, np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4")]))
     p = dp.DataProcessor(w)
     assert p.apply_alpha_filter(10) is None and p.data is w  # no opacity channel: skipped with a warning
+
+
+def test_zero_columns_and_append_columns_equal_numpy(gsx):
+    """the host halves of cap_sh_degree (data_processor.py:310-313) and add_rgb_from_sh (:262-274): same bytes as numpy's
+    field-by-field version, on the reference's 248-byte table, a table with trailing u1 fields, and tiny / empty inputs"""
+    L = gsx._lib
+    from oracle import datasets
+    for n in (0, 1, 7, 50_001):
+        a = datasets.sog_scene(n, 1) if n else np.zeros(0, dtype=datasets.splat_dtype(3))
+        b = a.copy()
+        names = ["f_rest_%d" % i for i in range(9, 45)] + ["not_a_field"]
+        L.host_zero_columns(a, names)
+        for nm in names[:-1]:
+            b[nm] = 0.0
+        assert a.tobytes() == b.tobytes()
+        cols = np.random.default_rng(n).integers(0, 256, (n, 3)).astype(np.uint8)
+        for base in (a, L.host_append_u8_columns(a, ("u", "v", "w"), cols)):      # second round: itemsize 251 -> 254
+            w = L.host_append_u8_columns(base, ("red", "green", "blue"), cols)
+            want = np.empty(n, dtype=base.dtype.descr + [("red", "u1"), ("green", "u1"), ("blue", "u1")])
+            for nm in base.dtype.names:
+                want[nm] = base[nm]
+            want["red"], want["green"], want["blue"] = cols[:, 0], cols[:, 1], cols[:, 2]
+            assert w.dtype == want.dtype and w.tobytes() == want.tobytes()
+    # scattered (non-adjacent) columns and a read-only view fall back to numpy's own assignment
+    a = datasets.sog_scene(100, 2)
+    b = a.copy()
+    L.host_zero_columns(a, ["x", "f_rest_3", "rot_3"])
+    b["x"] = 0.0
+    b["f_rest_3"] = 0.0
+    b["rot_3"] = 0.0
+    assert a.tobytes() == b.tobytes()

@@ -101,3 +101,60 @@ def test_write_sog_on_the_device_reproduces_the_reference_bundle(gsx, kref, tmp_
             np.testing.assert_array_equal(okm.quantize_to_codebook(ds[col], cb)[vis], tex[t][:n, ch][vis])
     lab = tex["shN_labels"][:n, 0].astype(np.int64) + 256 * tex["shN_labels"][:n, 1].astype(np.int64)
     assert lab.max() < meta["shN"]["count"]
+
+
+def _np_positions(v):
+    t = np.sign(v) * np.log(np.abs(v) + 1.0)                       # formats/sog.py:280-281
+    mn, mx = np.min(t), np.max(t)
+    return np.clip((t - mn) / (mx - mn) * 65535, 0, 65535).astype(np.uint16), mn, mx     # :293-295
+
+
+@pytest.mark.parametrize("kind", ["scene", "wide", "tiny", "mixed", "grid", "one_sided"])
+def test_log_positions_device_path_is_numpys_bytes(gsx, kind):
+    """gsx_sog_positions (float64 log + rounding certificate, numpy only for flagged texels) == numpy's own float32
+    expression of formats/sog.py:279-309, texel for texel, min / max bits included"""
+    lib = gsx._lib
+    rng = np.random.default_rng(5)
+    n = 1_000_003
+    v = {"scene": lambda: rng.standard_normal(n) * 3.0,
+         "wide": lambda: rng.standard_normal(n) * np.exp(rng.uniform(-12, 12, n)),
+         "tiny": lambda: rng.standard_normal(n) * 1e-6,
+         "mixed": lambda: np.concatenate([rng.standard_normal(n - 6) * 50.0, [0.0, -0.0, 1e-30, -1e-30, 3.0e5, -2.0e5]]),
+         "grid": lambda: np.round(rng.standard_normal(n) * 40.0) * 0.25,
+         "one_sided": lambda: np.abs(rng.standard_normal(n)) + 2.0}[kind]().astype(np.float32)
+    stats = {}
+    got, mn, mx = lib.sog_positions(v, stats)
+    want, wmn, wmx = _np_positions(v)
+    assert np.float32(mn).tobytes() == np.float32(wmn).tobytes() and np.float32(mx).tobytes() == np.float32(wmx).tobytes()
+    np.testing.assert_array_equal(got, want)
+    assert stats["uncertain"] <= 0.02 * n, stats      # the device decides (nearly) all of it
+
+
+def test_log_positions_on_the_reference_bundle(gsx, kref):
+    cases, arr = kref
+    for name in ("sog_20k_l2", "sog_3k_l8"):
+        case = cases["sog"][name]
+        data = datasets.sog_scene(case["n"], case["scene_seed"])
+        ds = data[np.lexsort((data["z"], data["y"], data["x"]))]
+        for c, a in enumerate("xyz"):
+            u, mn, mx = gsx._lib.sog_positions(ds[a])
+            np.testing.assert_array_equal((u & 0xff).astype(np.uint8), arr[name + "__means_l"][:case["n"], c])
+            np.testing.assert_array_equal((u >> 8).astype(np.uint8), arr[name + "__means_u"][:case["n"], c])
+            assert float(mn) == case["meta"]["means"]["mins"][c] and float(mx) == case["meta"]["means"]["maxs"][c]
+        np.testing.assert_array_equal(gsx._lib.sog_alpha(ds["opacity"]), arr[name + "__sh0"][:case["n"], 3])
+
+
+def test_sigmoid_alpha_device_path_is_numpys_bytes(gsx):
+    rng = np.random.default_rng(6)
+    n = 2_000_001
+    o = (rng.standard_normal(n) * 4.0).astype(np.float32)
+    o[:8] = [0.0, -0.0, 90.0, -90.0, 17.0, -17.0, 1e-8, -1e-8]
+    # logits of k/255 exactly: texel boundaries
+    kk = np.arange(1, 255, dtype=np.float64) / 255.0
+    o[8:8 + 254] = np.log(kk / (1 - kk)).astype(np.float32)
+    stats = {}
+    got = gsx._lib.sog_alpha(o, stats)
+    with np.errstate(all="ignore"):
+        want = np.clip(1.0 / (1.0 + np.exp(-o)) * 255, 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
+    assert stats["uncertain"] <= 0.005 * n, stats
