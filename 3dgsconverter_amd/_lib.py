@@ -45,6 +45,7 @@ SIGNATURES = {
     "gsx_ctx_create": (_I, [_I, C.POINTER(_P)]),
     "gsx_ctx_destroy": (None, [_P]),
     "gsx_ctx_set_stream": (_I, [_P, _P]),
+    "gsx_ctx_own_stream": (_I, [_P]),
     "gsx_ctx_synchronize": (_I, [_P]),
     "gsx_ctx_check": (_I, [_P]),
     "gsx_ctx_set_timing": (_I, [_P, _I]),
@@ -417,6 +418,52 @@ def kmeans1d(vals: np.ndarray, k: int, iters: int = 50, want_labels: bool = Fals
     return out[0] if len(out) == 1 else out
 
 
+PALETTE_LANES = 4   # concurrent contexts for independent K-Means problems (bench.py config4: 1 lane 73 ms, 4 lanes see profiles/)
+
+
+def kmeans_lloyd_many(problems, max_iter: int, lanes: int = PALETTE_LANES, device: int = 0):
+    """Independent Lloyd problems -- the SOG palette's chunks, formats/sog.py:536-552 -- on `lanes` contexts with streams of
+    their own: while one chunk's ~100 kernels run, the next chunks' rows are uploaded and their kernels fill the tails.
+    problems: list of (data f32[n,d], init f32[k,d]); -> list of (centroids f32[k,d], labels i32[n]).  Same kernels and
+    launch order per problem as kmeans_lloyd, hence the same results."""
+    require_hip()
+    if not problems:
+        return []
+    lanes = max(1, min(int(lanes), len(problems)))
+    ctxs = [Context(device, own_stream=True) for _ in range(lanes)]
+    out = [None] * len(problems)
+    bufs = []
+    try:
+        cap_d = max(p[0].size for p in problems) * 4
+        cap_c = max(p[1].size for p in problems) * 4
+        cap_l = max(len(p[0]) for p in problems) * 4
+        bufs = [(c.alloc(cap_d), c.alloc(cap_c), c.alloc(cap_l + 16)) for c in ctxs]
+        for base in range(0, len(problems), lanes):
+            live = []
+            for lane in range(min(lanes, len(problems) - base)):
+                data = np.ascontiguousarray(problems[base + lane][0], dtype=np.float32)
+                init = np.ascontiguousarray(problems[base + lane][1], dtype=np.float32)
+                n, d = data.shape
+                k = init.shape[0]
+                c = ctxs[lane]
+                bd, bc, bl = bufs[lane]
+                check(c.lib.gsx_dev_upload_async(c.handle, bd.ptr, data.ctypes.data, data.nbytes), "gsx_dev_upload_async")
+                check(c.lib.gsx_dev_upload_async(c.handle, bc.ptr, init.ctypes.data, init.nbytes), "gsx_dev_upload_async")
+                check(c.lib.gsx_dev_memset(c.handle, bl.ptr, 0, 4 * n), "gsx_dev_memset")   # max_iter == 0: labels stay 0
+                check(c.lib.gsx_kmeans_lloyd_dev(c.handle, bd.ptr, n, d, k, int(max_iter), bc.ptr, bl.ptr), "gsx_kmeans_lloyd_dev")
+                live.append((lane, data, init, n, d, k))   # (keeps the host arrays alive until the lane has been drained)
+            for lane, _, _, n, d, k in live:
+                bd, bc, bl = bufs[lane]
+                out[base + lane] = (bc.download(np.float32, k * d).reshape(k, d), bl.download(np.int32, n))
+    finally:
+        for trio in bufs:
+            for b in trio:
+                b.free()
+        for c in ctxs:
+            c.close()
+    return out
+
+
 def quantize_sorted_codebook(vals: np.ndarray, codebook: np.ndarray) -> np.ndarray:
     lib = require_hip()
     vals = np.ascontiguousarray(vals, dtype=np.float32)
@@ -610,13 +657,15 @@ class DeviceArray:
 class Context:
     """gsx_ctx wrapper: device-resident entry points (pointers are plain ints)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, own_stream: bool = False):
         self.lib = require_hip()
         h = C.c_void_p()
         check(self.lib.gsx_ctx_create(int(device), C.byref(h)), "gsx_ctx_create")
         self.handle = h
         if stream is not None:
             self.set_stream(stream)
+        elif own_stream:   # a non-blocking stream of its own: contexts created like this run concurrently on one GPU
+            check(self.lib.gsx_ctx_own_stream(self.handle), "gsx_ctx_own_stream")
 
     def close(self):
         if self.handle:

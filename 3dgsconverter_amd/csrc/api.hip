@@ -167,6 +167,7 @@ void gsx_ctx_destroy(gsx_ctx *c)
     for (auto &w : c->ws) w.release_all();
     gsx::DevBuf *bufs[] = {&c->devflags, &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
+    if (c->owned_stream) (void)hipStreamDestroy(c->owned_stream);
     delete c;
 }
 
@@ -174,6 +175,15 @@ int gsx_ctx_set_stream(gsx_ctx *c, void *s)
 {
     if (!c) GSX_FAIL("null ctx");
     c->stream = reinterpret_cast<hipStream_t>(s);
+    return 0;
+}
+
+int gsx_ctx_own_stream(gsx_ctx *c)
+{
+    if (!c) GSX_FAIL("null ctx");
+    GSX_HIP(hipSetDevice(c->device));
+    if (!c->owned_stream) GSX_HIP(hipStreamCreateWithFlags(&c->owned_stream, hipStreamNonBlocking));
+    c->stream = c->owned_stream;
     return 0;
 }
 
@@ -288,11 +298,12 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
     if (!c || !x || !y || !z || !mean_out) GSX_FAIL("gsx_sor_knn_dev: null argument");
     if (n_ref <= 0 || n_ref >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_knn_dev: n_ref=%lld out of range", (long long)n_ref);
     if (q_begin < 0 || q_count < 0 || q_begin + q_count > n_ref) GSX_FAIL("gsx_sor_knn_dev: query range out of bounds");
-    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_knn_dev: k=%d not supported (1 <= k <= 64)", k);
+    if (k < 1 || k > 2047) GSX_FAIL("gsx_sor_knn_dev: k=%d not supported (1 <= k <= 2047)", k);
     if (stride < 1) GSX_FAIL("gsx_sor_knn_dev: bad stride");
     GSX_HIP(hipSetDevice(c->device));
     if (q_count == 0) return 0;
     if (algo == GSX_KNN_AUTO) algo = n_ref < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID;
+    if (k > 64) algo = GSX_KNN_GRID;   // the list-free any-k kernel lives on the grid path (csrc/sor_grid.hip: knn_anyk_kernel)
     if (algo == GSX_KNN_BRUTE) {
         GSX_CHECK(c->ws[0].packed.reserve(sizeof(float4) * (size_t)n_ref));
         GSX_CHECK(timing_begin(c, GSX_T_SOR_BIN));
@@ -418,7 +429,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     if (mean_out) GSX_HIP(hipMemcpyAsync(mean_out, dmd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
     GSX_CHECK(gsx_ctx_check(c));  // synchronises; non-finite coordinates (either algorithm) are an error, like cKDTree's
-    const int used = algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo;
+    const int used = k > 64 ? GSX_KNN_GRID : (algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo);
     if (info) {
         // re-query diagnostics without recomputing: only the grid path has device-side counters
         memset(info, 0, sizeof(*info));

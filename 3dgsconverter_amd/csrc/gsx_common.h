@@ -96,6 +96,7 @@ struct TimingSlot {
 struct gsx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t owned_stream = nullptr;   // gsx_ctx_own_stream: a non-blocking stream created for (and destroyed with) the context
     bool timing = false;
     unsigned timing_mask = 0xffffffffu;  // slots that record events when timing is on (an event pair costs ~8 us of stream time)
     gsx::TimingSlot slots[GSX_T_SLOTS];

@@ -1450,6 +1450,177 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
     }
 }
 
+// ---------------------------------------------------------------- knn_anyk (k > 64)
+// The reference's cKDTree path takes any k (data_processor.py:171; the CLI's hidden --sor_k, main.py:278); the
+// register-resident lists of the kernels above stop at k = 64.  Larger k takes this exact, list-free path: one wave per
+// query; the (2H+1)^3 cells around the query's cell are walked as contiguous x-rows; the (k+1)-th smallest squared
+// distance is found by an 8-pass radix SELECT on the float64 bit pattern (non-negative doubles order like their bits): a
+// 256-bin LDS histogram per pass over the candidates that match the prefix so far, distances recomputed each pass -- no
+// per-query storage that grows with the candidate count.  Exact iff that distance is within the guaranteed radius
+// H h' (1 - 1e-3) (section 4.2's argument) or the block covers the grid; otherwise H grows.  The k+1 winners (ties at the
+// k-th value are equal numbers: which one is taken does not matter) are then collected, sorted in LDS by a wave-wide
+// bitonic network and summed by one lane in numpy's pairwise order (loops_utils.h.src: 8 accumulators up to 128
+// elements, halves rounded down to a multiple of 8 above).  k + 1 <= 2048.  Slow (9 distance evaluations per candidate)
+// and rare: nothing in the CLI's documented flags reaches it (--sor_intensity maps to k <= 50).
+constexpr int ANYK_MAX = 2048;
+
+template <int DEPTH, class F>
+__device__ double pairwise_sum_np(F at, int lo, int n)   // numpy's pairwise_sum for any n (DEPTH halvings unrolled)
+{
+    if constexpr (DEPTH == 0) {
+        return pairwise_sum_le128([&](int i) { return at(lo + i); }, n);
+    } else {
+        if (n <= 128) return pairwise_sum_le128([&](int i) { return at(lo + i); }, n);
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return __dadd_rn(pairwise_sum_np<DEPTH - 1>(at, lo, n2), pairwise_sum_np<DEPTH - 1>(at, lo + n2, n - n2));
+    }
+}
+
+__global__ __launch_bounds__(BRICK_THREADS) void knn_anyk_kernel(GridParams *__restrict__ gp, const float4 *__restrict__ refs,
+                                                                 const unsigned *__restrict__ rstart, const float4 *__restrict__ qpts,
+                                                                 int nq, int k, int q_begin, float *__restrict__ mean_out,
+                                                                 double *__restrict__ kth_out)
+{
+    __shared__ unsigned s_hist[BRICK_THREADS / 64][256];
+    __shared__ double s_sel[BRICK_THREADS / 64][ANYK_MAX];
+    __shared__ unsigned s_cnt[BRICK_THREADS / 64];
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    unsigned *hist = s_hist[wv];
+    double *sel = s_sel[wv];
+    const GridParams g = *gp;
+    const int kk = k + 1;
+    const int nwaves = gridDim.x * (BRICK_THREADS / 64);
+    if (g.bad_input) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) mean_out[i] = __builtin_nanf("");
+        return;
+    }
+    for (int t = blockIdx.x * (BRICK_THREADS / 64) + wv; t < nq; t += nwaves) {
+        const float4 qp = qpts[t];
+        if (__float_as_uint(qp.w) >> 31) continue;   // reference-only point
+        const double qxd = (double)qp.x, qyd = (double)qp.y, qzd = (double)qp.z;
+        const int cx = cell_coord(qp.x, g.ox, g.inv_h, g.nx);
+        const int cy = cell_coord(qp.y, g.oy, g.inv_h, g.ny);
+        const int cz = cell_coord(qp.z, g.oz, g.inv_h, g.nz);
+        for (int H = 1;; ++H) {
+            const int x0 = max(cx - H, 0), x1 = min(cx + H, g.nx - 1);
+            const int y0 = max(cy - H, 0), y1 = min(cy + H, g.ny - 1);
+            const int z0 = max(cz - H, 0), z1 = min(cz + H, g.nz - 1);
+            const bool covers = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
+            // f(d2 bits) for every candidate of the block
+            auto for_each = [&](auto f) __attribute__((always_inline)) {
+                for (int zz = z0; zz <= z1; ++zz)
+                    for (int yy = y0; yy <= y1; ++yy) {
+                        const int row = row_base(g, yy, zz);
+                        const int sb = (int)rstart[row + x0], se = (int)rstart[row + x1 + 1];
+                        for (int j = sb + lane; j < se; j += 64) {
+                            const float4 p = refs[j];
+                            f((unsigned long long)__double_as_longlong(dist2_f64(qxd, qyd, qzd, p.x, p.y, p.z)));
+                        }
+                    }
+            };
+            // ---- radix select of the kk-th smallest
+            unsigned long long prefix = 0ull, pmask = 0ull;
+            int remaining = kk;
+            bool enough = true;
+            for (int pass = 0; pass < 8 && enough; ++pass) {
+                const int shift = 56 - 8 * pass;
+                for (int i = lane; i < 256; i += 64) hist[i] = 0u;
+                wave_sync();
+                for_each([&](unsigned long long b) {
+                    if ((b & pmask) == prefix) atomicAdd(&hist[(unsigned)(b >> shift) & 255u], 1u);
+                });
+                wave_sync();
+                // lane l owns bins 4l .. 4l+3
+                const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+                unsigned inc = c0 + c1 + c2 + c3;
+                const unsigned mine = inc;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_up(inc, off);
+                    if (lane >= off) inc += o;
+                }
+                const unsigned total = __shfl(inc, 63);
+                if (pass == 0 && (int)total < kk) {   // fewer than k+1 points in the block
+                    enough = false;
+                    break;
+                }
+                const unsigned before = inc - mine;
+                const bool here = (int)before < remaining && remaining <= (int)(before + mine);
+                const int owner = (int)__builtin_ctzll(__ballot(here));
+                unsigned bin = 0, skip = 0;
+                if (lane == owner) {
+                    const unsigned c[4] = {c0, c1, c2, c3};
+                    unsigned run = before;
+                    for (int j = 0; j < 4; ++j) {
+                        if ((int)(run + c[j]) >= remaining) {
+                            bin = 4u * (unsigned)lane + (unsigned)j;
+                            skip = run;
+                            break;
+                        }
+                        run += c[j];
+                    }
+                }
+                bin = (unsigned)__shfl((int)bin, owner);
+                skip = (unsigned)__shfl((int)skip, owner);
+                remaining -= (int)skip;
+                prefix |= (unsigned long long)bin << shift;
+                pmask |= 0xffull << shift;
+                wave_sync();
+            }
+            if (!enough) {
+                if (covers) {   // N < k + 1: cKDTree pads with inf -> the mean is inf
+                    if (lane == 0) {
+                        mean_out[(int)__float_as_uint(qp.w) - q_begin] = __builtin_inff();
+                        if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = __builtin_inf();
+                    }
+                    break;
+                }
+                continue;
+            }
+            const double kth = __longlong_as_double((long long)prefix);
+            const double rH = (double)H * g.hprime * (1.0 - 1e-3);
+            if (!(covers || kth <= rH * rH)) continue;
+            // ---- collect the values strictly below the kk-th, fill up with the kk-th itself, sort, sum
+            if (lane == 0) s_cnt[wv] = 0u;
+            wave_sync();
+            for_each([&](unsigned long long b) {
+                if (b < prefix) sel[atomicAdd(&s_cnt[wv], 1u)] = __longlong_as_double((long long)b);
+            });
+            wave_sync();
+            const int nlt = (int)s_cnt[wv];   // < kk by the definition of the kk-th smallest
+            int P = 64;
+            while (P < kk) P <<= 1;
+            for (int i = nlt + lane; i < P; i += 64) sel[i] = i < kk ? kth : __builtin_inf();
+            wave_sync();
+            for (int size = 2; size <= P; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = lane; i < P / 2; i += 64) {
+                        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const double a = sel[lo], b = sel[hi];
+                        if ((a > b) == up) {
+                            sel[lo] = b;
+                            sel[hi] = a;
+                        }
+                    }
+                    wave_sync();
+                }
+            for (int i = lane; i < kk; i += 64) sel[i] = sqrt_rn_dist2(sel[i]);
+            wave_sync();
+            if (lane == 0) {
+                const double sum = pairwise_sum_np<5>([&](int i) { return sel[1 + i]; }, 0, k);   // entry 0 is the query itself
+                mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+                if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
+            }
+            wave_sync();
+            break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- knn_heavy (ring queries next to a huge cell)
 // A far "floater" whose ring reaches a cell holding most of the cloud would make ONE wave scan
 // millions of candidates (measured: 11 ms for 9 such queries at 1M splats).  knn_ring hands these
@@ -2211,10 +2382,13 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     KnnWs &w = ctx->ws[level];
     w.refined_total = 0;
     const int kk = k + 1;
-    if (kk > 65) GSX_FAIL("sor: k=%d not supported (k must be <= 64)", k);
+    const bool anyk = kk > 65;   // k > 64: the list-free exact path (knn_anyk_kernel) instead of knn_brick + ring kernels
+    if (kk > ANYK_MAX) GSX_FAIL("sor: k=%d not supported (k must be <= %d)", k, ANYK_MAX - 1);
     const int64_t cap = grid_cell_cap(n_ref);
     // slab mode (multi-GPU): every point is binned once, the halo [ref_only_from, n_ref) is flagged reference-only
     const bool slab = ref_only_from < n_ref;
+    if (anyk && (nshares > 1 || slab)) GSX_FAIL("sor: k=%d > 64 is served by the single-GPU path only", k);
+    if (anyk) adaptive = false;
     const bool all = (q_begin == 0 && q_count == n_ref) || slab;
     // (a share of the bricks -- the replicated multi-GPU exchange -- refines the deferred bricks of ITS share only)
     adaptive = adaptive && all && !slab && level + 1 < KNN_MAX_LEVELS;
@@ -2283,6 +2457,31 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     BrickLaunch a{gp, refs, rstart, qpts, qstart, k, q_begin, mean_out, kth_out, w.faillist.as<unsigned>(),
                   w.faillist.as<unsigned>() + std::max<int64_t>(q_count, 1),
                   w.extraitems.as<uint2>(), w.deferred.as<unsigned>(), w.heavylist.as<unsigned>(), q_count, n_ref};
+    if (anyk) {
+        GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((q_count + 3) / 4, (int64_t)ctx->num_cu * 2));
+        hipLaunchKernelGGL(knn_anyk_kernel, dim3(blocks), dim3(BRICK_THREADS), 0, ctx->stream, gp, refs, rstart, qpts, (int)q_count, k,
+                           (int)q_begin, mean_out, kth_out);
+        GSX_HIP(hipGetLastError());
+        GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
+        if (info) {
+            GridParams h2;
+            GSX_HIP(hipMemcpyAsync(&h2, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
+            GSX_HIP(hipStreamSynchronize(ctx->stream));
+            info->algo = GSX_KNN_GRID;
+            info->grid_dim[0] = h2.nx;
+            info->grid_dim[1] = h2.ny;
+            info->grid_dim[2] = h2.nz;
+            info->cell_size = h2.h;
+            info->n_cells = (int64_t)h2.nx * h2.ny * h2.nz;
+            info->n_bricks = 0;
+            info->n_fallback = q_count;
+            info->n_exhaustive = h2.exhaustive_count;
+            info->n_deferred_bricks = 0;
+            info->n_refined = 0;
+        }
+        return 0;
+    }
     GSX_CHECK(dispatch_bricks(ctx, a, ctx->filter_mfma != 0, ctx->phase2_net != 0));
 
     const bool trace = getenv("GSX_TRACE_LEVELS") != nullptr;

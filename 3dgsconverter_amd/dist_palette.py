@@ -33,6 +33,7 @@ def palette_kmeans(sh_data: np.ndarray, compression_level: int = 0, max_iter: in
     labels): ``gpu_ops.kmeans`` by default.  comm / be: a communicator and buffer backend of dist_slab (RcclComm +
     HipSlabBackend, or the host stand-ins of the tests); None = one GPU does every chunk.
     -> (centroids f32 [P, D], labels int64 [N] into the concatenated palette)"""
+    lanes_default = kmeans is None   # the product path: this rank's chunks on a few concurrent contexts (_lib.kmeans_lloyd_many)
     if kmeans is None:
         from .processing import gpu_ops
         kmeans = lambda d, k, it, init: gpu_ops.kmeans(d, k, max_iter=it, init_centroids=init)
@@ -51,11 +52,22 @@ def palette_kmeans(sh_data: np.ndarray, compression_level: int = 0, max_iter: in
     inits = [np.random.choice(e - s, k, replace=False) if k < e - s else None for (s, e), k in zip(bounds, ks)]
     mine = [i for i in range(len(bounds)) if i % world == rank]
     results = {}
-    for i in mine:
-        s, e = bounds[i]
-        chunk = np.ascontiguousarray(sh_data[s:e], dtype=np.float32)
-        init = chunk[inits[i]] if inits[i] is not None else None
-        results[i] = kmeans(chunk, ks[i], max_iter, init)
+    if lanes_default:
+        from . import _lib
+        todo = [i for i in mine if inits[i] is not None]
+        chunks = {i: np.ascontiguousarray(sh_data[bounds[i][0]:bounds[i][1]], dtype=np.float32) for i in todo}
+        done = _lib.kmeans_lloyd_many([(chunks[i], chunks[i][inits[i]]) for i in todo], max_iter)
+        results.update(dict(zip(todo, done)))
+        for i in mine:
+            if inits[i] is None:   # k >= rows: the reference's shortcut (gpu_ops.py:30-31)
+                s, e = bounds[i]
+                results[i] = kmeans(np.ascontiguousarray(sh_data[s:e], dtype=np.float32), ks[i], max_iter, None)
+    else:
+        for i in mine:
+            s, e = bounds[i]
+            chunk = np.ascontiguousarray(sh_data[s:e], dtype=np.float32)
+            init = chunk[inits[i]] if inits[i] is not None else None
+            results[i] = kmeans(chunk, ks[i], max_iter, init)
     if world > 1:
         # all-gather of padded per-rank blocks: [slots, kmax, d] centroids and [slots, chunk_size] labels
         slots = -(-len(bounds) // world)

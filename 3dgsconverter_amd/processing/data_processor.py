@@ -9,7 +9,7 @@ Differences from the reference, all deliberate:
     mask at :180 and returns the data unfiltered (:181-182); its GPU branch
     applies it (:149).  This class follows the GPU branch.
   * the KNN is exact (cKDTree semantics), not the Taichi kernel's 27-cell approximation
-    (SURVEY.md F4/F5); k up to 64.
+    (SURVEY.md F4/F5); any k up to 2047 (k <= 64 on the fast kernels).
   * there is NO CPU fallback: if the HIP library or the GPU is missing the call raises
     ``GsxError`` (a RuntimeError).
 Every method of the reference class is implemented here (round 3: ``cap_sh_degree``, ``add_rgb_from_sh``,
@@ -25,7 +25,7 @@ from ..utils import debug_print, status_print
 from . import clusters as _clusters
 
 
-MAX_SOR_K = 64  # include/gsx_hip.h: gsx_sor_* accept 1 <= k <= 64
+MAX_SOR_K = 2047  # include/gsx_hip.h: 1 <= k <= 64 on the fast kernels, 65..2047 through the exact list-free kernel (slow)
 
 
 def sor_params_from_intensity(intensity):
@@ -142,8 +142,8 @@ class DataProcessor:
         if num_points == 0:
             return self.data
         if not 1 <= int(k) <= MAX_SOR_K:
-            # the reference's cKDTree path takes any k and its Taichi kernel silently caps K at 50 (gpu_ops.py:244);
-            # the register-resident top-k lists of the HIP kernels stop at 64 -- say so instead of failing deep inside
+            # the reference's cKDTree path takes any k and its Taichi kernel silently caps K at 50 (gpu_ops.py:244); here
+            # k <= 64 runs on the register-resident kernels, 65..2047 on the exact list-free kernel
             raise ValueError(f"SOR: k={k} is outside the supported range 1..{MAX_SOR_K} of the MI355X path "
                              f"(--sor_intensity maps to k = 10..50, the CLI default is 25)")
         status_print("[SOR] Determining outliers on GPU (HIP gfx950, exact KNN)...")

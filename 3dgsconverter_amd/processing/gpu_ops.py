@@ -64,8 +64,8 @@ def filter_sor_gpu(data_np: np.ndarray, k: int = 25, threshold_factor: float = 1
     N, D = data_np.shape
     if D != 3:
         raise ValueError("Requires 3D data")
-    if not 1 <= int(k) <= 64:
-        raise ValueError(f"SOR: k={k} is outside the supported range 1..64 of the MI355X path")
+    if not 1 <= int(k) <= 2047:
+        raise ValueError(f"SOR: k={k} is outside the supported range 1..2047 of the MI355X path")
     res = _lib.sor_filter(np.ascontiguousarray(data_np, dtype=np.float32), int(k), float(threshold_factor),
                           want_mean=False)
     if verbose:

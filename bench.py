@@ -321,7 +321,7 @@ def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup
         ch.close()
 
 
-def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
+def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=0):
     """BASELINE.json configs[4] with SURVEY.md 8(d) config-5 data: f_rest ~ N(0, 0.1^2) f32 from numpy's seed-0 generator,
     initial centroids = random rows drawn like the reference's front door (np.random.seed(0); one np.random.choice per chunk,
     gpu_ops.py:182).  One step = all chunks of the scene, SH rows resident in HBM."""
@@ -331,6 +331,11 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
     nch, cs, k = plan["num_chunks"], plan["chunk_size"], plan["k_per_chunk"]
     rng = np.random.default_rng(0)
     np.random.seed(0)
+    # the chunks are independent problems (sog.py:536-552): they are dealt out to a few contexts with streams of their own,
+    # exactly as the product's palette path does (_lib.kmeans_lloyd_many), so that one chunk's small kernels fill the tails
+    # of another's
+    nlanes = max(1, min(lanes if lanes else L.PALETTE_LANES, nch))
+    lane_ctx = [L.Context(0, own_stream=True) for _ in range(nlanes)]
     chunks, inits, cents, labels, first_host = [], [], [], [], None
     for i in range(nch):
         rows = min(cs, n_scene - i * cs)
@@ -342,26 +347,39 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
         inits.append(ctx.alloc(init.nbytes).upload(np.ascontiguousarray(init)))
         cents.append(ctx.alloc(init.nbytes))
         labels.append(ctx.alloc(4 * rows + 16))
-    for name, val in params:
-        ctx.set_param(name, val)
+    for c in lane_ctx:
+        for name, val in params:
+            c.set_param(name, val)
 
     def step():
         for j in range(nch):
-            L.check(ctx.lib.gsx_dev_copy(ctx.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
-            L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
+            c = lane_ctx[j % nlanes]
+            L.check(c.lib.gsx_dev_copy(c.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
+            L.check(c.lib.gsx_kmeans_lloyd_dev(c.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
                     "gsx_kmeans_lloyd_dev")
 
+    class _AllLanes:   # what time_steps synchronises: every lane
+        def synchronize(self):
+            for c in lane_ctx:
+                c.synchronize()
+
     try:
-        t = time_steps(ctx, step, steps, warmup)
-        side = 1
-        ctx.set_param("timing_mask", (1 << L.T_KMEANS_ASSIGN) | (1 << L.T_KMEANS_UPDATE))
-        ctx.set_timing(True)
-        ctx.reset_timing()
-        step()
         ctx.synchronize()
-        n_as, ms_as = ctx.timing(L.T_KMEANS_ASSIGN)
-        n_up, ms_up = ctx.timing(L.T_KMEANS_UPDATE)
-        ctx.set_timing(False)
+        t = time_steps(_AllLanes(), step, steps, warmup)
+        # kernel groups: one extra pass on ONE lane with events (concurrent lanes would overlap each other's intervals)
+        side = 1
+        c0 = lane_ctx[0]
+        c0.set_param("timing_mask", (1 << L.T_KMEANS_ASSIGN) | (1 << L.T_KMEANS_UPDATE))
+        c0.set_timing(True)
+        c0.reset_timing()
+        for j in range(nch):
+            L.check(c0.lib.gsx_dev_copy(c0.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
+            L.check(c0.lib.gsx_kmeans_lloyd_dev(c0.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
+                    "gsx_kmeans_lloyd_dev")
+        c0.synchronize()
+        n_as, ms_as = c0.timing(L.T_KMEANS_ASSIGN)
+        n_up, ms_up = c0.timing(L.T_KMEANS_UPDATE)
+        c0.set_timing(False)
         assign_ms = ms_as / max(n_as, 1)            # one interval = operand prep + matrix-core assign + exact list, one chunk iteration
         rows0 = chunks[0][1]
         ktiles, ns = (k + 31) // 32, 3              # 32-centroid tiles, three 16-wide slices of the 45 (+3) dimensions
@@ -373,8 +391,11 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
                            "compression_level %d -> %d chunks of %d rows, K=%d per chunk, %d Lloyd iterations, rows resident in HBM"
                            % (n_scene, level, nch, cs, k, iters),
                "value": round(n_scene * steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(t["ms_per_step"], 3), "steps": steps,
+               "lanes": nlanes,
                "kernel_ms_per_step": {"assign (operands + mfma + exact list)": round(ms_as / side, 3),
-                                      "update (label sort + segmented reduce)": round(ms_up / side, 3)},
+                                      "update (label sort + segmented reduce)": round(ms_up / side, 3),
+                                      "note": "HIP-event sums of a separate pass on ONE lane (%d launches back to back); the timed region "
+                                              "runs the chunks on %d concurrent lanes" % (nch * iters, nlanes)},
                "roofline": {"bound": "mfma", "kernel": "kmeans_assign_mfma_cs_kernel<45> (+ operand prep and exact list kernel in the same interval)",
                             "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(assign_ms, 4),
@@ -400,10 +421,14 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=()):
                                    "inertia_gpu_same_chunk": round(okm.inertia(first_host, c0, l0), 2)}
         return out
     finally:
+        for c in lane_ctx:
+            c.synchronize()
         for b, _ in chunks:
             b.free()
         for b in inits + cents + labels:
             b.free()
+        for c in lane_ctx:
+            c.close()
 
 
 def main_single(args):
@@ -472,7 +497,7 @@ def main_single(args):
         attempt("config1", config1)
         attempt("host_to_host", lambda: run_host_to_host(L, xyz, args.k, args.sigma))
         attempt("config2", lambda: run_chain(L, ctx, gsx, xyz, 0.5, args.k, args.sigma, small, 2, cpu=want_cpu))
-        attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu))
+        attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu, lanes=args.lanes))
         attempt("clustered_1m", clustered)
         attempt("floaters_10m", floaters)
         out["configs"] = configs
@@ -689,6 +714,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the other configurations (N=1) / the 50M k=32 configs[3] line (N>1)")
     ap.add_argument("--param", action="append", default=[], help="name=value library knob (A/B runs)")
+    ap.add_argument("--lanes", type=int, default=0, help="config4: concurrent contexts for the independent K-Means chunks (0 = the library's default)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
                     help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
                          "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")

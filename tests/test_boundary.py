@@ -185,13 +185,13 @@ def test_info_struct_layout_matches_the_header(gsx, tmp_path):
 
 
 def test_sor_k_range_is_checked_at_the_python_boundary(gsx):
-    """k > 64 (the reference's cKDTree path takes any k, its Taichi kernel caps K at 50) is refused with a clear
-    message before anything reaches the device -- not a GsxError from deep inside the library"""
+    """the reference's cKDTree path takes any k (its Taichi kernel caps K at 50): here 1..2047 (65 and above on the exact
+    list-free kernel); anything else is refused with a clear message before it reaches the device"""
     arr = np.zeros(100, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4")])
     arr["x"] = np.arange(100)
-    with pytest.raises(ValueError, match="1..64"):
-        gsx.DataProcessor(arr).remove_flyers(65, 1.0)
-    with pytest.raises(ValueError, match="1..64"):
+    with pytest.raises(ValueError, match="1..2047"):
+        gsx.DataProcessor(arr).remove_flyers(2048, 1.0)
+    with pytest.raises(ValueError, match="1..2047"):
         gsx.gpu_ops.filter_sor_gpu(np.zeros((100, 3), np.float32), k=0)
     # every --sor_intensity maps inside the range (data_processor.py:125-134)
     from importlib import import_module

@@ -190,7 +190,7 @@ def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sizes,name", [((600000, 400000), "dens_u1m_L5_s0p5"), ((90001, 0, 59999), "dens_clustered_default")])
+@pytest.mark.parametrize("sizes,name", [((600000, 400000), "dens_u1m_L5_s0p5"), ((120001, 0, 79999), "dens_clustered_default")])
 def test_sharded_density_on_shared_gpu_equals_the_reference_masks(sizes, name, golden_cases, golden_arrays, tmp_path):
     """world 2 / 3 (unequal index shards, one EMPTY), histograms merged on the device == the reference's own masks"""
     case = golden_cases["density"][name]

@@ -127,7 +127,11 @@ def test_log_positions_device_path_is_numpys_bytes(gsx, kind):
     want, wmn, wmx = _np_positions(v)
     assert np.float32(mn).tobytes() == np.float32(wmn).tobytes() and np.float32(mx).tobytes() == np.float32(wmx).tobytes()
     np.testing.assert_array_equal(got, want)
-    assert stats["uncertain"] <= 0.02 * n, stats      # the device decides (nearly) all of it
+    # the device decides nearly all of it: a texel is undecided when numpy's possible results (+-5 ulp of the log) straddle a
+    # u16 step, i.e. with probability ~ 10 ulp(|l|) / (range / 65535)
+    t = np.sign(v) * np.log(np.abs(v) + 1.0)
+    expected = float(np.mean(10 * np.spacing(np.abs(t)) / ((wmx - wmn) / 65535.0)))
+    assert stats["uncertain"] <= n * (1.5 * expected + 1e-3), (stats, expected)
 
 
 def test_log_positions_on_the_reference_bundle(gsx, kref):
