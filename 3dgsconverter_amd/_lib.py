@@ -418,7 +418,8 @@ def kmeans1d(vals: np.ndarray, k: int, iters: int = 50, want_labels: bool = Fals
     return out[0] if len(out) == 1 else out
 
 
-PALETTE_LANES = 4   # concurrent contexts for independent K-Means problems (bench.py config4: 1 lane 73 ms, 4 lanes see profiles/)
+PALETTE_LANES = 8   # concurrent contexts for independent K-Means problems (bench.py config4 at 10M splats: 1 lane 72.8 ms,
+                    # 2: 57.1, 4: 54.9, 8: 50.7 -- profiles/r03_variants.txt)
 
 
 def kmeans_lloyd_many(problems, max_iter: int, lanes: int = PALETTE_LANES, device: int = 0):

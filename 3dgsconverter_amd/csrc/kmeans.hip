@@ -255,23 +255,12 @@ __global__ __launch_bounds__(64) void kmeans_centroid_operands_kernel(const floa
     opnd[((size_t)(t * NS + j) * 2 + 1) * 64 + lane] = lo;
 }
 
-#ifndef GSX_KM_WAVES
-#define GSX_KM_WAVES 4
-#endif
-#ifndef GSX_KM_PT
-#define GSX_KM_PT 1   // measured on a SOG chunk (156 250 x 45, K = 1024): 53 us with 1 tile per wave, 59 with 2, 61 with 3
-#endif
-constexpr int KM_MF_WAVES = GSX_KM_WAVES;
-constexpr int KM_MF_PT = GSX_KM_PT;                  // 32-point tiles per wave
+constexpr int KM_MF_WAVES = 4;
+constexpr int KM_MF_PT = 1;                          // 32-point tiles per wave (SOG chunk: 53 us with 1, 59 with 2, 61 with 3)
 constexpr int KM_MF_TILE = KM_MF_WAVES * KM_MF_PT * 32;  // points per workgroup
-#ifndef GSX_KM_PF
-#define GSX_KM_PF 2
-#endif
-constexpr int KM_PF = GSX_KM_PF;                     // centroid tiles requested ahead
-#ifndef GSX_KM_LDS_A
-#define GSX_KM_LDS_A 0   // 1: centroid operand tiles staged once per workgroup in LDS -- measured slower (89 vs 62 us per SOG
-                         // chunk: a workgroup barrier per tile); 0: every wave streams them from L2
-#endif
+constexpr int KM_PF = 2;                             // centroid tiles requested ahead (1 / 2 / 3: 59.1 / 59.2 / 59.2 us)
+// (centroid operand tiles staged per workgroup in LDS instead of streamed per wave from L2: 89 vs 62 us -- a workgroup
+//  barrier per tile; removed)
 
 // labels only: the update runs as a sort-by-label segmented reduction (kmeans_update_* below), not as 45 float64
 // atomics per point (7M per SOG chunk iteration: ~85 us of the fused VALU kernel's 340)
@@ -285,7 +274,6 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
     constexpr int DP = km_dp(D), NS = DP / 16, LS = DP + 1;   // odd LDS row stride
     constexpr int AW = NS * 2 * 64;                           // operand words (16 B) of one centroid tile
     __shared__ float s_tile[KM_MF_TILE * LS];
-    __shared__ ku32x4 s_a[GSX_KM_LDS_A ? 2 : 1][GSX_KM_LDS_A ? AW : 1];   // centroid operands shared by the four waves, double buffered
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float nc2 = *cmax2, nc = __builtin_sqrtf(nc2);
@@ -298,8 +286,6 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
             const int r = e / D;
             s_tile[r * LS + (e - r * D)] = data[base * D + e];
         }
-        if (GSX_KM_LDS_A)
-            for (int e = threadIdx.x; e < AW; e += 64 * KM_MF_WAVES) s_a[0][e] = opnd[e];
         __syncthreads();
         // this wave's point operands: lane l = point (l & 31) of each of its tiles, dimensions 16 j + 8 (l >> 5) ... + 7
         ku32x4 bh[KM_MF_PT][NS], bl[KM_MF_PT][NS];
@@ -337,7 +323,7 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
         }
         ku32x4 a[NS][2], a_pf[KM_PF][NS][2];   // a_pf[i]: tile t + 1 + i, requested KM_PF tiles ahead (an L2 round trip is
                                                // longer than one tile's ~600 cycles of MFMA work)
-        if (!GSX_KM_LDS_A) {
+        {
 #pragma unroll
             for (int j = 0; j < NS; ++j)
 #pragma unroll
@@ -352,15 +338,7 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
             }
         }
         for (int t = 0; t < ktiles; ++t) {
-            if (GSX_KM_LDS_A) {   // the workgroup fetches tile t+1 into the other buffer while its waves multiply tile t
-                const int cur = t & 1;
-                if (t + 1 < ktiles)
-                    for (int e = threadIdx.x; e < AW; e += 64 * KM_MF_WAVES) s_a[cur ^ 1][e] = opnd[(size_t)(t + 1) * AW + e];
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) a[j][v] = s_a[cur][(j * 2 + v) * 64 + lane];
-            } else {
+            {
                 const int tn = t + KM_PF < ktiles ? t + KM_PF : ktiles - 1;
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
@@ -403,9 +381,7 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
                 best[pt] = km_min(best[pt], lo[0]);
                 second[pt] = km_min3(m, second[pt], hi[0]);
             }
-            if (GSX_KM_LDS_A) {
-                __syncthreads();   // tile t+1 is in LDS, tile t's buffer is free
-            } else {
+            {
 #pragma unroll
                 for (int j = 0; j < NS; ++j)
 #pragma unroll
@@ -628,9 +604,6 @@ __global__ __launch_bounds__(256) void kmeans_centroid_reduce_kernel(const float
 // to the cluster's accumulators when the label changes: perfectly balanced whatever the cluster sizes are (one workgroup
 // per centroid, above, runs as long as its largest cluster and reads through one CU), ~2 x 45 float64 atomics per wave.
 // kmeans_finalize_reset_kernel divides and re-zeroes.
-#ifndef GSX_KM_SEGSUM
-#define GSX_KM_SEGSUM 1
-#endif
 __global__ __launch_bounds__(256) void kmeans_segment_sum_kernel(const float *__restrict__ data, int D,
                                                                  const unsigned *__restrict__ perm,
                                                                  const unsigned *__restrict__ starts,
@@ -791,7 +764,7 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
     GSX_HIP(hipMemsetAsync(meta, 0, sizeof(unsigned) * 16, c->stream));
     hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
                        reinterpret_cast<float *>(meta));
-    if (GSX_KM_CS && c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
+    if (c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
         // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h)
         const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)c->num_cu);
         hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
@@ -814,7 +787,7 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
     hipLaunchKernelGGL(kmeans_label_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, k, starts, cursor);
     hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
                        labels, n, k, cursor, list);
-    if (GSX_KM_SEGSUM && D <= 64) {
+    if (D <= 64) {
         const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 256), (int64_t)c->num_cu * 8));
         hipLaunchKernelGGL(kmeans_segment_sum_kernel, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
         hipLaunchKernelGGL(kmeans_finalize_reset_kernel, dim3(k), dim3(64), 0, c->stream, sums, counts, D, cent);

@@ -9,19 +9,7 @@
 // and the uncertain list are those of kmeans_assign_mfma_kernel (gpu_ops.py:57-73 is what both replace).
 #pragma once
 
-#ifndef GSX_KM_CS
-#define GSX_KM_CS 1   // 0: the streaming kernel for every K (A/B)
-#endif
-#ifndef GSX_KM_CS_WAIT
-#define GSX_KM_CS_WAIT 1
-#endif
-#ifndef GSX_KM_CS_MERGE
-#define GSX_KM_CS_MERGE 0   // 1: 8 lanes per point + shuffles (51 us), 0: one thread per point loops over the 16 views (47 us)
-#endif
-#ifndef GSX_KM_CS_WAVES
-#define GSX_KM_CS_WAVES 16
-#endif
-constexpr int KM_CS_WAVES = GSX_KM_CS_WAVES;
+constexpr int KM_CS_WAVES = 16;                // 8 waves x 4 centroid tiles: equal (profiles/r02_variants.txt)
 constexpr int KM_CS_CT = 32 / KM_CS_WAVES;    // centroid tiles per wave -> K <= KM_CS_WAVES * KM_CS_CT * 32 = 1024
 constexpr int KM_CS_PTILES = 4;              // 32-point tiles per block
 constexpr int KM_CS_BLOCK = 32 * KM_CS_PTILES;
@@ -103,9 +91,7 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     }
     // every load so far (the centroid operands above all) has landed: without this the compiler keeps `s_waitcnt vmcnt(6)`
     // in front of the MFMA chain for the first trip's sake, which in every later trip waits for the NEXT block's prefetch
-#if GSX_KM_CS_WAIT
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-#endif
     __syncthreads();
     int cur = 0;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
@@ -172,7 +158,7 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
         }
         if (has_next) split_store(cur ^ 1);
         __syncthreads();   // this block's views are complete, the next block's operand words are in place
-#if !GSX_KM_CS_MERGE
+        // (one thread per point loops over the 16 views: 47 us; 8 lanes per point + three shuffle rounds measured 51)
         if ((int)threadIdx.x < rows) {
             const int p = threadIdx.x;
             const int nw = min(KM_CS_WAVES, (ktiles + KM_CS_CT - 1) / KM_CS_CT);
@@ -194,46 +180,5 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
             if (sure) labels[base + p] = mi;
             else unc_list[atomicAdd(unc_count, 1u)] = (unsigned)(base + p);
         }
-#else
-        // ---- merge the waves' views of every point, certify, publish: 8 lanes per point, two views each, three shuffle
-        // rounds (every wave spends the same few hundred cycles; a 16-step loop in two waves held the others at the barrier)
-        {
-            const int p = (int)(threadIdx.x >> 3), sub = (int)(threadIdx.x & 7);
-            const int nw = min(KM_CS_WAVES, (ktiles + KM_CS_CT - 1) / KM_CS_CT);
-            float mb = __builtin_inff(), ms = __builtin_inff();
-            int mi = 0;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int w = 2 * sub + u;
-                if (w < nw) {
-                    const float b = s_best[cur][w][p], sc = s_second[cur][w][p];
-                    const float nsec = fminf(fmaxf(mb, b), fminf(ms, sc));
-                    mi = b < mb ? s_idx[cur][w][p] : mi;
-                    mb = fminf(mb, b);
-                    ms = nsec;
-                }
-            }
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                const float b = __shfl_xor(mb, off), sc = __shfl_xor(ms, off);
-                const int bi = __shfl_xor(mi, off);
-                const float nsec = fminf(fmaxf(mb, b), fminf(ms, sc));
-                mi = (b < mb || (b == mb && bi < mi)) ? bi : mi;
-                mb = fminf(mb, b);
-                ms = nsec;
-            }
-            if (sub == 0 && p < rows) {
-                float nx2 = 0.0f;
-#pragma unroll
-                for (int q = 0; q < NS * 2; ++q) nx2 += s_part[cur][p][q];
-                const float nx = __builtin_sqrtf(nx2);
-                // (|x|^2 summed word by word instead of dimension by dimension: 1 ulp of slack on a bound with 2x margin)
-                const float E = 6.1035156e-5f * (nx * nc + nc2) + 3.8146973e-6f * nx2 * (1.0f + 1e-6f);
-                const bool sure = (ms - mb) > 2.0f * E;   // false for NaN / inf rows and exact ties
-                if (sure) labels[base + p] = mi;
-                else unc_list[atomicAdd(unc_count, 1u)] = (unsigned)(base + p);
-            }
-        }
-#endif
     }
 }

@@ -139,7 +139,10 @@ struct TopNet {
     static_assert((L & (L - 1)) == 0 && L >= 8, "list length must be a power of two");
     // candidates per block.  8, not 16 (round 3): the same ~13 network ops per candidate, half the padding in a lane's
     // last block, 16 fewer live VGPRs -> two more waves per SIMD; 4 costs more network ops than it saves
-    static constexpr int BS = L < 8 ? L : 8;
+#ifndef GSX_NET_BS
+#define GSX_NET_BS 8
+#endif
+    static constexpr int BS = L < GSX_NET_BS ? L : GSX_NET_BS;
     double a[L];  // ascending, +inf padded
 
     __device__ __forceinline__ void init()

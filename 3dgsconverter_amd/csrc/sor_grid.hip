@@ -777,8 +777,18 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // four gathers in flight then need ~95 VGPRs and five waves per SIMD are resident for k <= 16 (three for k <= 32).  The
 // kernel is bound by latency as much as by issue: 3 -> 5 waves took knn_brick from 1.92 to 1.68 ms at 10M splats, the
 // setup code's spills (outside the loops) notwithstanding; six waves push spills into the loops (2.39 ms).
-constexpr int NET_WAVES9 = 5, NET_WAVES17 = 5, NET_WAVES33 = 3;
-constexpr int NET_HB = 4;   // candidate gathers in flight per lane (8: no change)
+// (tuning builds override these constants with -D; tools/build_variants.sh)
+#ifndef GSX_NET_WAVES17
+#define GSX_NET_WAVES17 5
+#endif
+#ifndef GSX_NET_WAVES33
+#define GSX_NET_WAVES33 3
+#endif
+#ifndef GSX_NET_HB
+#define GSX_NET_HB 4
+#endif
+constexpr int NET_WAVES9 = 5, NET_WAVES17 = GSX_NET_WAVES17, NET_WAVES33 = GSX_NET_WAVES33;
+constexpr int NET_HB = GSX_NET_HB;   // candidate gathers in flight per lane (8: no change)
 constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)

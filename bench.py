@@ -120,8 +120,8 @@ def sor_roofline(n, k, knn_ms, algo=0, n_total=None, single=True):
         trans = pmc.get("valu_trans_f64_insts", 0)
         if f64 is not None:
             cycles = CYC_F64 * f64 + CYC_TRANS_F64 * trans + CYC_F32 * (pmc["valu_insts"] - f64 - trans)
-            mix = "measured split: %d float64-class + %d f64 transcendental + %d other wave-instructions" % (
-                f64, trans, pmc["valu_insts"] - f64 - trans)
+            mix = ("%d float64-rate (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 as counted + v_min/max_f64 and v_cvt_f64_f32 derived from them, "
+                   "profiles/pmc_latest.json) + %d f64 transcendental + %d other wave-instructions" % (f64, trans, pmc["valu_insts"] - f64 - trans))
         else:
             cycles = CYC_F32 * pmc["valu_insts"]
             mix = "no f32/f64 split committed for this build: every instruction priced at the f32 rate (a lower bound)"

@@ -60,6 +60,10 @@ def dropin(gsx, monkeypatch):
         c, l, _ = okm.lloyd(data, init, int(max_iter))
         return c, l
 
+    def kmeans_lloyd_many(problems, max_iter, lanes=8, device=0):
+        # the palette's chunks on concurrent contexts: same per-chunk entry point (gsx_kmeans_lloyd_dev), same results
+        return [kmeans_lloyd(d, i, max_iter) for d, i in problems]
+
     def quantize(vals, cb):
         hits.append(("gsx_quantize_sorted_codebook", len(vals), len(cb)))
         return okm.quantize_to_codebook(np.asarray(vals, np.float32), np.asarray(cb, np.float32))
@@ -183,7 +187,7 @@ def dropin(gsx, monkeypatch):
             pass
 
     for name, fn in (("morton_order", morton_order), ("cply_pack", cply_pack), ("Context", FakeCtx), ("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
-                     ("kmeans_lloyd", kmeans_lloyd), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
+                     ("kmeans_lloyd", kmeans_lloyd), ("kmeans_lloyd_many", kmeans_lloyd_many), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
                      ("lexsort3", lexsort3), ("sog_quats", sog_quats),
                      ("sog_positions", sog_positions), ("sog_alpha", sog_alpha), ("kmeans1d", kmeans1d),
                      ("rgb_from_sh", rgb_from_sh), ("require_hip", lambda: None)):

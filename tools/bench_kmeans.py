@@ -49,15 +49,19 @@ def main(args):
     steps = args.steps if args.steps != 30 else 5
     warmup = min(args.warmup, 2)
 
-    # synthetic SH rows of this rank's chunks (f_rest ~ N(0, 0.1^2)), generated on the device
-    g = torch.Generator(device=dev)
+    # synthetic SH rows (f_rest ~ N(0, 0.1^2) f32 from numpy's seed-0 generator, initial centroids
+    # drawn like the reference's front door: np.random.seed(0), one np.random.choice per chunk, gpu_ops.py:182) -- the same
+    # stream as bench.py's config4, walked by every rank so that a chunk's data does not depend on the number of GPUs
+    rng = np.random.default_rng(0)
+    np.random.seed(0)
     chunks, inits = [], []
-    for i in mine:
+    for i in range(nch):
         rows = min(cs, n_scene - i * cs)
-        g.manual_seed(1000 + i)
-        x = torch.randn((rows, d), generator=g, device=dev, dtype=torch.float32) * 0.1
-        chunks.append(x)
-        inits.append(x[torch.randperm(rows, generator=g, device=dev)[:k]].contiguous())
+        x = rng.standard_normal((rows, d), dtype=np.float32) * np.float32(0.1)
+        pick = np.random.choice(rows, k, replace=False)
+        if i in mine:
+            chunks.append(torch.from_numpy(x).to(dev))
+            inits.append(torch.from_numpy(np.ascontiguousarray(x[pick])).to(dev))
     cents = [t.clone() for t in inits]
     labels = [torch.empty(c.shape[0], dtype=torch.int32, device=dev) for c in chunks]
     torch.cuda.synchronize()

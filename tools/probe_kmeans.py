@@ -1,0 +1,14 @@
+"""GPU box: BASELINE.json configs[4] (bench.py:run_kmeans) alone on ONE lane, for `rocprofv3 --kernel-trace --stats`
+(the per-kernel averages of a Lloyd iteration; concurrent lanes only change how the kernels overlap)."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+gsx = importlib.import_module("3dgsconverter_amd")
+L = gsx._lib
+r = bench.run_kmeans(L, L.Context(0), gsx, 10_000_000, 2, 1, cpu=False, lanes=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+print(r["ms_per_step"], r["kernel_ms_per_step"])

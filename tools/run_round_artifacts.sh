@@ -3,29 +3,31 @@
 # commands, PMC passes (separate passes: TCC FETCH / WRITE, SQ issue counters).  usage: run_round_artifacts.sh r02
 set -u
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 timeout 900 python bench.py > $OUT/bench_${R}_10m.json 2> $OUT/bench_${R}.err
 timeout 600 python bench.py --exchange slab --steps 20 --no-cpu-baseline > $OUT/bench_${R}_slab_1rank.json 2>> $OUT/bench_${R}.err
-timeout 900 python bench.py --workload kmeans > $OUT/bench_${R}_kmeans.json 2>> $OUT/bench_${R}.err
 timeout 600 python bench.py --n 50000000 --extent 10 --k 32 --steps 10 --no-cpu-baseline --no-secondary > $OUT/bench_${R}_50m_k32.json 2>> $OUT/bench_${R}.err
 cd /tmp
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R} -o trace -- python $ROOT/bench.py $B > $OUT/prof_${R}.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_km -o trace -- python $ROOT/bench.py --workload kmeans --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_${R}_km.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_km -o trace -- python $ROOT/tools/probe_kmeans.py > $OUT/prof_${R}_km.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_slab -o trace -- python $ROOT/bench.py --exchange slab $B > $OUT/prof_${R}_slab.log 2>&1
 P="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc_sq1_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/pmc_sq2_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+# the float64 / float32 split of the VALU stream (bench.py prices the issue cycles with it)
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 -d $OUT/pmc_sq3_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 -d $OUT/pmc_sq4_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 cd $ROOT
 for T in "" _km _slab; do python tools/rocpd_summary.py $OUT/prof_${R}${T}/trace_results.db > $OUT/kernel_stats_${R}${T}.txt 2>&1; done
 python tools/rocpd_summary.py --pmc $OUT/pmc_fetch_${R}/pmc_results.db $OUT/pmc_write_${R}/pmc_results.db > $OUT/pmc_${R}_tcc.txt 2>&1
-python tools/rocpd_summary.py --pmc $OUT/pmc_sq1_${R}/pmc_results.db $OUT/pmc_sq2_${R}/pmc_results.db $OUT/pmc_grbm_${R}/pmc_results.db > $OUT/pmc_${R}_sq.txt 2>&1
-cut -c1-400 $OUT/bench_${R}_10m.json; echo; cut -c1-300 $OUT/bench_${R}_kmeans.json; echo
+python tools/rocpd_summary.py --pmc $OUT/pmc_sq1_${R}/pmc_results.db $OUT/pmc_sq2_${R}/pmc_results.db $OUT/pmc_sq3_${R}/pmc_results.db $OUT/pmc_sq4_${R}/pmc_results.db $OUT/pmc_grbm_${R}/pmc_results.db > $OUT/pmc_${R}_sq.txt 2>&1
+cut -c1-400 $OUT/bench_${R}_10m.json; echo
 head -8 $OUT/kernel_stats_${R}.txt; grep -E "knn_brick" $OUT/pmc_${R}_tcc.txt $OUT/pmc_${R}_sq.txt | cut -c1-170
