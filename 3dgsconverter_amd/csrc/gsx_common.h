@@ -74,12 +74,13 @@ struct KnnWs {
     DevBuf subkth;      // double[n_sub] (k+1)-th squared distance computed at the next level
     DevBuf heavylist;   // u32[q_count] sorted indices of the knn_ring queries handed to knn_heavy
     DevBuf heavypart;   // double[batch * chunks * KCAP] per-chunk partial top lists
+    DevBuf probe;       // u32[G^3 + 32]: density probe of a sub-cloud (counts of a coarse grid, point-weighted histogram of them)
     uint64_t refined_total = 0;  // host-side: points gathered into sub-clouds by the current call
     void release_all()
     {
         DevBuf *all[] = {&packed, &qsorted, &bucketpts, &bkcnt, &cellstart, &qcellstart, &gridparams, &bboxpart,
                          &faillist, &extraitems, &deferred, &cellflag, &subxyz, &submap, &submean, &subkth,
-                         &heavylist, &heavypart};
+                         &heavylist, &heavypart, &probe};
         for (auto b : all) b->release();
     }
 };

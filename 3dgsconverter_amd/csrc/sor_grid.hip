@@ -187,6 +187,7 @@ struct GridParamArgs {   // what grid_params needs besides the partial boxes
     float parent_h;
     GridParams *gp;
     unsigned *devflags;
+    double h_hint;   // > 0: cell edge suggested by the density probe of the parent level (never above the bbox-volume edge)
 };
 __device__ void grid_params_body(const float *part, int nparts, const GridParamArgs &a);
 
@@ -292,6 +293,7 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
     } else {
         double per = vol * pts_per_cell / (double)(n > 0 ? n : 1);
         h = nd == 3 ? cbrt(per) : (nd == 2 ? sqrt(per) : per);
+        if (a.h_hint > 0.0 && a.h_hint < h) h = a.h_hint;   // any edge is valid (exactness does not depend on it): section 5.5
         double hmin = emax / (double)(MAX_DIM - 1);
         if (!(h > hmin)) h = hmin;
     }
@@ -1922,6 +1924,58 @@ __global__ __launch_bounds__(256) void gather_sub_kernel(GridParams *__restrict_
     }
 }
 
+// Density probe of a gathered sub-cloud (round 3).  The finer level used to size its cells from the sub-cloud's bounding-box
+// VOLUME; a Gaussian blob's core is ~30x denser than its box average, so every level only peeled a shell (3-4 levels per
+// blob).  Here: counts of a coarse G^3 grid over the box of the group's queries, then the point-weighted histogram of
+// log2(count) -- the host reads 32 numbers and sizes the cells for the density that 85 % of the points do not exceed,
+// divided by the factor a brick may be over-full before it is deferred again.  Affects speed only: any cell edge is exact.
+struct ProbeBox {
+    float lo[3], inv[3];   // bin = (int)((p - lo) * inv), inv = G / extent
+    int g;
+};
+__global__ __launch_bounds__(256) void probe_count_kernel(const float *__restrict__ sub, int n_stride, const unsigned *__restrict__ n_sub_p,
+                                                          ProbeBox pb, unsigned *__restrict__ counts)
+{
+    const int n_sub = (int)*n_sub_p;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_sub; i += gridDim.x * 256) {
+        const float p[3] = {sub[i], sub[(size_t)n_stride + i], sub[2 * (size_t)n_stride + i]};
+        int b[3];
+        bool in = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = (p[a] - pb.lo[a]) * pb.inv[a];
+            in = in && t >= 0.0f && t < (float)pb.g + 1.0f;
+            b[a] = min(pb.g - 1, max(0, (int)t));
+        }
+        if (in) atomicAdd(&counts[(b[2] * pb.g + b[1]) * pb.g + b[0]], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void probe_hist_kernel(const float *__restrict__ sub, int n_stride, const unsigned *__restrict__ n_sub_p,
+                                                         ProbeBox pb, const unsigned *__restrict__ counts, unsigned *__restrict__ hist32)
+{
+    __shared__ unsigned s_h[32];
+    if (threadIdx.x < 32) s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int n_sub = (int)*n_sub_p;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_sub; i += gridDim.x * 256) {
+        const float p[3] = {sub[i], sub[(size_t)n_stride + i], sub[2 * (size_t)n_stride + i]};
+        int b[3];
+        bool in = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = (p[a] - pb.lo[a]) * pb.inv[a];
+            in = in && t >= 0.0f && t < (float)pb.g + 1.0f;
+            b[a] = min(pb.g - 1, max(0, (int)t));
+        }
+        if (in) {
+            const unsigned c = counts[(b[2] * pb.g + b[1]) * pb.g + b[0]];
+            atomicAdd(&s_h[31 - __builtin_clz(c | 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && s_h[threadIdx.x]) atomicAdd(&hist32[threadIdx.x], s_h[threadIdx.x]);
+}
+
 // A finer-level result is the exact answer iff its (k+1)-th neighbour lies inside the region this
 // level guarantees to have gathered: every point outside the brick's neighbourhood is farther than
 // the distance to the nearest neighbourhood face that has cells behind it (same bound and margins
@@ -2387,14 +2441,18 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
 static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *y, const float *z, int64_t stride,
                           int64_t n_ref, int64_t q_begin, int64_t q_count, int k, float *mean_out, double *kth_out,
                           gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h,
-                          int64_t ref_only_from = INT32_MAX)
+                          int64_t ref_only_from = INT32_MAX, double h_hint = 0.0)
 {
     KnnWs &w = ctx->ws[level];
     w.refined_total = 0;
     const int kk = k + 1;
     const bool anyk = kk > 65;   // k > 64: the list-free exact path (knn_anyk_kernel) instead of knn_brick + ring kernels
     if (kk > ANYK_MAX) GSX_FAIL("sor: k=%d not supported (k must be <= %d)", k, ANYK_MAX - 1);
-    const int64_t cap = grid_cell_cap(n_ref);
+    // cells the grid may have.  Level 0: about one cell per two points (more would be empty cells to walk).  A refinement
+    // level sized by the density probe covers a box that is mostly EMPTY by construction (a blob's tails, the few floaters
+    // around a scene), so it gets room for 4 cells per point, within what the two-level sort can address.
+    const int64_t cap = h_hint > 0.0 ? std::min<int64_t>(std::max<int64_t>(4 * n_ref, 64), (int64_t)MAX_BUCKETS * MAX_BUCKET_CELLS - 64) + 64
+                                     : grid_cell_cap(n_ref);
     // slab mode (multi-GPU): every point is binned once, the halo [ref_only_from, n_ref) is flagged reference-only
     const bool slab = ref_only_from < n_ref;
     if (anyk && (nshares > 1 || slab)) GSX_FAIL("sor: k=%d > 64 is served by the single-GPU path only", k);
@@ -2447,7 +2505,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
     GridParamArgs gpa{(int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0, parent_h, gp,
-                      ctx->devflags.as<unsigned>()};
+                      ctx->devflags.as<unsigned>(), h_hint};
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
     GSX_HIP(hipGetLastError());
@@ -2586,6 +2644,10 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             // the finer level's answers are accepted only up to M: M = 4 x the cell edge the finer grid
             // will get, i.e. ~5x its typical (k+1)-th neighbour distance.
             ClipBox clip{};
+            unsigned hq_sub_queries = 0;
+            int hq_nd3 = 0;
+            double h_est = 0.0;   // cell edge the finer level would get from the box volume of the group's queries
+            float hq_lo[3] = {0, 0, 0}, hq_hi[3] = {0, 0, 0};
             {
                 GridParams hq;
                 GSX_HIP(hipMemcpyAsync(&hq, gp, sizeof(GridParams), hipMemcpyDeviceToHost, ctx->stream));
@@ -2597,8 +2659,14 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                     if (e > 0.0) { vol *= e; ++nd3; }
                     amax = std::max({amax, std::fabs((double)hq.qb_lo[ax]), std::fabs((double)hq.qb_hi[ax])});
                 }
+                hq_sub_queries = hq.sub_queries;
+                hq_nd3 = nd3;
+                for (int ax = 0; ax < 3; ++ax) {
+                    hq_lo[ax] = hq.qb_lo[ax];
+                    hq_hi[ax] = hq.qb_hi[ax];
+                }
                 const double per = hq.sub_queries > 0 ? vol * pts_per_cell / (double)hq.sub_queries : 0.0;
-                const double h_est = nd3 == 3 ? std::cbrt(per) : (nd3 == 2 ? std::sqrt(per) : (nd3 == 1 ? per : 0.0));
+                h_est = nd3 == 3 ? std::cbrt(per) : (nd3 == 2 ? std::sqrt(per) : (nd3 == 1 ? per : 0.0));
                 const double M = std::max(4.0 * h_est, 0.01 * (double)hgp.h);
                 const double cert = M * (1.0 - 1e-3) - 4e-7 * amax;  // f32 rounding of lo - M / hi + M
                 if (ctx->adaptive == 1 && hq.sub_queries > 0 && M < 2.0 * (double)hgp.h && cert > 0.0) {
@@ -2616,16 +2684,73 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             hipLaunchKernelGGL(gather_sub_kernel, dim3(div_up(n_ref, GATHER_CHUNK)), dim3(256), 0, ctx->stream, gp, refs, (int)n_ref,
                                flag, clip, sub, sub_orig, sub_sorted);
             GSX_HIP(hipGetLastError());
+            // density probe of the gathered points (see probe_count_kernel): rides on the synchronisation that reads n_sub
+            ProbeBox pb{};
+            double bin_vol = 0.0;
+            unsigned hist_h[32] = {0};
+            unsigned *probe_hist = nullptr;
+            if (ctx->adaptive == 1 && hq_sub_queries > 0 && hq_nd3 == 3) {
+                int G = (int)std::lround(std::cbrt((double)hq_sub_queries / 32.0));
+                G = std::max(8, std::min(64, G));
+                GSX_CHECK(w.probe.reserve(sizeof(unsigned) * ((size_t)G * G * G + 32)));
+                unsigned *counts = w.probe.as<unsigned>();
+                probe_hist = counts + (size_t)G * G * G;
+                GSX_HIP(hipMemsetAsync(counts, 0, sizeof(unsigned) * ((size_t)G * G * G + 32), ctx->stream));
+                pb.g = G;
+                bin_vol = 1.0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double e = (double)hq_hi[ax] - (double)hq_lo[ax];
+                    pb.lo[ax] = hq_lo[ax];
+                    pb.inv[ax] = (float)((double)G / e);
+                    bin_vol *= e / (double)G;
+                }
+                const int pblocks = std::min(div_up(n_ref, 1024), ctx->num_cu * 4);
+                hipLaunchKernelGGL(probe_count_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, sub, (int)n_ref, &gp->sub_count, pb, counts);
+                hipLaunchKernelGGL(probe_hist_kernel, dim3(pblocks), dim3(256), 0, ctx->stream, sub, (int)n_ref, &gp->sub_count, pb, counts,
+                                   probe_hist);
+                GSX_HIP(hipGetLastError());
+                GSX_HIP(hipMemcpyAsync(hist_h, probe_hist, sizeof(hist_h), hipMemcpyDeviceToHost, ctx->stream));
+            }
             unsigned n_sub = 0;
             GSX_HIP(hipMemcpyAsync(&n_sub, &gp->sub_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
             GSX_HIP(hipStreamSynchronize(ctx->stream));
             GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
-            if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level %d: sub-cloud %u points\n", level, n_sub);
+            double h_hint_sub = 0.0;
+            constexpr double probe_q = 0.85, probe_shrink = 0.7;   // measured: tools/run_r03_k.sh (quantile 0.5 .. 0.85)
+            if (probe_hist) {
+                unsigned long long tot = 0, run = 0;
+                for (int b = 0; b < 32; ++b) tot += hist_h[b];
+                int bq = -1;
+                for (int b = 0; b < 32 && tot; ++b) {
+                    run += hist_h[b];
+                    if ((double)run >= probe_q * (double)tot) {
+                        bq = b;
+                        break;
+                    }
+                }
+                if (bq >= 0 && bin_vol > 0.0) {
+                    // 85 % of the points sit in probe bins of at most ~1.5 * 2^bq points: cells sized for THAT density are
+                    // over-full only for the densest 15 % (a Gaussian's core is 1.4x denser than its 85 % level: no second
+                    // refinement), under-full for the tails, whose queries go to the ring kernels
+                    const double rho = 1.5 * std::ldexp(1.0, bq) / bin_vol;
+                    h_hint_sub = std::cbrt(pts_per_cell / rho);
+                    // a grid of that edge over the group's box must fit the cell budget, otherwise the edge would be stretched
+                    // to something in between and every brick of a uniform region would be over-full: keep the old sizing then
+                    double cells = 1.0;
+                    for (int ax = 0; ax < 3; ++ax) cells *= std::floor(((double)hq_hi[ax] - (double)hq_lo[ax] + 2.0 * (double)clip.r_cert) / h_hint_sub) + 1.0;
+                    const double budget = (double)std::min<int64_t>(4 * (int64_t)n_sub, (int64_t)MAX_BUCKETS * MAX_BUCKET_CELLS - 64);
+                    if (!(cells <= 0.8 * budget)) h_hint_sub = 0.0;
+                    // a near-uniform group (the probed edge within 30 % of the box-volume edge) keeps the box-volume edge: the
+                    // population per cell is tuned to a few per cent there (0.92x the edge = 13x the ring queries, measured)
+                    if (h_hint_sub > probe_shrink * h_est) h_hint_sub = 0.0;
+                }
+            }
+            if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level %d: sub-cloud %u points, probed cell edge %g\n", level, n_sub, h_hint_sub);
             if (n_sub == 0) GSX_FAIL("sor: refinement gathered no points for %u deferred bricks", g_count);
             GSX_CHECK(w.submean.reserve(sizeof(float) * (size_t)n_sub));
             GSX_CHECK(w.subkth.reserve(sizeof(double) * (size_t)n_sub));
             GSX_CHECK(knn_grid_level(ctx, level + 1, sub, sub + n_ref, sub + 2 * n_ref, 1, (int64_t)n_sub, 0, (int64_t)n_sub, k,
-                                     w.submean.as<float>(), w.subkth.as<double>(), nullptr, 0, 1, true, hgp.h));
+                                     w.submean.as<float>(), w.subkth.as<double>(), nullptr, 0, 1, true, hgp.h, INT32_MAX, h_hint_sub));
             hipLaunchKernelGGL(merge_sub_kernel, dim3(div_up((int64_t)n_sub, 256)), dim3(256), 0, ctx->stream, gp, sub, (int)n_ref,
                                sub_orig, sub_sorted, w.submean.as<float>(), w.subkth.as<double>(), (int)q_begin, clip.r_cert,
                                mean_out, kth_out, a.faillist);

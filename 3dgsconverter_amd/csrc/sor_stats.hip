@@ -11,11 +11,9 @@
 //     accumulators, recursive split at n/2 rounded down to a multiple of 8;
 //   * mean = (float)((double)sum / n); var likewise from sum((x-mean)^2); std = sqrtf;
 //   * threshold = mean + (float)factor * std in f32.
-// One 128-lane workgroup sums one 8192-element piece: two lanes own each 128-element leaf (4 of
-// numpy's 8 accumulators each, 16-byte loads), the 64 leaf sums combine in the balanced tree the
-// recursion produces for 8192.  The ragged last
-// piece is split into its (irregular) leaves by lane 0 and combined by the same recursion.
-// HBM-bound and tiny: 4 B/splat per pass, 3 passes.
+// One 128-lane workgroup sums one 8192-element piece: two lanes own each 128-element leaf (4 of numpy's 8 accumulators
+// each, 16-byte loads), the 64 leaf sums combine in the balanced tree the recursion produces for 8192.  The ragged last piece is split into its (irregular) leaves by lane 0
+// and combined by the same recursion.  HBM-bound and tiny: 4 B/splat per pass, 3 passes.
 #include "gsx_common.h"
 
 namespace gsx {
@@ -75,37 +73,52 @@ __device__ __forceinline__ float replay_tree(int n, const float *lv, int &li)
 }
 
 // mode 0: stats[0] = mean.  mode 1: stats[1] = std, stats[2] = threshold.
-// One wave: numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial; the
-// wave loads 64 piece sums per step (coalesced) and folds them in order through v_readlane.
+// numpy adds the per-piece sums SEQUENTIALLY, so the chain is inherently serial: the calling workgroup (every thread of it
+// must call) stages 1024 piece sums at a time in LDS with coalesced loads, thread 0 adds them in order from there (one
+// ds_read_b128 per four dependent adds; round 2 pulled every value through v_readlane: ~15 cycles per piece sum, 20 us at 10M
+// splats -- as long as the piece sums themselves took).
+constexpr int FOLD_TILE = 1024;
 __device__ __forceinline__ void stats_finalize_body(const float *__restrict__ chunk_sum, int64_t n, int64_t nchunks, int mode,
                                                     float factor, float *__restrict__ stats)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float s_fold[FOLD_TILE];
     float acc = 0.0f;
-    // eight 64-piece groups are requested back to back (device-scope loads stay in program order) before the serial
-    // chain starts: 3 round trips at 10M splats instead of 20
-    for (int64_t base0 = 0; base0 < nchunks; base0 += 64 * 8) {
-        float vv[8];
+    for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
+        const int m = (int)((nchunks - base) < FOLD_TILE ? (nchunks - base) : FOLD_TILE);
+        __syncthreads();
+        // (written by other workgroups: device-scope loads)
+        {
+            float t[FOLD_TILE / 64];   // every load of the tile requested before the first is stored (blockDim >= 64)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t i = base0 + 64 * u + lane;
-            vv[u] = i < nchunks ? __hip_atomic_load(&chunk_sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-        }
+            for (int u = 0; u < FOLD_TILE / 64; ++u) {
+                const int i = (int)threadIdx.x + u * (int)blockDim.x;
+                t[u] = i < m ? __hip_atomic_load(&chunk_sum[base + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t base = base0 + 64 * u;
-            if (base >= nchunks) break;
-            const int m = (int)((nchunks - base) < 64 ? (nchunks - base) : 64);
-            const float v = vv[u];
-            if (m == 64) {
-#pragma unroll
-                for (int j = 0; j < 64; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-            } else {
-                for (int j = 0; j < m; ++j) acc += __shfl(v, j);
+            for (int u = 0; u < FOLD_TILE / 64; ++u) {
+                const int i = (int)threadIdx.x + u * (int)blockDim.x;
+                if (i < m) s_fold[i] = t[u];
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int i = 0;
+            for (; i + 64 <= m; i += 64) {   // 16 LDS reads in flight, then 64 dependent adds
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4 *>(&s_fold[i + 4 * u]);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    acc += v[u].x;
+                    acc += v[u].y;
+                    acc += v[u].z;
+                    acc += v[u].w;
+                }
+            }
+            for (; i < m; ++i) acc += s_fold[i];
+        }
     }
-    if (lane != 0) return;
+    if (threadIdx.x != 0) return;
     const float q = (float)((double)acc / (double)n);  // f32 sum / np.intp count: float64 divide, cast back
     if (mode == 0) {
         stats[0] = q;
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) *fold.ticket = 0;
-    if (threadIdx.x < 64) stats_finalize_body(chunk_sum, n, (int64_t)gridDim.x, SQ ? 1 : 0, fold.factor, fold.stats_out);
+    stats_finalize_body(chunk_sum, n, (int64_t)gridDim.x, SQ ? 1 : 0, fold.factor, fold.stats_out);
 }
 
 template <bool SQ>
@@ -168,7 +181,9 @@ __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int6
 
     if (len == NP_BUF) {  // block-uniform
         // 64 leaves of 128 elements; two lanes per leaf: lane (leaf, hh) owns accumulators 4hh..4hh+3
-        // (numpy's r[0..7]) and walks the leaf's 16 rows with one 16-byte load per row.
+        // (numpy's r[0..7]) and walks the leaf's 16 rows with one 16-byte load per row.  (Round 3 tried parking the piece
+        // in LDS first with fully coalesced loads: 34 KB per workgroup cost more occupancy than the coalescing returned --
+        // stats 0.099 -> 0.110 ms per 10M-splat step.)
         const int leaf = threadIdx.x >> 1, hh = threadIdx.x & 1;
         const float4 *q = reinterpret_cast<const float4 *>(p + leaf * 128 + hh * 4);
         float4 v = q[0];
