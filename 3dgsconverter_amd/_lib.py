@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSX_LIB_PATH: an experiment build of build.py (GSX_EXTRA_FLAGS -> 3dgsconverter_amd/variants/), for A/B runs only
 LIB_PATH = os.environ.get("GSX_LIB_PATH") or os.path.join(_HERE, "libgsx_hip.so")
 
-KNN_AUTO, KNN_BRUTE, KNN_GRID = 0, 1, 2
+KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_TREE = 0, 1, 2, 3
 T_SOR_KNN, T_SOR_BIN, T_SOR_FALLBACK, T_SOR_STATS, T_DENSITY, T_KMEANS_ASSIGN, T_KMEANS_UPDATE, T_QUANTIZE = range(8)
 
 

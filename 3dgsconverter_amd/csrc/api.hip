@@ -81,6 +81,9 @@ static int timing_resolve(gsx_ctx *ctx, int slot)
 int launch_pack_points(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, float4 *);  // flags non-finite input in ctx->devflags
 int launch_knn_brute(gsx_ctx *, const float4 *, int64_t, int64_t, int64_t, const unsigned *, const unsigned *,
                      int64_t, int, float *);
+int knn_tree_info(gsx_ctx *, gsx_sor_info *);
+int launch_knn_tree(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int, float *, double *,
+                    gsx_sor_info *, int64_t);
 int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int,
                     float *, gsx_sor_info *, int share = 0, int nshares = 1);
 int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
@@ -165,6 +168,7 @@ void gsx_ctx_destroy(gsx_ctx *c)
     for (auto &s : c->slots)
         for (auto e : s.ev) (void)hipEventDestroy(e);
     for (auto &w : c->ws) w.release_all();
+    c->tree_ws.release_all();
     gsx::DevBuf *bufs[] = {&c->devflags, &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
     if (c->owned_stream) (void)hipStreamDestroy(c->owned_stream);
@@ -250,6 +254,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->timing_mask = (unsigned)value;
     } else if (!strcmp(name, "adaptive")) {
         c->adaptive = (int)value;
+    } else if (!strcmp(name, "tree")) {
+        c->tree = (int)value;
     } else if (!strcmp(name, "defer_words")) {
         c->defer_words = (int)value;
     } else if (!strcmp(name, "filter_mfma")) {
@@ -319,7 +325,10 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
         }
         return 0;
     }
+    // adaptive mode (clouds a uniform grid cannot resolve): the Morton-tree path unless the level-by-level grid is asked for
+    if (algo == GSX_KNN_GRID && c->adaptive && c->tree && k <= 64 && n_ref > k) algo = GSX_KNN_TREE;
     if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, info);
+    if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, INT32_MAX);
     GSX_FAIL("gsx_sor_knn_dev: unknown algo %d", algo);
 }
 
@@ -429,7 +438,8 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     if (mean_out) GSX_HIP(hipMemcpyAsync(mean_out, dmd, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
     GSX_CHECK(gsx_ctx_check(c));  // synchronises; non-finite coordinates (either algorithm) are an error, like cKDTree's
-    const int used = k > 64 ? GSX_KNN_GRID : (algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo);
+    int used = k > 64 ? GSX_KNN_GRID : (algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo);
+    if (used == GSX_KNN_GRID && c->adaptive && c->tree && k <= 64 && n > k) used = GSX_KNN_TREE;   // as gsx_sor_knn_dev routes it
     if (info) {
         // re-query diagnostics without recomputing: only the grid path has device-side counters
         memset(info, 0, sizeof(*info));
@@ -446,6 +456,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
             info->n_deferred_bricks = hgp.deferred_count;
             info->n_refined = (int64_t)c->ws[0].refined_total;
         }
+        if (used == GSX_KNN_TREE) GSX_CHECK(knn_tree_info(c, info));
     }
     return 0;
 }

@@ -85,6 +85,28 @@ struct KnnWs {
     }
 };
 
+// Buffers of the Morton-tree KNN (sor_tree.hip)
+struct TreeWs {
+    DevBuf keys[2];     // u64[n]: Morton keys (unsorted | sorted)
+    DevBuf vals[2];     // u32[n]: original indices (identity | key order)
+    DevBuf refs;        // float4[n] points in key order
+    DevBuf flags;       // u8[n]: leaf bit level | 0x80 on a leaf's first point
+    DevBuf tilecnt, tileoff;   // u32[tiles]: leaves starting in a tile, exclusive scan
+    DevBuf leafstart;   // u32[leaves + 1]
+    DevBuf leafbl;      // u8[leaves]
+    DevBuf faillist;    // u32[n] sorted indices of the queries knn_leaf could not certify
+    DevBuf failbound;   // double[n]: their k-th distance bound (>= 0) or minus the squared radius to start with
+    DevBuf bboxpart;    // float[7 * blocks]
+    DevBuf params;      // TreeParams
+    DevBuf temp;        // rocprim temporary storage
+    void release_all()
+    {
+        DevBuf *all[] = {&keys[0], &keys[1], &vals[0], &vals[1], &refs, &flags, &tilecnt, &tileoff, &leafstart, &leafbl,
+                         &faillist, &failbound, &bboxpart, &params, &temp};
+        for (auto b : all) b->release();
+    }
+};
+
 struct TimingSlot {
     std::vector<hipEvent_t> ev;  // pairs: start, stop
     size_t used = 0;
@@ -110,6 +132,7 @@ struct gsx_ctx {
     int debug_skip = 0;  // profiling ablations of knn_brick (never set by the product path)
     int adaptive = 0;    // 1: bricks too populated for the grid are re-run on a finer grid (one host sync per call)
     int defer_words = 64;
+    int tree = 1;        // adaptive mode: 1 = the Morton-tree path (sor_tree.hip, no host round trips), 0 = level-by-level grid refinement
     int kmeans_mfma = 1;  // K-Means assign for D in {9,24,45}, K >= 64: 1 = matrix-core filter + exact certificate, 0 = packed-f32 VALU scan
     int kmeans_cs = 1;   // centroid-stationary matrix-core assign for K <= 1024 (0: the streaming kernel; A/B)
     int ring_fast = 1;   // knn_ring_fast before knn_ring (0: A/B only)
@@ -118,6 +141,7 @@ struct gsx_ctx {
 
     // SOR workspace: one KnnWs per refinement level of the KNN grid (level 0 = the whole cloud)
     gsx::KnnWs ws[gsx::KNN_MAX_LEVELS];
+    gsx::TreeWs tree_ws;     // Morton-tree KNN workspace
     gsx::DevBuf devflags;    // u32[16]: device-side error word (bit 0: non-finite coordinates), read by gsx_ctx_check
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging

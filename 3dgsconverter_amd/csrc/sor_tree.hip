@@ -1,0 +1,1005 @@
+// sor_tree.hip -- EXACT k-nearest-neighbour mean distance on a Morton-ordered cloud: the path for clouds whose density varies
+// by orders of magnitude (Gaussian blobs, a dense scene inside a box inflated by far floaters), which one uniform grid
+// cannot resolve and which sor_grid.hip's level-by-level refinement serves with a host round trip per level.
+//
+// Replaces the same reference code as sor_grid.hip (data_processor.py:160-173: cKDTree build + query(k+1) + row mean; the
+// approximate Taichi kernel gpu_ops.py:98-176) with the same bits in the output; it is the device-side counterpart of
+// what cKDTree is for the reference: a space partition that follows the data.  No host synchronisation anywhere.
+//
+//   tree_bbox            bounding box -> origin, fine cell edge s = extent / 2^21                      (one pass)
+//   tree_keys            63-bit Morton key of every point's fine cell                                  (one pass)
+//   rocprim radix sort   (key, index) pairs
+//   tree_gather          float4 {x, y, z, index} in key order
+//   tree_leaf_flags / tree_leaf_compact
+//                        LEAVES: the largest nodes of the implicit binary radix tree (a node = all keys sharing the bits
+//                        above bit level b: a box with sides 1:1:1, 2:1:1 or 2:2:1) that hold at most 64 points.  Found
+//                        without building a tree: node(i, b) holds more than 64 points iff keys j and j+64 agree above b
+//                        for some j in [i-64, i], so the smallest such b is a sliding-window minimum over the sorted keys.
+//   knn_leaf             one WAVE per leaf: its <= 64 points are the queries (one per lane, contiguous in memory); the
+//                        candidates are the points of the leaf's box grown by one CELL on every side, a cell being the cube
+//                        of half the leaf's longest side: at most 4x4x4 cells, each a contiguous key range found by one
+//                        lane's binary search.  From there on it is knn_brick (sor_grid.hip): bf16-split MFMA filter
+//                        (phase 1), per-lane walk of the mask words with exact float64 distances and sorting-network
+//                        selection (phase 2), numpy's summation order in the epilogue.  A query is exact iff its k-th
+//                        neighbour is nearer than the nearest face of the searched box that has space behind it.
+//   knn_tree_query       the queries knn_leaf could not certify (sparse leaves next to dense ones, the rim of the cloud):
+//                        one wave per query, nearest-first descent of the implicit octree below the smallest node that
+//                        contains the query's ball, pruned by the running k-th distance; the list lives one entry per lane.
+//
+// Exactness of the geometry: a point's fine cell is floor((x - o) * inv_s) evaluated in float64 -- monotone in x -- so all
+// points of cells >= c along an axis lie at x >= o + c*s up to ~1e-15 relative; every plane distance used as a guarantee is
+// reduced by TreeParams::slack (1e-14 of the cloud's magnitude), far more than those roundings.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "gsx_common.h"
+#include "knn_common.h"
+#include "knn_mfma.h"
+#include "sor_grid_params.h"
+
+namespace gsx {
+
+constexpr int TB = 21;                 // key bits per axis
+constexpr int TREE_TOP = 3 * TB;       // bit level of the root (all 63 key bits free)
+constexpr int LEAF_CAP = 64;           // points per leaf = lanes of a wave
+constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
+constexpr int TWCAP = 28;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
+constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag kernels
+constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points hands its queries to knn_tree_query
+constexpr int TQ_STACK = 176;          // 21 levels x 7 siblings + the start node
+constexpr int TQ_SCAN = 256;           // a node with at most this many points is scanned, not split
+
+struct TreeParams {
+    double ox, oy, oz;     // origin = per-axis minimum
+    double s, inv_s;       // fine cell edge, 1/s
+    double slack;          // subtracted from every guaranteed plane distance
+    int n;
+    unsigned bad_input;    // non-finite coordinates: the kernels do nothing, knn_tree_query fills the output with NaN
+    unsigned nleaves;
+    unsigned fail_count;
+    unsigned ticket_bbox;  // self-resetting arrival ticket of tree_bbox_kernel
+    unsigned pad;
+    unsigned leaf_ctr[8 * 32];
+    unsigned fail_ctr[8 * 32];
+};
+
+__device__ __forceinline__ unsigned long long spread21(unsigned v)   // bit t -> bit 3t
+{
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffULL;
+    x = (x | x << 16) & 0x1f0000ff0000ffULL;
+    x = (x | x << 8) & 0x100f00f00f00f00fULL;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+    x = (x | x << 2) & 0x1249249249249249ULL;
+    return x;
+}
+__device__ __forceinline__ unsigned compact21(unsigned long long x)   // bit 3t -> bit t
+{
+    x &= 0x1249249249249249ULL;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
+    x = (x ^ (x >> 32)) & 0x1fffffULL;
+    return (unsigned)x;
+}
+__device__ __forceinline__ unsigned long long morton63(unsigned ix, unsigned iy, unsigned iz)
+{
+    return spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+}
+// fine cell of a coordinate (monotone in v; v >= o for every point of the cloud)
+__device__ __forceinline__ unsigned fine_cell(float v, double o, double inv_s)
+{
+    const double t = __dmul_rn(__dsub_rn((double)v, o), inv_s);
+    const int c = (int)t;
+    return (unsigned)min(max(c, 0), (1 << TB) - 1);
+}
+
+// ---------------------------------------------------------------- bounding box -> TreeParams
+__global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ z, int64_t stride, int n, float *__restrict__ part,
+                                                        TreeParams *__restrict__ tp, unsigned *__restrict__ devflags)
+{
+    __shared__ float red[7][4];
+    __shared__ unsigned s_last;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float bad = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v[3] = {x[(int64_t)i * stride], y[(int64_t)i * stride], z[(int64_t)i * stride]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], v[a]);
+            mx[a] = fmaxf(mx[a], v[a]);
+            bad = (fabsf(v[a]) < __builtin_inff()) ? bad : 1.0f;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad = fmaxf(bad, __shfl_xor(bad, off));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            red[a][w] = mn[a];
+            red[3 + a][w] = mx[a];
+        }
+        red[6][w] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        float v = red[threadIdx.x][0];
+        for (int i = 1; i < 4; ++i) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][i]) : fmaxf(v, red[threadIdx.x][i]);
+        __hip_atomic_store(&part[blockIdx.x * 7 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tp->ticket_bbox, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup to arrive folds the partial boxes (its first wave) and writes the parameters
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    float v[7] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
+                  -__builtin_inff()};
+    for (int i = lane; i < (int)gridDim.x; i += 64)
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            const float t = __hip_atomic_load(&part[i * 7 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[a] = a < 3 ? fminf(v[a], t) : fmaxf(v[a], t);
+        }
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v[a], off);
+            v[a] = a < 3 ? fminf(v[a], o) : fmaxf(v[a], o);
+        }
+    // zero the work counters of this call (every lane takes a few)
+    for (int i = lane; i < 8 * 32; i += 64) {
+        tp->leaf_ctr[i] = 0;
+        tp->fail_ctr[i] = 0;
+    }
+    if (lane != 0) return;
+    tp->ticket_bbox = 0;
+    const bool isbad = v[6] != 0.0f || n <= 0;
+    double emax = 0.0, mag = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        emax = fmax(emax, (double)v[3 + a] - (double)v[a]);
+        mag = fmax(mag, fmax(fabs((double)v[a]), fabs((double)v[3 + a])));
+    }
+    // 2^21 fine cells along the longest axis; the 2^-18 head room keeps the maximum inside the last cell
+    const double s = (emax > 0.0 && emax < 1e300) ? emax * (1.0 + 0x1p-18) * 0x1p-21 : 1.0;
+    tp->ox = isbad ? 0.0 : (double)v[0];
+    tp->oy = isbad ? 0.0 : (double)v[1];
+    tp->oz = isbad ? 0.0 : (double)v[2];
+    tp->s = s;
+    tp->inv_s = 1.0 / s;
+    tp->slack = 1e-14 * (mag + emax);
+    tp->n = n;
+    tp->bad_input = v[6] != 0.0f ? 1u : 0u;
+    tp->nleaves = 0;
+    tp->fail_count = 0;
+    if (v[6] != 0.0f) atomicOr(devflags, 1u);
+}
+
+__global__ __launch_bounds__(256) void tree_keys_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ z, int64_t stride, int n,
+                                                        const TreeParams *__restrict__ tp, unsigned long long *__restrict__ keys,
+                                                        unsigned *__restrict__ vals)
+{
+    const double ox = tp->ox, oy = tp->oy, oz = tp->oz, inv_s = tp->inv_s;
+    const bool bad = tp->bad_input != 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned long long key = 0;
+        if (!bad)
+            key = morton63(fine_cell(x[(int64_t)i * stride], ox, inv_s), fine_cell(y[(int64_t)i * stride], oy, inv_s),
+                           fine_cell(z[(int64_t)i * stride], oz, inv_s));
+        keys[i] = key;
+        vals[i] = (unsigned)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void tree_gather_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, int64_t stride, int n,
+                                                          const unsigned *__restrict__ order, float4 *__restrict__ refs,
+                                                          int ref_only_from)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned v = order[i];
+        const unsigned tag = v | ((int)v >= ref_only_from ? 0x80000000u : 0u);
+        refs[i] = make_float4(x[(int64_t)v * stride], y[(int64_t)v * stride], z[(int64_t)v * stride], __uint_as_float(tag));
+    }
+}
+
+// ---------------------------------------------------------------- leaves
+// flags[i] = bit level of the leaf of sorted point i | 0x80 if i is the leaf's first point; tilecnt[t] = leaves starting in tile t
+__global__ __launch_bounds__(256) void tree_leaf_flags_kernel(const unsigned long long *__restrict__ keys, int n,
+                                                              unsigned char *__restrict__ flags, unsigned *__restrict__ tilecnt)
+{
+    __shared__ unsigned char a[LEAF_TILE + LEAF_CAP];   // a[t] belongs to sorted index t0 - LEAF_CAP + t
+    __shared__ unsigned wsum[4];
+    const int t0 = blockIdx.x * LEAF_TILE;
+    for (int t = threadIdx.x; t < LEAF_TILE + LEAF_CAP; t += 256) {
+        const long long j = (long long)t0 - LEAF_CAP + t;
+        int v = 64;   // no window of LEAF_CAP + 1 points starts here
+        if (j >= 0 && j + LEAF_CAP < n) {
+            const unsigned long long d = keys[j] ^ keys[j + LEAF_CAP];
+            v = d ? 64 - __builtin_clzll(d) : 0;   // smallest bit level at which j and j + LEAF_CAP share a node
+        }
+        a[t] = (unsigned char)v;
+    }
+    __syncthreads();
+    unsigned heads = 0;
+#pragma unroll
+    for (int u = 0; u < LEAF_TILE / 256; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        const int i = t0 + t;
+        if (i < n) {
+            int split = 64;   // smallest bit level at which the node of i holds more than LEAF_CAP points
+            for (int d = 0; d <= LEAF_CAP; ++d) split = min(split, (int)a[t + d]);
+            const int bl = max(split - 1, 0);   // split == 0: more than LEAF_CAP points in one fine cell -- an over-full leaf
+            const bool head = i == 0 || (keys[i] >> bl) != (keys[i - 1] >> bl);
+            flags[i] = (unsigned char)(bl | (head ? 0x80 : 0));
+            heads += head ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) heads += __shfl_xor(heads, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = heads;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void tree_leaf_compact_kernel(const unsigned char *__restrict__ flags, int n,
+                                                                const unsigned *__restrict__ tileoff, const unsigned *__restrict__ tilecnt,
+                                                                unsigned *__restrict__ leafstart, unsigned char *__restrict__ leafbl,
+                                                                TreeParams *__restrict__ tp)
+{
+    __shared__ unsigned wsum[4];
+    const int t0 = blockIdx.x * LEAF_TILE;
+    const int i0 = t0 + threadIdx.x * (LEAF_TILE / 256);   // 4 consecutive points per thread: leaves stay in key order
+    unsigned char f[LEAF_TILE / 256];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int u = 0; u < LEAF_TILE / 256; ++u) {
+        f[u] = i0 + u < n ? flags[i0 + u] : 0;
+        cnt += f[u] >> 7;
+    }
+    unsigned inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off);
+        if ((int)(threadIdx.x & 63) >= off) inc += o;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = tileoff[blockIdx.x];
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    unsigned at = base + inc - cnt;
+#pragma unroll
+    for (int u = 0; u < LEAF_TILE / 256; ++u)
+        if (f[u] & 0x80) {
+            leafstart[at] = (unsigned)(i0 + u);
+            leafbl[at] = f[u] & 0x7f;
+            ++at;
+        }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const unsigned total = tileoff[blockIdx.x] + tilecnt[blockIdx.x];
+        leafstart[total] = (unsigned)n;
+        tp->nleaves = total;
+    }
+}
+
+// ---------------------------------------------------------------- knn_leaf
+constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? 5 : (kcap <= 33 ? 3 : 2); }
+
+template <int KCAP>
+__global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_kernel(
+    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const float4 *__restrict__ refs,
+    const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k, int q_begin, int q_count,
+    float rf_scale, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist,
+    double *__restrict__ failbound)
+{
+    constexpr int L = KCAP - 1;
+    using Net = TopNet<L>;
+    constexpr int BS = Net::BS, HB = 4 < BS ? 4 : BS;
+    __shared__ unsigned s_mask[TREE_THREADS / 64][TWCAP][64];
+    // per mask word: the (pre-adjusted) first index of up to four key ranges and where in the word each one ends
+    __shared__ unsigned s_wb[TREE_THREADS / 64][4][TWCAP];
+    __shared__ unsigned s_wcut[TREE_THREADS / 64][TWCAP];
+
+    if (tp->bad_input) return;
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    unsigned(*mask)[64] = s_mask[wv];
+    unsigned *wb0 = s_wb[wv][0], *wb1 = s_wb[wv][1], *wb2 = s_wb[wv][2], *wb3 = s_wb[wv][3];
+    unsigned *wcut = s_wcut[wv];
+
+    const int n = tp->n;
+    const int nsteps = 32 - __builtin_clz((unsigned)max(n, 1));
+    const double ox = tp->ox, oy = tp->oy, oz = tp->oz, s = tp->s, slack = tp->slack;
+
+    WorkQueue wq;
+    wq_init(wq, tp->leaf_ctr, (int)tp->nleaves, TREE_THREADS / 64);
+    for (;;) {
+        const int item = uniform(wq_next(wq));
+        if (item < 0) break;
+        const int ls = uniform((int)leafstart[item]), le = uniform((int)leafstart[item + 1]);
+        const int bl = uniform((int)leafbl[item]);
+        const int nq = le - ls;
+        const unsigned long long key0 = keys[ls];
+        // the leaf's box in fine cells: bits below bl are free -- x gets ceil(bl/3) of them, y ceil((bl-1)/3), z floor(bl/3)
+        const int q3 = bl / 3, r3 = bl - 3 * q3;
+        const int bxb = q3 + (r3 >= 1), byb = q3 + (r3 >= 2), bzb = q3;
+        const unsigned long long nodekey = (key0 >> bl) << bl;
+        const int fx = (int)compact21(nodekey), fy = (int)compact21(nodekey >> 1), fz = (int)compact21(nodekey >> 2);
+        const int Lc = max(bxb - 1, 0);   // a CELL is the cube of 2^Lc fine cells: half the leaf's longest side
+        const int ncx = 1 << (bxb - Lc), ncy = 1 << (byb - Lc), ncz = 1 << (bzb - Lc);   // cells of the leaf: 1 or 2 per axis
+        const int CX0 = (fx >> Lc) - 1, CY0 = (fy >> Lc) - 1, CZ0 = (fz >> Lc) - 1;   // first cell of the searched box
+        const int rx = ncx + 2, ry = ncy + 2, rz = ncz + 2;
+        const int cmax = 1 << (TB - Lc);
+
+        // ---- lane (ci, cj, cl) looks up the key range of cell (CX0 + ci, CY0 + cj, CZ0 + cl)
+        int r_lo = 0, r_len = 0;
+        {
+            const int ci = lane & 3, cj = (lane >> 2) & 3, cl = lane >> 4;
+            const int X = CX0 + ci, Y = CY0 + cj, Z = CZ0 + cl;
+            const bool inleaf = ci >= 1 && ci <= ncx && cj >= 1 && cj <= ncy && cl >= 1 && cl <= ncz;
+            const bool valid = ci < rx && cj < ry && cl < rz && X >= 0 && Y >= 0 && Z >= 0 && X < cmax && Y < cmax && Z < cmax && !inleaf;
+            const unsigned long long code = valid ? morton63((unsigned)X, (unsigned)Y, (unsigned)Z) : 0ULL;
+            const unsigned long long klo = code << (3 * Lc), khi = (code + 1) << (3 * Lc);   // khi may be 2^63: above every key
+            unsigned a0 = 0, a1 = valid ? (unsigned)n : 0u, b0 = 0, b1 = a1;
+            for (int it = 0; it < nsteps; ++it) {   // two interleaved lower bounds over the whole sorted array
+                const unsigned ma = (a0 + a1) >> 1, mb = (b0 + b1) >> 1;
+                const unsigned long long ka = keys[min(ma, (unsigned)n - 1)], kb = keys[min(mb, (unsigned)n - 1)];
+                if (a0 < a1) {
+                    if (ka < klo) a0 = ma + 1; else a1 = ma;
+                }
+                if (b0 < b1) {
+                    if (kb < khi) b0 = mb + 1; else b1 = mb;
+                }
+            }
+            r_lo = (int)a0;
+            r_len = (int)(b0 - a0);
+            if (lane == 21) {   // cell (1,1,1): stands for the leaf itself, whose range is known
+                r_lo = ls;
+                r_len = nq;
+            }
+            // the two cells of an x-pair are siblings (the leaf's first cell has an even x): one range
+            if (ncx == 2) {
+                const int nl = __shfl_down(r_len, 1);
+                if (!inleaf && ci == 1) r_len += nl;
+                if (!inleaf && ci == 2) r_len = 0;
+            }
+        }
+        // non-empty ranges to the low lanes (lane order kept)
+        const unsigned long long ne = __ballot(r_len > 0);
+        const int nr = (int)__popcll(ne);
+        int rs_start, rs_len;
+        {
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ne >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ne, 0u));
+            const int dst = r_len > 0 ? below : nr + (lane - below);
+            rs_start = __builtin_amdgcn_ds_permute(dst << 2, r_lo);
+            rs_len = __builtin_amdgcn_ds_permute(dst << 2, r_len);
+        }
+        int ncand = rs_len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off);
+        ncand = uniform(ncand);
+
+        // geometry shared by the batches of this leaf
+        const double cell = s * (double)(1 << Lc);   // cell edge (real units)
+        const float hf = (float)cell, g_inv_h = (float)(1.0 / cell);
+        const float ccx = (float)(ox + ((double)fx + 0.5 * (double)(1 << bxb)) * s);
+        const float ccy = (float)(oy + ((double)fy + 0.5 * (double)(1 << byb)) * s);
+        const float ccz = (float)(oz + ((double)fz + 0.5 * (double)(1 << bzb)) * s);
+        (void)hf;
+        // radius inside which ~2 (k+1) points are expected at the leaf's own density (the uniform grid's cell edge), x rf_scale
+        const double vol = s * s * s * ldexp(1.0, bl);
+        const double r_f = (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1));
+        const bool irregular = ncand > TREE_CAND_LIMIT;
+
+        for (int qb = 0; qb < nq; qb += 64) {
+            const int f = qb + lane;
+            const bool live = f < nq;
+            const int qidx = ls + (live ? f : 0);
+            const float4 qp = refs[qidx];
+            const float qx = qp.x, qy = qp.y, qz = qp.z;
+            const unsigned self_w = __float_as_uint(qp.w);
+            const int qorig = (int)(self_w & 0x7fffffffu) - q_begin;
+            const bool is_query = live && !(self_w >> 31) && qorig >= 0 && qorig < q_count;
+            if (!__any(is_query)) continue;
+            if (irregular) {   // wave-uniform: too many candidates for one wave's lock-step scan
+                if (is_query) {
+                    const unsigned slot = atomicAdd(&tp->fail_count, 1u);
+                    faillist[slot] = (unsigned)qidx;
+                    failbound[slot] = -(4.0 * cell * cell);
+                }
+                continue;
+            }
+            // ---- acceptance radius: distance to the nearest face of the searched box with space behind it, capped at r_f
+            double racc_sq;
+            {
+                double rs = r_f;
+                const double qd[3] = {(double)qx, (double)qy, (double)qz};
+                const double od[3] = {ox, oy, oz};
+                const int c0[3] = {CX0, CY0, CZ0};
+                const int rr[3] = {rx, ry, rz};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (c0[a] > 0) rs = fmin(rs, (qd[a] - (od[a] + (double)c0[a] * cell)) - slack);
+                    if (c0[a] + rr[a] < cmax) rs = fmin(rs, ((od[a] + (double)(c0[a] + rr[a]) * cell) - qd[a]) - slack);
+                }
+                rs = fmax(rs, 0.0);
+                racc_sq = rs * rs;
+            }
+            float tau = is_query ? bound_from(racc_sq) : -1.0f;
+
+            Net lst;
+            bool lst_empty = true;
+            int widx = 0;
+            unsigned nzw = 0;
+
+            // ---- phase 2 (as knn_brick's): walk this lane's set bits, exact float64 distances, network selection
+            auto drain = [&]() __attribute__((always_inline)) {
+                const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
+                wave_sync();
+                unsigned m = 0, cut = 0x202020u;
+                int b0 = ls, b1 = ls, b2 = ls, b3 = ls;
+                for (;;) {
+                    double blk[BS];
+#pragma unroll
+                    for (int h0 = 0; h0 < BS; h0 += HB) {
+                        float4 pt[HB];
+                        bool ok[HB];
+#pragma unroll
+                        for (int j = 0; j < HB; ++j) {
+                            if (m == 0 && nzw != 0) {
+                                const int w = __builtin_ctz(nzw);
+                                nzw &= nzw - 1;
+                                m = mask[w][lane];
+                                b0 = (int)wb0[w];
+                                b1 = (int)wb1[w];
+                                b2 = (int)wb2[w];
+                                b3 = (int)wb3[w];
+                                cut = wcut[w];
+                            }
+                            ok[j] = m != 0;
+                            const int i = ok[j] ? __builtin_clz(m) : 0;
+                            m &= ~(0x80000000u >> i);
+                            const int base = i < (int)(cut & 255u) ? b0 : (i < (int)((cut >> 8) & 255u) ? b1 : (i < (int)((cut >> 16) & 255u) ? b2 : b3));
+                            pt[j] = refs[base + i];
+                        }
+#pragma unroll
+                        for (int j = 0; j < HB; ++j) {
+                            const double d = dist2_f64(qxd, qyd, qzd, pt[j].x, pt[j].y, pt[j].z);
+                            blk[h0 + j] = (ok[j] && __float_as_uint(pt[j].w) != self_w) ? d : __builtin_inf();
+                        }
+                    }
+                    if (uniform((int)lst_empty)) lst.assign_block(blk); else lst.merge_block(blk);
+                    lst_empty = false;
+                    if (!__any(m != 0 || nzw != 0)) break;
+                }
+                tau = fminf(tau, bound_from(lst.kth(k)));
+                widx = 0;
+                nzw = 0;
+                wave_sync();
+            };
+
+            // ---- the candidate ranges are walked as ONE flat sequence cut into 32-candidate words; a word takes up to four
+            // range pieces (a cell holds a handful of points: two pieces per word would leave the MFMA tiles half empty)
+            struct Word { int b[4]; int e[4]; int r, off; };   // b[j] + t = index of candidate t for t in [e[j-1], e[j]); wave-uniform
+            auto next_word = [&](int r, int off) __attribute__((always_inline)) {
+                Word o;
+                int fill = 0;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    int len = r < nr ? __builtin_amdgcn_readlane(rs_len, r & 63) : 0;
+                    while (r < nr && off >= len) {
+                        ++r;
+                        off = 0;
+                        len = r < nr ? __builtin_amdgcn_readlane(rs_len, r & 63) : 0;
+                    }
+                    int take = 0, st = 0;
+                    if (r < nr && fill < 32) {
+                        take = min(len - off, 32 - fill);
+                        st = __builtin_amdgcn_readlane(rs_start, r & 63) + off;
+                    }
+                    o.b[sg] = st - fill;
+                    fill += take;
+                    off += take;
+                    o.e[sg] = fill;
+                }
+                o.r = r;
+                o.off = off;
+                return o;
+            };
+            // number of words the cutting will produce
+            int nwords = 0;
+            {
+                int r = 0, off = 0;
+                for (;;) {
+                    const Word w = next_word(r, off);
+                    if (w.e[3] == 0) break;
+                    ++nwords;
+                    r = w.r;
+                    off = w.off;
+                    if (nwords > TWCAP) break;
+                }
+            }
+            if (nwords <= TWCAP) {
+                // ---- phase 1, matrix cores: cell-unit coordinates relative to the leaf centre (|u| <= 2); see knn_mfma.h
+                const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
+                const float nq2 = __builtin_fmaf(uqz, uqz, __builtin_fmaf(uqy, uqy, uqx * uqx));
+                const bool upper = lane >= 32;
+                const float s_q = tau >= 0.0f ? nq2 - ((tau * g_inv_h) * g_inv_h * (1.0f + 1e-6f) + MF_SLACK) : 1.0e30f;
+                bf16x8 opa, opb;
+                mf_query_operands(uqx, uqy, uqz, s_q, opa, opb);
+                const int my_cand = mf_cand_of_row(lane & 31);
+                auto fetch = [&](const Word &w) __attribute__((always_inline)) {
+                    const int c = w.e[3];
+                    if (c == 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int t = min(my_cand, c - 1);   // slots past the end repeat the last candidate (masked out below)
+                    const int base = t < w.e[0] ? w.b[0] : (t < w.e[1] ? w.b[1] : (t < w.e[2] ? w.b[2] : w.b[3]));
+                    return refs[base + t];
+                };
+                Word w_cur = next_word(0, 0);
+                Word w_n1 = next_word(w_cur.r, w_cur.off);
+                float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
+                while (w_cur.e[3] > 0) {
+                    const Word w_n2 = next_word(w_n1.r, w_n1.off);
+                    const float4 p_n2 = fetch(w_n2);
+                    const bf16x8 cand = mf_candidate_operand((p_cur.x - ccx) * g_inv_h, (p_cur.y - ccy) * g_inv_h,
+                                                             (p_cur.z - ccz) * g_inv_h, upper);
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const unsigned ma = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opa, zero, 0, 0, 0));
+                    const unsigned mb = mf_sign_bits(__builtin_amdgcn_mfma_f32_32x32x16_bf16(cand, opb, zero, 0, 0, 0));
+                    auto sw = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
+                    const unsigned m = ((sw[0] << 16) | (sw[1] & 0xffffu)) & (0xffffffffu << (32 - w_cur.e[3]));
+                    mask[widx][lane] = m;
+                    if (lane == 0) {
+                        wb0[widx] = (unsigned)w_cur.b[0];
+                        wb1[widx] = (unsigned)w_cur.b[1];
+                        wb2[widx] = (unsigned)w_cur.b[2];
+                        wb3[widx] = (unsigned)w_cur.b[3];
+                        wcut[widx] = (unsigned)w_cur.e[0] | ((unsigned)w_cur.e[1] << 8) | ((unsigned)w_cur.e[2] << 16);
+                    }
+                    nzw |= (m != 0 ? 1u : 0u) << widx;
+                    ++widx;
+                    w_cur = w_n1;
+                    p_cur = p_n1;
+                    w_n1 = w_n2;
+                    p_n1 = p_n2;
+                }
+                lst.init();
+            } else {
+                // ---- phase 1, float32 VALU on scalar loads: a box with more words than the park holds is filtered range by
+                // range and drained whenever the park is full (the list then lives across the filter loop)
+                lst.init();
+                for (int r = 0; r < nr; ++r) {
+                    const int gs = __builtin_amdgcn_readlane(rs_start, r & 63);
+                    const int len = __builtin_amdgcn_readlane(rs_len, r & 63);
+                    for (int w0 = 0; w0 < len; w0 += 32) {
+                        if (widx == TWCAP) drain();
+                        const int c = min(32, len - w0);
+                        const float4 *__restrict__ p = refs + gs + w0;
+                        const float neg_tau = -tau;
+                        unsigned m = 0;
+                        for (int i = 0; i < c; ++i) {
+                            const float4 P = p[i];   // wave-uniform address
+                            m = shift_in_lt(m, qx, qy, qz, P.x, P.y, P.z, neg_tau);
+                        }
+                        m <<= (32 - c);
+                        mask[widx][lane] = m;
+                        if (lane == 0) {
+                            wb0[widx] = (unsigned)(gs + w0);
+                            wb1[widx] = wb2[widx] = wb3[widx] = (unsigned)(gs + w0);
+                            wcut[widx] = 0x202020u;
+                        }
+                        nzw |= (m != 0 ? 1u : 0u) << widx;
+                        ++widx;
+                    }
+                }
+            }
+            drain();
+
+            if (is_query) {
+                const double kth_d2 = lst.kth(k);
+                if (kth_d2 <= racc_sq) {
+                    if (kth_out) kth_out[qorig] = kth_d2;
+                    mean_out[qorig] = mean_from_net(lst, k);
+                } else {
+                    const unsigned slot = atomicAdd(&tp->fail_count, 1u);
+                    faillist[slot] = (unsigned)qidx;
+                    // a full list bounds the k-th distance from above: the ball to search is known; otherwise start at 2 cells
+                    failbound[slot] = kth_d2 < __builtin_inf() ? kth_d2 : -(4.0 * cell * cell);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- knn_tree_query (fallback)
+struct TNode {
+    unsigned lo, hi;            // range of the sorted array
+    unsigned long long code;    // key >> 3*level of its points
+    double mind2;               // lower bound of the squared distance from the query to any of its points
+    int level;                  // octree level: a cube of 2^level fine cells
+    int pad;
+};
+
+__device__ __forceinline__ double wave_min_f64_(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double bcast_f64(double v, int src)   // wave-uniform src
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// first index in [lo, hi) whose key is >= K (hi if none): 64 probes per round, all lanes take part; wave-uniform arguments
+__device__ __forceinline__ unsigned wave_lower_bound(const unsigned long long *__restrict__ keys, unsigned lo, unsigned hi,
+                                                     unsigned long long K, int lane)
+{
+    while (hi - lo > 64u) {
+        const unsigned size = hi - lo, stride = (size + 63u) >> 6;
+        auto P = [&](unsigned t) { const unsigned p = lo + (t + 1u) * stride - 1u; return p < hi - 1u ? p : hi - 1u; };
+        const bool pred = keys[P((unsigned)lane)] < K;
+        const int cnt = (int)__popcll(__ballot(pred));
+        const unsigned nlo = cnt > 0 ? P((unsigned)cnt - 1u) + 1u : lo;
+        const unsigned nhi = cnt < 64 ? P((unsigned)cnt) : hi;
+        lo = (unsigned)uniform((int)nlo);
+        hi = (unsigned)uniform((int)nhi);
+    }
+    const unsigned p = lo + (unsigned)lane;
+    const bool pred = p < hi && keys[p < hi ? p : 0u] < K;
+    return lo + (unsigned)__popcll(__ballot(pred && hi > lo));
+}
+
+__global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
+    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const float4 *__restrict__ refs,
+    const unsigned *__restrict__ faillist, const double *__restrict__ failbound, int k, int q_begin, int out_count,
+    float *__restrict__ mean_out, double *__restrict__ kth_out)
+{
+    __shared__ TNode s_stack[TREE_THREADS / 64][TQ_STACK];
+    __shared__ double s_out[TREE_THREADS / 64][64];
+    if (tp->bad_input) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < out_count; i += gridDim.x * blockDim.x) mean_out[i] = __builtin_nanf("");
+        return;
+    }
+    const int nfail = (int)tp->fail_count;
+    if (nfail == 0) return;
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    TNode *stack = s_stack[wv];
+    double *out = s_out[wv];
+    const int n = tp->n;
+    const double od[3] = {tp->ox, tp->oy, tp->oz};
+    const double s = tp->s, inv_s = tp->inv_s, slack = tp->slack;
+    const int g = lane >> 3, u = lane & 7;
+
+    WorkQueue wq;
+    wq_init(wq, tp->fail_ctr, nfail, TREE_THREADS / 64);
+    for (;;) {
+        const int item = uniform(wq_next(wq));
+        if (item < 0) break;
+        const int qidx = uniform((int)faillist[item]);
+        const float4 qp = refs[qidx];
+        const unsigned self_w = __float_as_uint(qp.w);
+        const double qd[3] = {(double)qp.x, (double)qp.y, (double)qp.z};
+        const double bound = failbound[item];
+        double R = bound >= 0.0 ? __dsqrt_rn(bound) * (1.0 + 1e-9) + 4.0 * slack : __dsqrt_rn(-bound);
+
+        for (;;) {   // one pass per search radius (a known bound needs exactly one)
+            // the smallest octree node that contains the ball's box (one fine cell of margin against the cell rounding)
+            unsigned cl[3], ch[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double tl = ((qd[a] - R) - od[a]) * inv_s - 1.0, th = ((qd[a] + R) - od[a]) * inv_s + 1.0;
+                cl[a] = (unsigned)fmin(fmax(tl, 0.0), (double)((1 << TB) - 1));
+                ch[a] = (unsigned)fmin(fmax(th, 0.0), (double)((1 << TB) - 1));
+            }
+            const unsigned long long klo = morton63(cl[0], cl[1], cl[2]), khi = morton63(ch[0], ch[1], ch[2]);
+            const unsigned long long df = klo ^ khi;
+            const int lst_level = df ? (63 - __builtin_clzll(df)) / 3 + 1 : 0;   // 0 .. 21
+            const bool whole = lst_level >= TB;
+            TNode root;
+            root.level = lst_level;
+            root.code = whole ? 0ULL : klo >> (3 * lst_level);
+            root.mind2 = 0.0;
+            if (whole) {
+                root.lo = 0;
+                root.hi = (unsigned)n;
+            } else {
+                root.lo = wave_lower_bound(keys, 0u, (unsigned)n, root.code << (3 * lst_level), lane);
+                root.hi = wave_lower_bound(keys, root.lo, (unsigned)n, (root.code + 1) << (3 * lst_level), lane);
+            }
+            // everything outside that node is farther than rc (the whole cloud: nothing is outside)
+            double rc = __builtin_inf();
+            if (!whole) {
+                const unsigned nc[3] = {compact21(root.code), compact21(root.code >> 1), compact21(root.code >> 2)};
+                const double side = s * (double)(1u << lst_level);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (nc[a] > 0) rc = fmin(rc, (qd[a] - (od[a] + (double)nc[a] * side)) - slack);
+                    if ((nc[a] + 1u) < (1u << (TB - lst_level))) rc = fmin(rc, ((od[a] + (double)(nc[a] + 1u) * side) - qd[a]) - slack);
+                }
+                rc = fmax(rc, 0.0);
+            }
+            // points beyond rc cannot be certified in this pass anyway; a known bound on the k-th distance is tighter still
+            double T0 = whole ? __builtin_inf() : rc * rc;
+            if (bound >= 0.0) T0 = fmin(T0, bound);
+
+            double best = __builtin_inf();   // lane j: j-th smallest squared distance so far (the query itself excluded)
+            asm volatile("" : "+v"(best));   // opaque: see kv
+            // entry k-1: the running k-th distance.  Read back from the list, not assigned the constant: this compiler puts a
+            // wave-uniform double constant into s_mov_b64 with a 64-bit literal, which the instruction does not have (the
+            // register then holds 0: measured)
+            double kv = bcast_f64(best, k - 1);
+            int sp = 0;
+            if (lane == 0) stack[0] = root;
+            sp = 1;
+            wave_sync();
+            while (sp > 0) {
+                --sp;
+                const TNode nd = stack[sp];   // same address in every lane
+                const unsigned nlo = (unsigned)uniform((int)nd.lo), nhi = (unsigned)uniform((int)nd.hi);
+                const int level = uniform(nd.level);
+                const double md = bcast_f64(nd.mind2, 0);
+                if (md > T0 || md >= kv) continue;
+                const unsigned cnt = nhi - nlo;
+                if (cnt <= (unsigned)TQ_SCAN || level == 0) {
+                    // ---- scan: 64 points at a time; the nearest candidate below the running k-th distance is inserted first
+                    for (unsigned b = nlo; b < nhi; b += 64u) {
+                        const unsigned j = b + (unsigned)lane;
+                        bool have = j < nhi;
+                        const float4 p = refs[have ? j : nlo];
+                        const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                        have = have && __float_as_uint(p.w) != self_w && d <= T0;
+                        for (;;) {
+                            const bool cand = have && d < kv;
+                            if (!__any(cand)) break;
+                            const double dm = wave_min_f64_(cand ? d : __builtin_inf());
+                            const unsigned long long pick = __ballot(cand && d == dm);
+                            const int src = (int)__builtin_ctzll(pick);
+                            if (lane == src) have = false;
+                            const int pos = (int)__popcll(__ballot(best <= dm));
+                            const double up = __shfl_up(best, 1);
+                            best = lane < pos ? best : (lane == pos ? dm : up);
+                            kv = bcast_f64(best, k - 1);
+                        }
+                    }
+                } else {
+                    // ---- split: the 7 inner boundaries of the node's 8 children, one 8-lane group each (8 probes per round)
+                    const unsigned long long ccode = (nd.code << 3) | (unsigned long long)g;
+                    const unsigned long long K = ccode << (3 * (level - 1));
+                    unsigned slo = nlo, shi = g == 0 ? nlo : nhi;   // group 0: its child starts at nlo
+                    for (;;) {
+                        const unsigned size = shi - slo;
+                        const bool big = size > 8u;
+                        if (!__any(big)) break;
+                        const unsigned stride = (size + 7u) >> 3;
+                        auto P = [&](unsigned t) { const unsigned p = slo + (t + 1u) * stride - 1u; return p < shi - 1u ? p : shi - 1u; };
+                        const unsigned p = big ? P((unsigned)u) : nlo;
+                        const bool pred = big && keys[p] < K;
+                        const unsigned long long bal = __ballot(pred);
+                        const int c8 = __popc((unsigned)(bal >> (8 * g)) & 0xffu);
+                        if (big) {
+                            const unsigned a = c8 > 0 ? P((unsigned)c8 - 1u) + 1u : slo;
+                            const unsigned b = c8 < 8 ? P((unsigned)c8) : shi;
+                            slo = a;
+                            shi = b;
+                        }
+                    }
+                    unsigned pos;
+                    {
+                        const unsigned p = slo + (unsigned)u;
+                        const bool pred = p < shi && keys[p < shi ? p : nlo] < K;
+                        const unsigned long long bal = __ballot(pred);
+                        pos = slo + (unsigned)__popc((unsigned)(bal >> (8 * g)) & 0xffu);
+                    }
+                    const unsigned nxt = (unsigned)__shfl_down((int)pos, 8);   // start of the next child
+                    const unsigned clo = pos, chi = g == 7 ? nhi : nxt;
+                    // lower bound of the distance to the child's box
+                    const unsigned cc[3] = {compact21(ccode), compact21(ccode >> 1), compact21(ccode >> 2)};
+                    const double side = s * (double)(1u << (level - 1));
+                    double m2 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const double plo = od[a] + (double)cc[a] * side, phi = od[a] + (double)(cc[a] + 1u) * side;
+                        const double dd = fmax(fmax((plo - qd[a]) - slack, (qd[a] - phi) - slack), 0.0);
+                        m2 += dd * dd;
+                    }
+                    m2 *= (1.0 - 1e-14);
+                    const bool keep = chi > clo && !(m2 > T0) && m2 < kv;
+                    // nearest child on top of the stack: slot = number of kept children that are farther (ties by index)
+                    int farther = 0, nkept = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const double om = __shfl(m2, 8 * c);
+                        const int ok = __shfl((int)keep, 8 * c);
+                        nkept += ok;
+                        farther += (ok && (om > m2 || (om == m2 && c > g))) ? 1 : 0;
+                    }
+                    if (keep && u == 0) {
+                        TNode ch;
+                        ch.lo = clo;
+                        ch.hi = chi;
+                        ch.code = ccode;
+                        ch.mind2 = m2;
+                        ch.level = level - 1;
+                        ch.pad = 0;
+                        stack[sp + farther] = ch;
+                    }
+                    sp += uniform(nkept);
+                    wave_sync();
+                }
+            }
+            // certified iff k neighbours were found inside the radius the pass covered
+            const double rcert = fmin(R - 2.0 * slack, rc);
+            if (whole || kv <= rcert * rcert) {
+                if (lane < 64) out[lane] = __dsqrt_rn(best);
+                wave_sync();
+                if (lane == 0) {
+                    const int qorig = (int)(self_w & 0x7fffffffu) - q_begin;
+                    const double sum = pairwise_sum_le128([&](int i) { return out[i]; }, k);
+                    mean_out[qorig] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                    if (kth_out) kth_out[qorig] = kv;
+                }
+                wave_sync();
+                break;
+            }
+            R *= 2.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host
+static int tree_blocks(const gsx_ctx *ctx, int64_t n, int per_thread)
+{
+    const int64_t want = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * 16));
+}
+
+template <int KCAP>
+static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_t q_count, float *mean_out, double *kth_out)
+{
+    static int occ = 0;
+    if (!occ) {
+        GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, knn_leaf_kernel<KCAP>, TREE_THREADS, 0));
+        occ = std::max(1, std::min(occ, 8));
+    }
+    const char *rf = getenv("GSX_TREE_RF");
+    const float rf_scale = rf ? (float)atof(rf) : 1.1f;
+    hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
+                       w.keys[1].as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
+                       w.leafbl.as<unsigned char>(), k, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
+                       w.faillist.as<unsigned>(), w.failbound.as<double>());
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
+                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from)
+{
+    if (k < 1 || k > 64) GSX_FAIL("sor (tree): k=%d not supported (1 <= k <= 64)", k);
+    if (n_ref < 1 || n_ref > (int64_t)INT32_MAX - 64) GSX_FAIL("sor (tree): n=%lld out of range", (long long)n_ref);
+    if (n_ref <= k) GSX_FAIL("sor (tree): k=%d needs more than %lld points", k, (long long)n_ref);
+    TreeWs &w = ctx->tree_ws;
+    const size_t n = (size_t)n_ref;
+    const int ntiles = div_up(n_ref, LEAF_TILE);
+    const int bbox_blocks = std::min(tree_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
+    for (int b = 0; b < 2; ++b) {
+        GSX_CHECK(w.keys[b].reserve(sizeof(unsigned long long) * n));
+        GSX_CHECK(w.vals[b].reserve(sizeof(unsigned) * n));
+    }
+    GSX_CHECK(w.refs.reserve(sizeof(float4) * n));
+    GSX_CHECK(w.flags.reserve(n));
+    GSX_CHECK(w.tilecnt.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
+    GSX_CHECK(w.tileoff.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
+    GSX_CHECK(w.leafstart.reserve(sizeof(unsigned) * (n + 1)));
+    GSX_CHECK(w.leafbl.reserve(n));
+    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * n));
+    GSX_CHECK(w.failbound.reserve(sizeof(double) * n));
+    GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
+    if (!w.params.p) {
+        GSX_CHECK(w.params.reserve(sizeof(TreeParams)));
+        GSX_HIP(hipMemsetAsync(w.params.p, 0, sizeof(TreeParams), ctx->stream));
+    }
+    size_t t_sort = 0, t_scan = 0;
+    unsigned long long *k0 = w.keys[0].as<unsigned long long>(), *k1 = w.keys[1].as<unsigned long long>();
+    unsigned *v0 = w.vals[0].as<unsigned>(), *v1 = w.vals[1].as<unsigned>();
+    unsigned *tilecnt = w.tilecnt.as<unsigned>(), *tileoff = w.tileoff.as<unsigned>();
+    GSX_HIP(rocprim::radix_sort_pairs(nullptr, t_sort, k0, k1, v0, v1, n, 0, 63, ctx->stream));
+    GSX_HIP(rocprim::exclusive_scan(nullptr, t_scan, tilecnt, tileoff, 0u, (size_t)ntiles, rocprim::plus<unsigned>(), ctx->stream));
+    GSX_CHECK(w.temp.reserve(std::max(t_sort, t_scan)));
+    TreeParams *tp = w.params.as<TreeParams>();
+
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
+    hipLaunchKernelGGL(tree_bbox_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
+                       w.bboxpart.as<float>(), tp, ctx->devflags.as<unsigned>());
+    hipLaunchKernelGGL(tree_keys_kernel, dim3(tree_blocks(ctx, n_ref, 4)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, tp,
+                       k0, v0);
+    GSX_HIP(hipGetLastError());
+    GSX_HIP(rocprim::radix_sort_pairs(w.temp.p, t_sort, k0, k1, v0, v1, n, 0, 63, ctx->stream));
+    hipLaunchKernelGGL(tree_gather_kernel, dim3(tree_blocks(ctx, n_ref, 2)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
+                       v1, w.refs.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
+    hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, w.flags.as<unsigned char>(),
+                       tilecnt);
+    GSX_HIP(hipGetLastError());
+    GSX_HIP(rocprim::exclusive_scan(w.temp.p, t_scan, tilecnt, tileoff, 0u, (size_t)ntiles, rocprim::plus<unsigned>(), ctx->stream));
+    hipLaunchKernelGGL(tree_leaf_compact_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, w.flags.as<unsigned char>(), (int)n_ref,
+                       tileoff, tilecnt, w.leafstart.as<unsigned>(), w.leafbl.as<unsigned char>(), tp);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
+
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
+    const int kk = k + 1;
+    if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
+    else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
+    else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
+    else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
+    GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
+    hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 4), dim3(TREE_THREADS), 0, ctx->stream, tp, k1, w.refs.as<float4>(),
+                       w.faillist.as<unsigned>(), w.failbound.as<double>(), k, (int)q_begin, (int)q_count, mean_out, kth_out);
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
+
+    if (info || getenv("GSX_TRACE_LEVELS")) {
+        TreeParams h;
+        GSX_HIP(hipMemcpyAsync(&h, tp, sizeof(TreeParams), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (getenv("GSX_TRACE_LEVELS"))
+            fprintf(stderr, "[gsx] tree: n=%d fine cell %g leaves=%u (%.1f points each) fallback queries=%u\n", h.n, h.s, h.nleaves,
+                    h.nleaves ? (double)h.n / h.nleaves : 0.0, h.fail_count);
+        if (h.bad_input) return gsx_ctx_check(ctx);
+        if (info) {
+            info->algo = GSX_KNN_TREE;
+            info->grid_dim[0] = info->grid_dim[1] = info->grid_dim[2] = 0;
+            info->cell_size = (float)h.s;
+            info->n_cells = 0;
+            info->n_bricks = h.nleaves;
+            info->n_fallback = h.fail_count;
+            info->n_exhaustive = 0;
+            info->n_deferred_bricks = 0;
+            info->n_refined = 0;
+        }
+    }
+    return 0;
+}
+
+// diagnostics of the last tree run of this context (synchronous)
+int knn_tree_info(gsx_ctx *ctx, gsx_sor_info *info)
+{
+    TreeParams h;
+    if (!ctx->tree_ws.params.p) GSX_FAIL("sor (tree): no run to report on");
+    GSX_HIP(hipMemcpy(&h, ctx->tree_ws.params.p, sizeof(TreeParams), hipMemcpyDeviceToHost));
+    info->algo = GSX_KNN_TREE;
+    info->cell_size = (float)h.s;
+    info->n_bricks = h.nleaves;
+    info->n_fallback = h.fail_count;
+    return 0;
+}
+
+}  // namespace gsx

@@ -36,7 +36,9 @@ typedef struct gsx_ctx gsx_ctx;
 enum {
     GSX_KNN_AUTO = 0,  /* grid-binned exact KNN, brute force for tiny inputs   */
     GSX_KNN_BRUTE = 1, /* LDS-tiled brute force (BASELINE.json configs[1])     */
-    GSX_KNN_GRID = 2   /* grid-binned exact KNN + exact fallback ring/brute    */
+    GSX_KNN_GRID = 2,  /* grid-binned exact KNN + exact fallback ring/brute    */
+    GSX_KNN_TREE = 3   /* Morton-ordered leaves + exact tree descent: clouds whose density varies by orders of
+                          magnitude (csrc/sor_tree.hip); same bits as the other two; k <= 64                      */
 };
 
 /* timing slots (HIP-event pairs recorded on the context stream when enabled) */
