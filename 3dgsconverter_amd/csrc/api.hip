@@ -325,8 +325,7 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
         }
         return 0;
     }
-    // adaptive mode (clouds a uniform grid cannot resolve): the Morton-tree path unless the level-by-level grid is asked for
-    if (algo == GSX_KNN_GRID && c->adaptive && c->tree && k <= 64 && n_ref > k) algo = GSX_KNN_TREE;
+    // (adaptive mode: launch_knn_grid itself hands clouds its grid cannot resolve to the tree path, csrc/sor_tree.hip)
     if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, info);
     if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, INT32_MAX);
     GSX_FAIL("gsx_sor_knn_dev: unknown algo %d", algo);
@@ -439,7 +438,7 @@ int gsx_sor_filter(const float *x, const float *y, const float *z, int64_t strid
     if (stats_out) GSX_HIP(hipMemcpyAsync(stats_out, dstats, sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
     GSX_CHECK(gsx_ctx_check(c));  // synchronises; non-finite coordinates (either algorithm) are an error, like cKDTree's
     int used = k > 64 ? GSX_KNN_GRID : (algo == GSX_KNN_AUTO ? (n < c->brute_below ? GSX_KNN_BRUTE : GSX_KNN_GRID) : algo);
-    if (used == GSX_KNN_GRID && c->adaptive && c->tree && k <= 64 && n > k) used = GSX_KNN_TREE;   // as gsx_sor_knn_dev routes it
+    if (used == GSX_KNN_GRID && c->last_knn_algo == GSX_KNN_TREE) used = GSX_KNN_TREE;   // adaptive mode chose the tree path
     if (info) {
         // re-query diagnostics without recomputing: only the grid path has device-side counters
         memset(info, 0, sizeof(*info));

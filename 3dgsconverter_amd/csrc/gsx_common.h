@@ -90,6 +90,7 @@ struct TreeWs {
     DevBuf keys[2];     // u64[n]: Morton keys (unsorted | sorted)
     DevBuf vals[2];     // u32[n]: original indices (identity | key order)
     DevBuf refs;        // float4[n] points in key order
+    DevBuf samples;     // u64[n/32 + 1]: the last key of every 32-key block
     DevBuf flags;       // u8[n]: leaf bit level | 0x80 on a leaf's first point
     DevBuf tilecnt, tileoff;   // u32[tiles]: leaves starting in a tile, exclusive scan
     DevBuf leafstart;   // u32[leaves + 1]
@@ -101,7 +102,7 @@ struct TreeWs {
     DevBuf temp;        // rocprim temporary storage
     void release_all()
     {
-        DevBuf *all[] = {&keys[0], &keys[1], &vals[0], &vals[1], &refs, &flags, &tilecnt, &tileoff, &leafstart, &leafbl,
+        DevBuf *all[] = {&keys[0], &keys[1], &vals[0], &vals[1], &refs, &samples, &flags, &tilecnt, &tileoff, &leafstart, &leafbl,
                          &faillist, &failbound, &bboxpart, &params, &temp};
         for (auto b : all) b->release();
     }
@@ -132,6 +133,7 @@ struct gsx_ctx {
     int debug_skip = 0;  // profiling ablations of knn_brick (never set by the product path)
     int adaptive = 0;    // 1: bricks too populated for the grid are re-run on a finer grid (one host sync per call)
     int defer_words = 64;
+    int last_knn_algo = 0;   // algorithm the last KNN call of this context ended up in (GSX_KNN_*)
     int tree = 1;        // adaptive mode: 1 = the Morton-tree path (sor_tree.hip, no host round trips), 0 = level-by-level grid refinement
     int kmeans_mfma = 1;  // K-Means assign for D in {9,24,45}, K >= 64: 1 = matrix-core filter + exact certificate, 0 = packed-f32 VALU scan
     int kmeans_cs = 1;   // centroid-stationary matrix-core assign for K <= 1024 (0: the streaming kernel; A/B)

@@ -2282,12 +2282,16 @@ static int dispatch_ring(gsx_ctx *ctx, const BrickLaunch &a)
 int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
                     int64_t n_halo, int k, float *mean_out, double *kth_out);
 
+// csrc/sor_tree.hip: the path for clouds this grid cannot resolve
+int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
+                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from);
+
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
 // Sort (x,y,z)[first, first+n) by cell of the grid in gp: `sorted` and `start` (cell_start) are outputs.
 static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, const float *z, int64_t stride, int64_t first,
                       int64_t n, GridParams *gp, unsigned *start, float4 *sorted, int64_t cell_cap = 0, unsigned *cursor = nullptr,
-                      int64_t ref_only_from = INT32_MAX)
+                      int64_t ref_only_from = INT32_MAX, bool hist_done = false)
 {
     const bool big_path = cursor != nullptr;  // adaptive mode: oversized buckets are sorted by all workgroups
     unsigned *bk_cnt = w.bkcnt.as<unsigned>();
@@ -2295,8 +2299,9 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
     unsigned *bk_cursor = bk_start + MAX_BUCKETS + 1;
     float4 *tmp = w.bucketpts.as<float4>();
     const int tiles = (int)std::min<int64_t>(div_up(n, BIN_TILE), (int64_t)ctx->num_cu * 4);
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n, gp,
-                       bk_cnt, bk_start, bk_cursor);   // its last workgroup scans the bucket sizes
+    if (!hist_done)
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, (int)first, (int)n, gp,
+                           bk_cnt, bk_start, bk_cursor);   // its last workgroup scans the bucket sizes
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(tiles), dim3(SCATTER_THREADS), 0, ctx->stream, x, y, z, stride, (int)first, (int)n,
                        gp, bk_cursor, tmp, (int)std::min<int64_t>(ref_only_from, INT32_MAX));
     if (big_path) GSX_HIP(hipMemsetAsync(start, 0, sizeof(unsigned) * (size_t)(cell_cap + 1), ctx->stream));  // counts of big buckets
@@ -2322,6 +2327,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                           int64_t ref_only_from = INT32_MAX, double h_hint = 0.0)
 {
     KnnWs &w = ctx->ws[level];
+    if (level == 0) ctx->last_knn_algo = GSX_KNN_GRID;
     w.refined_total = 0;
     const int kk = k + 1;
     const bool anyk = kk > 65;   // k > 64: the list-free exact path (knn_anyk_kernel) instead of knn_brick + ring kernels
@@ -2388,8 +2394,38 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                        w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
     GSX_HIP(hipGetLastError());
     if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
+    // Adaptive mode, first decision: can ONE grid resolve this cloud at all?  The coarse histogram of the two-level sort (one
+    // bucket = a column of cells sized for ~4096 points of a uniform cloud) says so after 0.1 ms: a cloud whose fullest bucket
+    // holds several times the average (a scene inside a box inflated by floaters: 2400x; Gaussian blobs: 30x+) goes to the
+    // Morton-tree path (sor_tree.hip) at once -- no cell size fits it, and refining level by level costs a host round trip
+    // and a re-binning per level (clustered 1M: 16.5 ms against 1.3 ms).
+    const bool tree_ok = adaptive && ctx->tree && level == 0 && nshares == 1 && kk <= 65 && n_ref > k;
+    bool hist_done = false;
+    if (tree_ok) {
+        unsigned *bk_cnt = w.bkcnt.as<unsigned>();
+        const int tiles = (int)std::min<int64_t>(div_up(n_ref, BIN_TILE), (int64_t)ctx->num_cu * 4);
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(tiles), dim3(256), 0, ctx->stream, x, y, z, stride, 0, (int)n_ref, gp, bk_cnt,
+                           bk_cnt + MAX_BUCKETS, bk_cnt + 2 * MAX_BUCKETS + 1);
+        GSX_HIP(hipGetLastError());
+        static thread_local std::vector<unsigned> starts(MAX_BUCKETS + 1);
+        GSX_HIP(hipMemcpyAsync(starts.data(), bk_cnt + MAX_BUCKETS, sizeof(unsigned) * (MAX_BUCKETS + 1), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        unsigned mx = 0, nonzero = 0;
+        for (int b = 0; b < MAX_BUCKETS; ++b) {
+            const unsigned c = starts[b + 1] >= starts[b] ? starts[b + 1] - starts[b] : 0u;   // (entries past the last bucket repeat the total)
+            mx = std::max(mx, c);
+            nonzero += c > 0;
+        }
+        hist_done = true;
+        if (nonzero > 0 && (double)mx > 3.0 * (double)n_ref / (double)nonzero) {
+            GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
+            if (getenv("GSX_TRACE_LEVELS"))
+                fprintf(stderr, "[gsx] level 0: fullest bucket %u of %lld points in %u buckets -> tree path\n", mx, (long long)n_ref, nonzero);
+            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, slab ? ref_only_from : INT32_MAX);
+        }
+    }
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr,
-                         slab ? ref_only_from : INT32_MAX));
+                         slab ? ref_only_from : INT32_MAX, hist_done));
     const float4 *qpts = refs;
     const unsigned *qstart = rstart;
     if (!all) {
@@ -2442,6 +2478,12 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             fprintf(stderr, "[gsx] level %d: n=%lld h=%.5g dims=%dx%dx%d bricks=%d defer_words=%d deferred=%u extra=%u fail=%u\n", level,
                     (long long)n_ref, hgp.h, hgp.nx, hgp.ny, hgp.nz, hgp.nbricks, hgp.defer_words, hgp.deferred_count,
                     hgp.extra_count, hgp.fail_count);
+        if (hgp.deferred_count > 0 && !hgp.bad_input && tree_ok) {
+            // second decision: the histogram looked even, yet some bricks hold far more than their cells were sized for
+            // (density varying inside the buckets).  The tree path takes the whole cloud over; this level's work is lost.
+            if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level 0: %u deferred bricks -> tree path\n", hgp.deferred_count);
+            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX);
+        }
         if (hgp.deferred_count > 0 && !hgp.bad_input) {
             const unsigned nd = hgp.deferred_count;
             GSX_CHECK(w.cellflag.reserve((size_t)hgp.ncells + 64));

@@ -47,11 +47,24 @@ constexpr int TB = 21;                 // key bits per axis
 constexpr int TREE_TOP = 3 * TB;       // bit level of the root (all 63 key bits free)
 constexpr int LEAF_CAP = 64;           // points per leaf = lanes of a wave
 constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
-constexpr int TWCAP = 28;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
+#ifndef GSX_TWCAP
+#define GSX_TWCAP 28
+#endif
+#ifndef GSX_LEAF_WAVES17
+#define GSX_LEAF_WAVES17 5
+#endif
+#ifndef GSX_TREE_ABL   // profiling builds only (results become wrong): 1 = no phase 2, 2 = no phase 1, 4 = no range look-ups, 16 = no word count, 32 = no cbrt
+#define GSX_TREE_ABL 0
+#endif
+static_assert(GSX_TWCAP <= 32, "the non-empty-word mask of a batch is one 32-bit register");
+constexpr int TWCAP = GSX_TWCAP;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
 constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag kernels
 constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points hands its queries to knn_tree_query
-constexpr int TQ_STACK = 176;          // 21 levels x 7 siblings + the start node
+constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small array (2.5 MB at 10M points: cache resident) that the
+                                       // range look-ups search first; only the last 5 steps touch the 80 MB key array
+constexpr int TQ_STACK = 192;          // 27 roots + 21 levels x 7 siblings
 constexpr int TQ_SCAN = 256;           // a node with at most this many points is scanned, not split
+constexpr int TQ_CAND = 256;           // candidates inside the search ball a wave collects before it ranks them
 
 struct TreeParams {
     double ox, oy, oz;     // origin = per-axis minimum
@@ -63,8 +76,12 @@ struct TreeParams {
     unsigned fail_count;
     unsigned ticket_bbox;  // self-resetting arrival ticket of tree_bbox_kernel
     unsigned pad;
+    unsigned fail2_count;  // queries knn_tree_near handed on to knn_tree_query
+    unsigned pad2;
+    unsigned dbg[8];
     unsigned leaf_ctr[8 * 32];
     unsigned fail_ctr[8 * 32];
+    unsigned fail2_ctr[8 * 32];
 };
 
 __device__ __forceinline__ unsigned long long spread21(unsigned v)   // bit t -> bit 3t
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
     for (int i = lane; i < 8 * 32; i += 64) {
         tp->leaf_ctr[i] = 0;
         tp->fail_ctr[i] = 0;
+        tp->fail2_ctr[i] = 0;
     }
     if (lane != 0) return;
     tp->ticket_bbox = 0;
@@ -190,6 +208,8 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
     tp->bad_input = v[6] != 0.0f ? 1u : 0u;
     tp->nleaves = 0;
     tp->fail_count = 0;
+    tp->fail2_count = 0;
+    for (int i = 0; i < 8; ++i) tp->dbg[i] = 0;
     if (v[6] != 0.0f) atomicOr(devflags, 1u);
 }
 
@@ -220,6 +240,14 @@ __global__ __launch_bounds__(256) void tree_gather_kernel(const float *__restric
         const unsigned tag = v | ((int)v >= ref_only_from ? 0x80000000u : 0u);
         refs[i] = make_float4(x[(int64_t)v * stride], y[(int64_t)v * stride], z[(int64_t)v * stride], __uint_as_float(tag));
     }
+}
+
+__global__ __launch_bounds__(256) void tree_samples_kernel(const unsigned long long *__restrict__ keys, int n,
+                                                           unsigned long long *__restrict__ samples)
+{
+    const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nblk; j += gridDim.x * blockDim.x)
+        samples[j] = keys[min(j * KEY_BLOCK + KEY_BLOCK - 1, n - 1)];   // the last key of block j
 }
 
 // ---------------------------------------------------------------- leaves
@@ -302,14 +330,67 @@ __global__ __launch_bounds__(256) void tree_leaf_compact_kernel(const unsigned c
     }
 }
 
+// key range [a, b) of the cell `code` at octree level Lc (every lane its own cell; lanes with want == false get an empty range).
+// Start: a binary lower bound, first over the sampled keys, then inside the 32-key block found.  End: galloped from the start --
+// a cell holds a handful of points, so two or three probes next to the start replace a second 24-step search.  (The three
+// KNN kernels are bound by the NUMBER of these scattered 8-byte loads, not by the length of the chain: a 4-ary search -- half
+// the steps, 1.5x the loads -- made every one of them 5-10 % slower.)
+__device__ __forceinline__ void cell_range(const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
+                                           int n, int nblk, bool want, unsigned long long code, int Lc, unsigned &a, unsigned &b)
+{
+    const unsigned long long klo = code << (3 * Lc), khi = (code + 1) << (3 * Lc);   // khi may be 2^63: above every key
+    unsigned a0 = 0, a1 = want ? (unsigned)nblk : 0u;
+    while (__any(a0 < a1)) {
+        if (a0 < a1) {
+            const unsigned mid = (a0 + a1) >> 1;
+            if (samples[mid] < klo) a0 = mid + 1u; else a1 = mid;
+        }
+    }
+    // (block index nblk: every key is smaller, the bound is n)
+    a0 *= KEY_BLOCK;
+    a1 = want ? min(a0 + KEY_BLOCK, (unsigned)n) : a0;
+    if (a0 > (unsigned)n) a0 = a1 = (unsigned)n;
+    while (__any(a0 < a1)) {
+        if (a0 < a1) {
+            const unsigned mid = (a0 + a1) >> 1;
+            if (keys[mid] < klo) a0 = mid + 1u; else a1 = mid;
+        }
+    }
+    unsigned b0 = a0, b1 = a0, step = 4u;
+    bool act = want && a0 < (unsigned)n;
+    while (__any(act)) {
+        if (act) {
+            const unsigned p = b0 + step - 1u;
+            if (p >= (unsigned)n) {
+                b1 = (unsigned)n;
+                act = false;
+            } else if (keys[p] < khi) {
+                b0 = p + 1u;
+                step <<= 2;
+            } else {
+                b1 = p;
+                act = false;
+            }
+        }
+    }
+    while (__any(b0 < b1)) {
+        if (b0 < b1) {
+            const unsigned mid = (b0 + b1) >> 1;
+            if (keys[mid] < khi) b0 = mid + 1u; else b1 = mid;
+        }
+    }
+    a = a0;
+    b = b0;
+}
+
 // ---------------------------------------------------------------- knn_leaf
-constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? 5 : (kcap <= 33 ? 3 : 2); }
+constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? 3 : 2); }
 
 template <int KCAP>
 __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_kernel(
-    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const float4 *__restrict__ refs,
-    const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k, int q_begin, int q_count,
-    float rf_scale, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist,
+    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
+    const float4 *__restrict__ refs, const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k,
+    int q_begin, int q_count, float rf_scale, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist,
     double *__restrict__ failbound)
 {
     constexpr int L = KCAP - 1;
@@ -328,7 +409,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     unsigned *wcut = s_wcut[wv];
 
     const int n = tp->n;
-    const int nsteps = 32 - __builtin_clz((unsigned)max(n, 1));
+    const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
     const double ox = tp->ox, oy = tp->oy, oz = tp->oz, s = tp->s, slack = tp->slack;
 
     WorkQueue wq;
@@ -359,17 +440,13 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             const bool inleaf = ci >= 1 && ci <= ncx && cj >= 1 && cj <= ncy && cl >= 1 && cl <= ncz;
             const bool valid = ci < rx && cj < ry && cl < rz && X >= 0 && Y >= 0 && Z >= 0 && X < cmax && Y < cmax && Z < cmax && !inleaf;
             const unsigned long long code = valid ? morton63((unsigned)X, (unsigned)Y, (unsigned)Z) : 0ULL;
-            const unsigned long long klo = code << (3 * Lc), khi = (code + 1) << (3 * Lc);   // khi may be 2^63: above every key
-            unsigned a0 = 0, a1 = valid ? (unsigned)n : 0u, b0 = 0, b1 = a1;
-            for (int it = 0; it < nsteps; ++it) {   // two interleaved lower bounds over the whole sorted array
-                const unsigned ma = (a0 + a1) >> 1, mb = (b0 + b1) >> 1;
-                const unsigned long long ka = keys[min(ma, (unsigned)n - 1)], kb = keys[min(mb, (unsigned)n - 1)];
-                if (a0 < a1) {
-                    if (ka < klo) a0 = ma + 1; else a1 = ma;
-                }
-                if (b0 < b1) {
-                    if (kb < khi) b0 = mb + 1; else b1 = mb;
-                }
+            unsigned a0 = 0, b0 = 0;
+            if (GSX_TREE_ABL & 4) {
+                a0 = (unsigned)ls;
+                b0 = (unsigned)ls + ((lane & 7) == 0 ? 40u : 0u);   // 8 fake ranges of 40 candidates
+                if (b0 > (unsigned)n) b0 = (unsigned)ls;
+            } else {
+                cell_range(keys, samples, n, nblk, valid, code, Lc, a0, b0);
             }
             r_lo = (int)a0;
             r_len = (int)(b0 - a0);
@@ -408,7 +485,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
         (void)hf;
         // radius inside which ~2 (k+1) points are expected at the leaf's own density (the uniform grid's cell edge), x rf_scale
         const double vol = s * s * s * ldexp(1.0, bl);
-        const double r_f = (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1));
+        const double r_f = (GSX_TREE_ABL & 32) ? 1e30 : (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1));
         const bool irregular = ncand > TREE_CAND_LIMIT;
 
         for (int qb = 0; qb < nq; qb += 64) {
@@ -422,10 +499,26 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             const bool is_query = live && !(self_w >> 31) && qorig >= 0 && qorig < q_count;
             if (!__any(is_query)) continue;
             if (irregular) {   // wave-uniform: too many candidates for one wave's lock-step scan
+                // Typically a SLIVER: a node whose box is large because most of it lies outside the object whose rim it cuts
+                // (<= 64 points in a thin slab along a face or an edge), while its one-cell margin reaches deep into the dense
+                // inside.  The radius to try first comes from the density inside the tight box of the leaf's own points.
+                float lo3[3] = {live ? qx : 3.0e38f, live ? qy : 3.0e38f, live ? qz : 3.0e38f};
+                float hi3[3] = {live ? qx : -3.0e38f, live ? qy : -3.0e38f, live ? qz : -3.0e38f};
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], off));
+                        hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], off));
+                    }
+                const double e3[3] = {(double)hi3[0] - (double)lo3[0], (double)hi3[1] - (double)lo3[1], (double)hi3[2] - (double)lo3[2]};
+                const double emx = fmax(fmax(e3[0], e3[1]), e3[2]);
+                const double vt = fmax(e3[0], 1e-3 * emx) * fmax(e3[1], 1e-3 * emx) * fmax(e3[2], 1e-3 * emx);
+                const double rt = 1.3 * cbrt(0.397 * (double)(k + 1) * vt / (double)min(nq - qb, 64));
                 if (is_query) {
                     const unsigned slot = atomicAdd(&tp->fail_count, 1u);
                     faillist[slot] = (unsigned)qidx;
-                    failbound[slot] = -(4.0 * cell * cell);
+                    failbound[slot] = -fmax(rt * rt, 0.25 * s * s);
                 }
                 continue;
             }
@@ -456,6 +549,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             auto drain = [&]() __attribute__((always_inline)) {
                 const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
                 wave_sync();
+                if (GSX_TREE_ABL & 1) nzw = 0;
                 unsigned m = 0, cut = 0x202020u;
                 int b0 = ls, b1 = ls, b2 = ls, b3 = ls;
                 for (;;) {
@@ -526,20 +620,11 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 o.off = off;
                 return o;
             };
-            // number of words the cutting will produce
-            int nwords = 0;
-            {
-                int r = 0, off = 0;
-                for (;;) {
-                    const Word w = next_word(r, off);
-                    if (w.e[3] == 0) break;
-                    ++nwords;
-                    r = w.r;
-                    off = w.off;
-                    if (nwords > TWCAP) break;
-                }
-            }
-            if (nwords <= TWCAP) {
+            // The matrix-core filter is run on the assumption that the words of the box fit the park (28 words = 896 candidates:
+            // nearly always).  If they do not, its masks are dropped and the box is filtered again the slow way -- counting the
+            // words first cost 0.85 ms at 10M points (scalar loop over the ranges), the occasional wasted filter costs nothing.
+            bool parked = ncand <= TWCAP * 32;
+            if (parked) {
                 // ---- phase 1, matrix cores: cell-unit coordinates relative to the leaf centre (|u| <= 2); see knn_mfma.h
                 const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
                 const float nq2 = __builtin_fmaf(uqz, uqz, __builtin_fmaf(uqy, uqy, uqx * uqx));
@@ -558,7 +643,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 Word w_cur = next_word(0, 0);
                 Word w_n1 = next_word(w_cur.r, w_cur.off);
                 float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
-                while (w_cur.e[3] > 0) {
+                while (w_cur.e[3] > 0 && widx < TWCAP && !(GSX_TREE_ABL & 2)) {
                     const Word w_n2 = next_word(w_n1.r, w_n1.off);
                     const float4 p_n2 = fetch(w_n2);
                     const bf16x8 cand = mf_candidate_operand((p_cur.x - ccx) * g_inv_h, (p_cur.y - ccy) * g_inv_h,
@@ -583,11 +668,17 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                     w_n1 = w_n2;
                     p_n1 = p_n2;
                 }
-                lst.init();
-            } else {
+                if (w_cur.e[3] > 0 && !(GSX_TREE_ABL & 2)) {   // wave-uniform: words left over
+                    parked = false;
+                    widx = 0;
+                    nzw = 0;
+                }
+                wave_sync();
+            }
+            lst.init();
+            if (!parked) {
                 // ---- phase 1, float32 VALU on scalar loads: a box with more words than the park holds is filtered range by
                 // range and drained whenever the park is full (the list then lives across the filter loop)
-                lst.init();
                 for (int r = 0; r < nr; ++r) {
                     const int gs = __builtin_amdgcn_readlane(rs_start, r & 63);
                     const int len = __builtin_amdgcn_readlane(rs_len, r & 63);
@@ -617,14 +708,17 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
 
             if (is_query) {
                 const double kth_d2 = lst.kth(k);
-                if (kth_d2 <= racc_sq) {
+                if (GSX_TREE_ABL) {
+                    mean_out[qorig] = (float)kth_d2;   // keeps the list live, never fails
+                } else if (kth_d2 <= racc_sq) {
                     if (kth_out) kth_out[qorig] = kth_d2;
                     mean_out[qorig] = mean_from_net(lst, k);
                 } else {
                     const unsigned slot = atomicAdd(&tp->fail_count, 1u);
                     faillist[slot] = (unsigned)qidx;
-                    // a full list bounds the k-th distance from above: the ball to search is known; otherwise start at 2 cells
-                    failbound[slot] = kth_d2 < __builtin_inf() ? kth_d2 : -(4.0 * cell * cell);
+                    // the filter only let candidates inside the acceptance radius through, of which there were fewer than k (a full
+                    // list would bound the k-th distance): the next ball to try is 1.3x wider -- 2.2x the volume
+                    failbound[slot] = kth_d2 < __builtin_inf() ? kth_d2 : -fmax(1.69 * racc_sq, 0.25 * cell * cell);
                 }
             }
         }
@@ -676,30 +770,176 @@ __device__ __forceinline__ unsigned wave_lower_bound(const unsigned long long *_
     return lo + (unsigned)__popcll(__ballot(pred && hi > lo));
 }
 
+// ---------------------------------------------------------------- knn_tree_near (near misses)
+// Nearly every query knn_leaf cannot certify has a FULL list: k candidates were found, the k-th just lies beyond the nearest
+// face of the searched box.  That k-th distance bounds the true one from above, so the answer is inside a known ball -- no
+// descent needed: the ball is covered by at most 6^3 cells whose edge is between a quarter and half of its diameter, each a
+// contiguous key range (one lane, one search); the few dozen points inside the ball are collected in LDS and the k nearest
+// taken by rank.  ~20 dependent memory round trips per query instead of knn_tree_query's 40-100.  Queries without a bound, and
+// balls that reach into a much denser region, are handed on to knn_tree_query.
+__global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
+    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
+    const float4 *__restrict__ refs, const unsigned *__restrict__ faillist, const double *__restrict__ failbound, int k,
+    int q_begin, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist2,
+    double *__restrict__ failbound2)
+{
+    __shared__ double s_cand[TREE_THREADS / 64][TQ_CAND];
+    __shared__ double s_out[TREE_THREADS / 64][64];
+    __shared__ unsigned s_cnt[TREE_THREADS / 64];
+    if (tp->bad_input) return;
+    const int nfail = (int)tp->fail_count;
+    if (nfail == 0) return;
+    const int lane = lane_id();
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    double *cand = s_cand[wv], *out = s_out[wv];
+    unsigned *cnt = &s_cnt[wv];
+    const int n = tp->n;
+    const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
+    const double od[3] = {tp->ox, tp->oy, tp->oz};
+    const double s = tp->s, inv_s = tp->inv_s, slack = tp->slack;
+
+    WorkQueue wq;
+    wq_init(wq, tp->fail_ctr, nfail, TREE_THREADS / 64);
+    for (;;) {
+        const int item = uniform(wq_next(wq));
+        if (item < 0) break;
+        const int qidx = uniform((int)faillist[item]);
+        const double bound = failbound[item];
+        bool defer = false;
+        const float4 qp = refs[qidx];
+        const unsigned self_w = __float_as_uint(qp.w);
+        const double qd[3] = {(double)qp.x, (double)qp.y, (double)qp.z};
+        // a known bound on the k-th distance, or (negative) the square of a radius to try: every point inside the ball is looked
+        // at, so finding k of them within r - 2 slack certifies the answer.  A ball that holds fewer (the query sits at the rim
+        // of an object: half of it is empty) is widened twice, 1.3x each, before the query is handed on.
+        double r = bound >= 0.0 ? __dsqrt_rn(bound) * (1.0 + 1e-9) + 4.0 * slack : __dsqrt_rn(-bound);
+        int M = 0;
+        for (int attempt = 0;; ++attempt) {
+            const double rin = fmax(r - 2.0 * slack, 0.0);
+            const double T = bound >= 0.0 ? bound : rin * rin;
+            int Lg = 0;   // cells of 2^Lg fine cells: the smallest with an edge of at least r / 2
+            while (Lg < TB && s * (double)(1u << Lg) < 0.5 * r) ++Lg;
+            const double g = s * (double)(1u << Lg);
+            int c0[3], nc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double tl = ((qd[a] - r) - od[a]) * inv_s - 1.0, th = ((qd[a] + r) - od[a]) * inv_s + 1.0;
+                const unsigned l = (unsigned)fmin(fmax(tl, 0.0), (double)((1 << TB) - 1)) >> Lg;
+                const unsigned h = (unsigned)fmin(fmax(th, 0.0), (double)((1 << TB) - 1)) >> Lg;
+                c0[a] = uniform((int)l);
+                nc[a] = uniform((int)(h - l) + 1);
+            }
+            const int total = nc[0] * nc[1] * nc[2];
+            defer = total > 512;
+            if (defer && lane == 0) atomicAdd(&tp->dbg[0], 1u);
+            if (lane == 0) *cnt = 0u;
+            wave_sync();
+            for (int cb = 0; cb < total && !defer; cb += 64) {
+                const int c = cb + lane;
+                const bool valid = c < total;
+                const int iz = c / (nc[0] * nc[1]), rem = c - iz * nc[0] * nc[1], iy = rem / nc[0], ix = rem - iy * nc[0];
+                const unsigned X[3] = {(unsigned)(c0[0] + ix), (unsigned)(c0[1] + iy), (unsigned)(c0[2] + iz)};
+                double m2 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double plo = od[a] + (double)X[a] * g, phi = od[a] + (double)(X[a] + 1u) * g;
+                    const double dd = fmax(fmax((plo - qd[a]) - slack, (qd[a] - phi) - slack), 0.0);
+                    m2 += dd * dd;
+                }
+                const bool keep = valid && m2 * (1.0 - 1e-14) <= T;
+                unsigned a0, b0;
+                cell_range(keys, samples, n, nblk, keep, keep ? morton63(X[0], X[1], X[2]) : 0ULL, Lg, a0, b0);
+                const unsigned len = b0 - a0;
+                if (__any(len > 64u)) {   // a cell far denser than the ball's own neighbourhood: the pruning descent's job
+                    defer = true;
+                    if (lane == 0) atomicAdd(&tp->dbg[1], 1u);
+                    if (lane == 0) atomicAdd(&tp->dbg[5 + min(attempt, 2)], 1u);
+                    break;
+                }
+                for (unsigned j = 0; j < len; ++j) {   // a handful of points per cell
+                    const float4 p = refs[a0 + j];
+                    const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                    if (__float_as_uint(p.w) != self_w && d <= T) {
+                        const unsigned at = atomicAdd(cnt, 1u);
+                        if (at < (unsigned)TQ_CAND) cand[at] = d;
+                    }
+                }
+            }
+            wave_sync();
+            M = uniform((int)*cnt);
+            if (defer || M > TQ_CAND) {
+                if (!defer && lane == 0) atomicAdd(&tp->dbg[2], 1u);
+                defer = true;
+                break;
+            }
+            if (M >= k) break;
+            if (bound >= 0.0 || attempt == 2) {
+                if (lane == 0) atomicAdd(&tp->dbg[bound >= 0.0 ? 4 : 3], 1u);
+                defer = true;
+                break;
+            }
+            r *= 1.3;
+        }
+        if (defer) {
+            if (lane == 0) {
+                const unsigned slot = atomicAdd(&tp->fail2_count, 1u);
+                faillist2[slot] = (unsigned)qidx;
+                failbound2[slot] = bound >= 0.0 ? bound : -4.0 * r * r;   // a radius that was tried: the descent starts at twice that
+            }
+            continue;
+        }
+        // the k smallest of the collected values, by rank
+        double kth2 = 0.0;
+        for (int i0 = 0; i0 < M; i0 += 64) {
+            const int i = i0 + lane;
+            const double ci = i < M ? cand[i] : __builtin_inf();
+            int rank = 0;
+            for (int j = 0; j < M; ++j) {
+                const double cj = cand[j];
+                rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+            }
+            if (i < M && rank < k) out[rank] = __dsqrt_rn(ci);
+            const unsigned long long last = __ballot(i < M && rank == k - 1);
+            if (last) kth2 = bcast_f64(ci, (int)__builtin_ctzll(last));
+        }
+        wave_sync();
+        if (lane == 0) {
+            const int qorig = (int)(self_w & 0x7fffffffu) - q_begin;
+            const double sum = pairwise_sum_le128([&](int i) { return out[i]; }, k);
+            mean_out[qorig] = __double2float_rn(__ddiv_rn(sum, (double)k));
+            if (kth_out) kth_out[qorig] = kth2;
+        }
+        wave_sync();
+    }
+}
+
 __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
-    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const float4 *__restrict__ refs,
+    TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
+    const float4 *__restrict__ refs,
     const unsigned *__restrict__ faillist, const double *__restrict__ failbound, int k, int q_begin, int out_count,
     float *__restrict__ mean_out, double *__restrict__ kth_out)
 {
     __shared__ TNode s_stack[TREE_THREADS / 64][TQ_STACK];
     __shared__ double s_out[TREE_THREADS / 64][64];
+    __shared__ double s_cand[TREE_THREADS / 64][TQ_CAND];
     if (tp->bad_input) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < out_count; i += gridDim.x * blockDim.x) mean_out[i] = __builtin_nanf("");
         return;
     }
-    const int nfail = (int)tp->fail_count;
+    const int nfail = (int)tp->fail2_count;
     if (nfail == 0) return;
     const int lane = lane_id();
     const int wv = uniform((int)(threadIdx.x >> 6));
     TNode *stack = s_stack[wv];
     double *out = s_out[wv];
+    double *cand = s_cand[wv];
     const int n = tp->n;
     const double od[3] = {tp->ox, tp->oy, tp->oz};
     const double s = tp->s, inv_s = tp->inv_s, slack = tp->slack;
     const int g = lane >> 3, u = lane & 7;
 
     WorkQueue wq;
-    wq_init(wq, tp->fail_ctr, nfail, TREE_THREADS / 64);
+    wq_init(wq, tp->fail2_ctr, nfail, TREE_THREADS / 64);
     for (;;) {
         const int item = uniform(wq_next(wq));
         if (item < 0) break;
@@ -709,46 +949,39 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
         const double qd[3] = {(double)qp.x, (double)qp.y, (double)qp.z};
         const double bound = failbound[item];
         double R = bound >= 0.0 ? __dsqrt_rn(bound) * (1.0 + 1e-9) + 4.0 * slack : __dsqrt_rn(-bound);
+        bool known = bound >= 0.0;   // the bound is used for the first pass only (it cannot fail; if it did, plain doubling takes over)
 
+        // Two ways through a pass.  COLLECT (first): every point inside the certifiable ball goes to an LDS buffer, and the k
+        // nearest are picked by rank afterwards -- a query that just missed in knn_leaf has a bound a few neighbours wide, so
+        // the buffer holds ~k..2k values and nothing is kept sorted on the way.  INSERT (when the buffer overflows: a ball that
+        // reaches into a much denser region): the sorted list, one entry per lane, whose k-th entry prunes the descent.
+        bool insert_mode = !known;   // a radius to try comes from knn_tree_near, which has done the collecting already
         for (;;) {   // one pass per search radius (a known bound needs exactly one)
-            // the smallest octree node that contains the ball's box (one fine cell of margin against the cell rounding)
-            unsigned cl[3], ch[3];
+            // The ball's box (one fine cell of margin against the cell rounding) is covered by at most 3^3 cells whose edge is at
+            // least R + s: these are the roots of the descent -- NOT their common ancestor, which is the whole cloud whenever the
+            // box straddles a high-level boundary of the octree (measured: most descents started from nodes of 10^5..10^7 points).
+            int Lg = 0;
+            while (Lg < TB && s * (double)(1u << Lg) < R + s) ++Lg;   // box width 2 R + 2 s <= 2 cells: it meets at most 3 per axis
+            const bool whole = Lg >= TB;   // one cell: the whole cloud
+            const double gedge = s * (double)(1u << Lg);
+            int c0[3], nc[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const double tl = ((qd[a] - R) - od[a]) * inv_s - 1.0, th = ((qd[a] + R) - od[a]) * inv_s + 1.0;
-                cl[a] = (unsigned)fmin(fmax(tl, 0.0), (double)((1 << TB) - 1));
-                ch[a] = (unsigned)fmin(fmax(th, 0.0), (double)((1 << TB) - 1));
+                const unsigned l = (unsigned)fmin(fmax(tl, 0.0), (double)((1 << TB) - 1)) >> Lg;
+                const unsigned h = (unsigned)fmin(fmax(th, 0.0), (double)((1 << TB) - 1)) >> Lg;
+                c0[a] = uniform((int)l);
+                nc[a] = uniform((int)(h - l) + 1);
             }
-            const unsigned long long klo = morton63(cl[0], cl[1], cl[2]), khi = morton63(ch[0], ch[1], ch[2]);
-            const unsigned long long df = klo ^ khi;
-            const int lst_level = df ? (63 - __builtin_clzll(df)) / 3 + 1 : 0;   // 0 .. 21
-            const bool whole = lst_level >= TB;
-            TNode root;
-            root.level = lst_level;
-            root.code = whole ? 0ULL : klo >> (3 * lst_level);
-            root.mind2 = 0.0;
-            if (whole) {
-                root.lo = 0;
-                root.hi = (unsigned)n;
-            } else {
-                root.lo = wave_lower_bound(keys, 0u, (unsigned)n, root.code << (3 * lst_level), lane);
-                root.hi = wave_lower_bound(keys, root.lo, (unsigned)n, (root.code + 1) << (3 * lst_level), lane);
-            }
-            // everything outside that node is farther than rc (the whole cloud: nothing is outside)
-            double rc = __builtin_inf();
-            if (!whole) {
-                const unsigned nc[3] = {compact21(root.code), compact21(root.code >> 1), compact21(root.code >> 2)};
-                const double side = s * (double)(1u << lst_level);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (nc[a] > 0) rc = fmin(rc, (qd[a] - (od[a] + (double)nc[a] * side)) - slack);
-                    if ((nc[a] + 1u) < (1u << (TB - lst_level))) rc = fmin(rc, ((od[a] + (double)(nc[a] + 1u) * side) - qd[a]) - slack);
-                }
-                rc = fmax(rc, 0.0);
-            }
-            // points beyond rc cannot be certified in this pass anyway; a known bound on the k-th distance is tighter still
-            double T0 = whole ? __builtin_inf() : rc * rc;
-            if (bound >= 0.0) T0 = fmin(T0, bound);
+            const int total = nc[0] * nc[1] * nc[2];   // <= 27: one lane each
+            const double rc = whole ? __builtin_inf() : R;
+            // points beyond the certified radius are of no use to this pass; a known bound on the k-th distance is tighter still
+            const double rcert = fmin(R - 2.0 * slack, rc);
+            double T0 = whole ? __builtin_inf() : rcert * rcert;
+            if (known) T0 = fmin(T0, bound);
+            known = false;
+            int M = 0;              // collected candidates (wave-uniform)
+            bool overflow = false;
 
             double best = __builtin_inf();   // lane j: j-th smallest squared distance so far (the query itself excluded)
             asm volatile("" : "+v"(best));   // opaque: see kv
@@ -757,8 +990,48 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
             // register then holds 0: measured)
             double kv = bcast_f64(best, k - 1);
             int sp = 0;
-            if (lane == 0) stack[0] = root;
-            sp = 1;
+            {
+                const int c = lane;
+                const bool valid = c < total;
+                const int iz = c / (nc[0] * nc[1]), rem = c - iz * nc[0] * nc[1], iy = rem / nc[0], ix = rem - iy * nc[0];
+                const unsigned X[3] = {(unsigned)(c0[0] + ix), (unsigned)(c0[1] + iy), (unsigned)(c0[2] + iz)};
+                double m2 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double plo = od[a] + (double)X[a] * gedge, phi = od[a] + (double)(X[a] + 1u) * gedge;
+                    const double dd = fmax(fmax((plo - qd[a]) - slack, (qd[a] - phi) - slack), 0.0);
+                    m2 += dd * dd;
+                }
+                m2 *= (1.0 - 1e-14);
+                bool keep = valid && !(m2 > T0);
+                const unsigned long long code = keep ? morton63(X[0], X[1], X[2]) : 0ULL;
+                unsigned rlo = 0, rhi = 0;
+                if (whole) {
+                    rhi = keep ? (unsigned)n : 0u;
+                } else {
+                    cell_range(keys, samples, n, (n + KEY_BLOCK - 1) / KEY_BLOCK, keep, code, Lg, rlo, rhi);
+                }
+                keep = keep && rhi > rlo;
+                // nearest root on top of the stack: slot = number of kept roots that are farther (ties by lane)
+                int farther = 0, nkept = 0;
+                for (int o = 0; o < total; ++o) {
+                    const double om = __shfl(m2, o);
+                    const int ok = __shfl((int)keep, o);
+                    nkept += ok;
+                    farther += (ok && (om > m2 || (om == m2 && o > lane))) ? 1 : 0;
+                }
+                if (keep) {
+                    TNode nd;
+                    nd.lo = rlo;
+                    nd.hi = rhi;
+                    nd.code = code;
+                    nd.mind2 = m2;
+                    nd.level = Lg;
+                    nd.pad = 0;
+                    stack[farther] = nd;
+                }
+                sp = uniform(nkept);
+            }
             wave_sync();
             while (sp > 0) {
                 --sp;
@@ -766,28 +1039,53 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                 const unsigned nlo = (unsigned)uniform((int)nd.lo), nhi = (unsigned)uniform((int)nd.hi);
                 const int level = uniform(nd.level);
                 const double md = bcast_f64(nd.mind2, 0);
-                if (md > T0 || md >= kv) continue;
+                if (md > T0 || (insert_mode && md >= kv)) continue;
                 const unsigned cnt = nhi - nlo;
-                if (cnt <= (unsigned)TQ_SCAN || level == 0) {
-                    // ---- scan: 64 points at a time; the nearest candidate below the running k-th distance is inserted first
-                    for (unsigned b = nlo; b < nhi; b += 64u) {
-                        const unsigned j = b + (unsigned)lane;
-                        bool have = j < nhi;
-                        const float4 p = refs[have ? j : nlo];
-                        const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
-                        have = have && __float_as_uint(p.w) != self_w && d <= T0;
-                        for (;;) {
-                            const bool cand = have && d < kv;
-                            if (!__any(cand)) break;
-                            const double dm = wave_min_f64_(cand ? d : __builtin_inf());
-                            const unsigned long long pick = __ballot(cand && d == dm);
-                            const int src = (int)__builtin_ctzll(pick);
-                            if (lane == src) have = false;
-                            const int pos = (int)__popcll(__ballot(best <= dm));
-                            const double up = __shfl_up(best, 1);
-                            best = lane < pos ? best : (lane == pos ? dm : up);
-                            kv = bcast_f64(best, k - 1);
+                // Once the list is full a node's box often undercuts the k-th distance while none of its points does (a far query's
+                // ball grazes a dense face: a thin cap through hundreds of small nodes): scanning a node of up to 2048 points then
+                // costs one round of loads, descending through it a dozen dependent ones.
+                const unsigned scan_cap = (insert_mode && kv < 1e300) ? 2048u : (unsigned)TQ_SCAN;
+                if (cnt <= scan_cap || level == 0) {
+                    // ---- scan: 4 x 64 points in flight; the nearest candidate below the running k-th distance is inserted first
+                    for (unsigned b4 = nlo; b4 < nhi; b4 += 256u) {
+                        float4 p4[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const unsigned j = b4 + 64u * (unsigned)v + (unsigned)lane;
+                            p4[v] = refs[j < nhi ? j : nlo];
                         }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const unsigned j = b4 + 64u * (unsigned)v + (unsigned)lane;
+                            if (b4 + 64u * (unsigned)v >= nhi) break;   // wave-uniform
+                            const float4 p = p4[v];
+                            const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                            bool have = j < nhi && __float_as_uint(p.w) != self_w && d <= T0;
+                            if (!insert_mode) {
+                                const unsigned long long hb = __ballot(have);
+                                const int at = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u));
+                                if (have && at < TQ_CAND) cand[at] = d;
+                                M += (int)__popcll(hb);
+                            } else {
+                                for (;;) {
+                                    const bool cnd = have && d < kv;
+                                    if (!__any(cnd)) break;
+                                    const double dm = wave_min_f64_(cnd ? d : __builtin_inf());
+                                    const unsigned long long pick = __ballot(cnd && d == dm);
+                                    const int src = (int)__builtin_ctzll(pick);
+                                    if (lane == src) have = false;
+                                    const int pos = (int)__popcll(__ballot(best <= dm));
+                                    const double up = __shfl_up(best, 1);
+                                    best = lane < pos ? best : (lane == pos ? dm : up);
+                                    kv = bcast_f64(best, k - 1);
+                                }
+                            }
+                        }
+                        if (!insert_mode && M > TQ_CAND) break;   // wave-uniform: the buffer is full
+                    }
+                    if (M > TQ_CAND) {   // wave-uniform
+                        overflow = true;
+                        break;
                     }
                 } else {
                     // ---- split: the 7 inner boundaries of the node's 8 children, one 8-lane group each (8 probes per round)
@@ -831,7 +1129,7 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                         m2 += dd * dd;
                     }
                     m2 *= (1.0 - 1e-14);
-                    const bool keep = chi > clo && !(m2 > T0) && m2 < kv;
+                    const bool keep = chi > clo && !(m2 > T0) && (!insert_mode || m2 < kv);
                     // nearest child on top of the stack: slot = number of kept children that are farther (ties by index)
                     int farther = 0, nkept = 0;
 #pragma unroll
@@ -855,8 +1153,41 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                     wave_sync();
                 }
             }
-            // certified iff k neighbours were found inside the radius the pass covered
-            const double rcert = fmin(R - 2.0 * slack, rc);
+            if (!insert_mode) {
+                if (overflow) {   // same radius again, with the pruning list
+                    insert_mode = true;
+                    continue;
+                }
+                if (M >= k) {
+                    // every collected value is <= T0 <= rcert^2: the k smallest are the answer.  rank = values before mine
+                    wave_sync();
+                    double kth2 = 0.0;
+                    for (int i0 = 0; i0 < M; i0 += 64) {
+                        const int i = i0 + lane;
+                        const double ci = i < M ? cand[i] : __builtin_inf();
+                        int rank = 0;
+                        for (int j = 0; j < M; ++j) {
+                            const double cj = cand[j];   // same address in every lane
+                            rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
+                        }
+                        if (i < M && rank < k) out[rank] = __dsqrt_rn(ci);
+                        const unsigned long long last = __ballot(i < M && rank == k - 1);
+                        if (last) kth2 = bcast_f64(ci, (int)__builtin_ctzll(last));
+                    }
+                    wave_sync();
+                    if (lane == 0) {
+                        const int qorig = (int)(self_w & 0x7fffffffu) - q_begin;
+                        const double sum = pairwise_sum_le128([&](int i) { return out[i]; }, k);
+                        mean_out[qorig] = __double2float_rn(__ddiv_rn(sum, (double)k));
+                        if (kth_out) kth_out[qorig] = kth2;
+                    }
+                    wave_sync();
+                    break;
+                }
+                R *= 2.0;   // fewer than k points inside the ball (a whole-cloud pass always has them: n > k)
+                continue;
+            }
+            // INSERT mode: certified iff k neighbours were found inside the radius the pass covered
             if (whole || kv <= rcert * rcert) {
                 if (lane < 64) out[lane] = __dsqrt_rn(best);
                 wave_sync();
@@ -892,7 +1223,7 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_
     const char *rf = getenv("GSX_TREE_RF");
     const float rf_scale = rf ? (float)atof(rf) : 1.1f;
     hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
-                       w.keys[1].as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
+                       w.keys[1].as<unsigned long long>(), w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
                        w.leafbl.as<unsigned char>(), k, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
                        w.faillist.as<unsigned>(), w.failbound.as<double>());
     GSX_HIP(hipGetLastError());
@@ -906,6 +1237,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     if (n_ref < 1 || n_ref > (int64_t)INT32_MAX - 64) GSX_FAIL("sor (tree): n=%lld out of range", (long long)n_ref);
     if (n_ref <= k) GSX_FAIL("sor (tree): k=%d needs more than %lld points", k, (long long)n_ref);
     TreeWs &w = ctx->tree_ws;
+    ctx->last_knn_algo = GSX_KNN_TREE;
     const size_t n = (size_t)n_ref;
     const int ntiles = div_up(n_ref, LEAF_TILE);
     const int bbox_blocks = std::min(tree_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
@@ -914,13 +1246,14 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
         GSX_CHECK(w.vals[b].reserve(sizeof(unsigned) * n));
     }
     GSX_CHECK(w.refs.reserve(sizeof(float4) * n));
+    GSX_CHECK(w.samples.reserve(sizeof(unsigned long long) * (n / KEY_BLOCK + 2)));
     GSX_CHECK(w.flags.reserve(n));
     GSX_CHECK(w.tilecnt.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
     GSX_CHECK(w.tileoff.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
     GSX_CHECK(w.leafstart.reserve(sizeof(unsigned) * (n + 1)));
     GSX_CHECK(w.leafbl.reserve(n));
-    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * n));
-    GSX_CHECK(w.failbound.reserve(sizeof(double) * n));
+    GSX_CHECK(w.faillist.reserve(sizeof(unsigned) * 2 * n));    // knn_leaf's list | knn_tree_near's leftovers
+    GSX_CHECK(w.failbound.reserve(sizeof(double) * 2 * n));
     GSX_CHECK(w.bboxpart.reserve(sizeof(float) * 7 * (size_t)bbox_blocks));
     if (!w.params.p) {
         GSX_CHECK(w.params.reserve(sizeof(TreeParams)));
@@ -944,6 +1277,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_HIP(rocprim::radix_sort_pairs(w.temp.p, t_sort, k0, k1, v0, v1, n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(tree_gather_kernel, dim3(tree_blocks(ctx, n_ref, 2)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        v1, w.refs.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
+    hipLaunchKernelGGL(tree_samples_kernel, dim3(tree_blocks(ctx, n_ref / KEY_BLOCK + 1, 1)), dim3(256), 0, ctx->stream, k1, (int)n_ref,
+                       w.samples.as<unsigned long long>());
     hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, w.flags.as<unsigned char>(),
                        tilecnt);
     GSX_HIP(hipGetLastError());
@@ -961,8 +1296,12 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
-    hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 4), dim3(TREE_THREADS), 0, ctx->stream, tp, k1, w.refs.as<float4>(),
-                       w.faillist.as<unsigned>(), w.failbound.as<double>(), k, (int)q_begin, (int)q_count, mean_out, kth_out);
+    hipLaunchKernelGGL(knn_tree_near_kernel, dim3(ctx->num_cu * 6), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
+                       w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.faillist.as<unsigned>(), w.failbound.as<double>(), k,
+                       (int)q_begin, mean_out, kth_out, w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n);
+    hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 4), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
+                       w.samples.as<unsigned long long>(), w.refs.as<float4>(),
+                       w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n, k, (int)q_begin, (int)q_count, mean_out, kth_out);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
 
@@ -971,8 +1310,11 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
         GSX_HIP(hipMemcpyAsync(&h, tp, sizeof(TreeParams), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
         if (getenv("GSX_TRACE_LEVELS"))
-            fprintf(stderr, "[gsx] tree: n=%d fine cell %g leaves=%u (%.1f points each) fallback queries=%u\n", h.n, h.s, h.nleaves,
-                    h.nleaves ? (double)h.n / h.nleaves : 0.0, h.fail_count);
+            fprintf(stderr, "[gsx] tree: n=%d fine cell %g leaves=%u (%.1f points each) fallback queries=%u, of which descents=%u\n", h.n,
+                    h.s, h.nleaves, h.nleaves ? (double)h.n / h.nleaves : 0.0, h.fail_count, h.fail2_count);
+        if (getenv("GSX_TRACE_LEVELS"))
+            fprintf(stderr, "[gsx] near: cells>512 %u, dense cell %u (attempt 0/1/2: %u %u %u), M>cap %u, M<k %u, bound M<k %u\n", h.dbg[0], h.dbg[1],
+                    h.dbg[5], h.dbg[6], h.dbg[7], h.dbg[2], h.dbg[3], h.dbg[4]);
         if (h.bad_input) return gsx_ctx_check(ctx);
         if (info) {
             info->algo = GSX_KNN_TREE;
@@ -981,7 +1323,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
             info->n_cells = 0;
             info->n_bricks = h.nleaves;
             info->n_fallback = h.fail_count;
-            info->n_exhaustive = 0;
+            info->n_exhaustive = h.fail2_count;
             info->n_deferred_bricks = 0;
             info->n_refined = 0;
         }
@@ -999,6 +1341,7 @@ int knn_tree_info(gsx_ctx *ctx, gsx_sor_info *info)
     info->cell_size = (float)h.s;
     info->n_bricks = h.nleaves;
     info->n_fallback = h.fail_count;
+    info->n_exhaustive = h.fail2_count;
     return 0;
 }
 
