@@ -19,7 +19,8 @@ uniform grid is bad at -- each with its own roofline and CPU baseline:
                   both filters (configs[2]; the device chain `install()` gives the reference's orchestrator)
     config4       10M-splat SOG SH-palette K-Means (configs[4]: 64 chunks x (156 250 x 45), K=1024, 10 iterations)
     host_to_host  the 10M SOR call from a contiguous host xyz array to a host mask (gsx_sor_filter, PCIe included)
-    clustered_1m / floaters_10m   Gaussian blobs of very different density / a scene + 0.5 % far floaters (adaptive grid)
+    clustered_1m / floaters_10m   Gaussian blobs of very different density / a scene + 0.5 % far floaters (adaptive mode:
+                  the Morton-tree path)
 The N=1 run does not import torch: device memory comes from gsx_dev_malloc / gsx_dev_upload (include/gsx_hip.h), the
 clock is time.perf_counter around gsx_ctx_synchronize.  With N > 1 torch.distributed hands out the RCCL unique id and
 provides the barrier around the timed region; the data path is the C library's.  Prints ONE JSON line (rank 0).
@@ -481,17 +482,21 @@ def main_single(args):
         def clustered():
             xc = synth_clustered(1_000_000, 0)
             r = run_sor(L, ctx, xc, args.k, args.sigma, small, 2, cpu=want_cpu, adaptive=True)
-            r["workload"] = "1000000 splats in six Gaussian blobs (sigma 0.05...1.5) + 2 %% far flyers, SOR k=%d, adaptive grid" % args.k
+            r["workload"] = ("1000000 splats in six Gaussian blobs (sigma 0.05...1.5) + 2 %% far flyers, SOR k=%d, adaptive mode "
+                             "(routed to the Morton-tree path, csrc/sor_tree.hip)" % args.k)
             r["roofline"] = sor_roofline(1_000_000, args.k, r["knn_kernel_ms"], single=False)
-            r["roofline"]["note"] = "knn_brick launches of all refinement levels together; " + r["roofline"]["note"]
+            r["roofline"]["kernel"] = "knn_leaf_kernel<17>"
+            r["roofline"]["note"] = "knn_leaf (one wave per Morton leaf), priced like knn_brick; " + r["roofline"]["note"]
             return r
 
         def floaters():
             xf = synth_scene_with_floaters(args.n, 0)
             r = run_sor(L, ctx, xf, args.k, args.sigma, small, 2, cpu=want_cpu, adaptive=True)
-            r["workload"] = "%d splats: a 10^3 scene + 0.5 %% floaters in a 1000^3 box, SOR k=%d, adaptive grid" % (args.n, args.k)
+            r["workload"] = ("%d splats: a 10^3 scene + 0.5 %% floaters in a 1000^3 box, SOR k=%d, adaptive mode (routed to the "
+                             "Morton-tree path, csrc/sor_tree.hip)" % (args.n, args.k))
             r["roofline"] = sor_roofline(args.n, args.k, r["knn_kernel_ms"], single=False)
-            r["roofline"]["note"] = "knn_brick launches of all refinement levels together; " + r["roofline"]["note"]
+            r["roofline"]["kernel"] = "knn_leaf_kernel<17>"
+            r["roofline"]["note"] = "knn_leaf (one wave per Morton leaf), priced like knn_brick; " + r["roofline"]["note"]
             return r
 
         attempt("config1", config1)

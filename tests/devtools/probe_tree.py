@@ -1,5 +1,5 @@
 """GPU box: the Morton-tree KNN (algo 3, csrc/sor_tree.hip) against cKDTree on small clouds, then timings on the clouds a
-uniform grid is bad at.    python tools/probe_tree.py [check|time] ..."""
+uniform grid is bad at.    python tests/devtools/probe_tree.py [check|time] ..."""
 import importlib
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
