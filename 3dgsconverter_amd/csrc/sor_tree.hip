@@ -9,7 +9,9 @@
 //   tree_bbox            bounding box -> origin, fine cell edge s = extent / 2^21                      (one pass)
 //   tree_keys            63-bit Morton key of every point's fine cell                                  (one pass)
 //   rocprim radix sort   (key, index) pairs
-//   tree_gather          float4 {x, y, z, index} in key order
+//   tree_gather, tree_samples
+//                        float4 {x, y, z, index} in key order; the last key of every 32-key block (cache resident: the range
+//                        look-ups below search it first)
 //   tree_leaf_flags / tree_leaf_compact
 //                        LEAVES: the largest nodes of the implicit binary radix tree (a node = all keys sharing the bits
 //                        above bit level b: a box with sides 1:1:1, 2:1:1 or 2:2:1) that hold at most 64 points.  Found
@@ -22,9 +24,13 @@
 //                        (phase 1), per-lane walk of the mask words with exact float64 distances and sorting-network
 //                        selection (phase 2), numpy's summation order in the epilogue.  A query is exact iff its k-th
 //                        neighbour is nearer than the nearest face of the searched box that has space behind it.
-//   knn_tree_query       the queries knn_leaf could not certify (sparse leaves next to dense ones, the rim of the cloud):
-//                        one wave per query, nearest-first descent of the implicit octree below the smallest node that
-//                        contains the query's ball, pruned by the running k-th distance; the list lives one entry per lane.
+//   knn_tree_near        the queries knn_leaf could not certify (the rim of an object, leaves of ~5 points per cell): one wave
+//                        per query, the ball of a radius to try covered by key-range cells, the points inside collected in
+//                        LDS, the k nearest taken by rank.
+//   knn_tree_query       what is left (a ball that reaches into a much denser region, sparse surroundings): nearest-first
+//                        descent of the implicit octree below the cells that cover the ball, pruned by the running k-th
+//                        distance; the list lives one entry per lane.
+// Adaptive mode (sor_grid.hip: knn_grid_level) routes a cloud here when the coarse histogram of the grid's own sort is uneven.
 //
 // Exactness of the geometry: a point's fine cell is floor((x - o) * inv_s) evaluated in float64 -- monotone in x -- so all
 // points of cells >= c along an axis lie at x >= o + c*s up to ~1e-15 relative; every plane distance used as a guarantee is
@@ -44,7 +50,6 @@
 namespace gsx {
 
 constexpr int TB = 21;                 // key bits per axis
-constexpr int TREE_TOP = 3 * TB;       // bit level of the root (all 63 key bits free)
 constexpr int LEAF_CAP = 64;           // points per leaf = lanes of a wave
 constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 #ifndef GSX_TWCAP
@@ -78,7 +83,8 @@ struct TreeParams {
     unsigned pad;
     unsigned fail2_count;  // queries knn_tree_near handed on to knn_tree_query
     unsigned pad2;
-    unsigned dbg[8];
+    unsigned defer_why[8];   // knn_tree_near's reasons for handing a query on (trace output only): 0 too many cells, 1 dense cell,
+                             // 2 buffer full, 3 / 4 fewer than k points inside the last radius tried / inside a known bound, 5-7 attempt
     unsigned leaf_ctr[8 * 32];
     unsigned fail_ctr[8 * 32];
     unsigned fail2_ctr[8 * 32];
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
     tp->nleaves = 0;
     tp->fail_count = 0;
     tp->fail2_count = 0;
-    for (int i = 0; i < 8; ++i) tp->dbg[i] = 0;
+    for (int i = 0; i < 8; ++i) tp->defer_why[i] = 0;
     if (v[6] != 0.0f) atomicOr(devflags, 1u);
 }
 
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
             }
             const int total = nc[0] * nc[1] * nc[2];
             defer = total > 512;
-            if (defer && lane == 0) atomicAdd(&tp->dbg[0], 1u);
+            if (defer && lane == 0) atomicAdd(&tp->defer_why[0], 1u);
             if (lane == 0) *cnt = 0u;
             wave_sync();
             for (int cb = 0; cb < total && !defer; cb += 64) {
@@ -852,8 +858,8 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
                 const unsigned len = b0 - a0;
                 if (__any(len > 64u)) {   // a cell far denser than the ball's own neighbourhood: the pruning descent's job
                     defer = true;
-                    if (lane == 0) atomicAdd(&tp->dbg[1], 1u);
-                    if (lane == 0) atomicAdd(&tp->dbg[5 + min(attempt, 2)], 1u);
+                    if (lane == 0) atomicAdd(&tp->defer_why[1], 1u);
+                    if (lane == 0) atomicAdd(&tp->defer_why[5 + min(attempt, 2)], 1u);
                     break;
                 }
                 for (unsigned j = 0; j < len; ++j) {   // a handful of points per cell
@@ -868,13 +874,13 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
             wave_sync();
             M = uniform((int)*cnt);
             if (defer || M > TQ_CAND) {
-                if (!defer && lane == 0) atomicAdd(&tp->dbg[2], 1u);
+                if (!defer && lane == 0) atomicAdd(&tp->defer_why[2], 1u);
                 defer = true;
                 break;
             }
             if (M >= k) break;
             if (bound >= 0.0 || attempt == 2) {
-                if (lane == 0) atomicAdd(&tp->dbg[bound >= 0.0 ? 4 : 3], 1u);
+                if (lane == 0) atomicAdd(&tp->defer_why[bound >= 0.0 ? 4 : 3], 1u);
                 defer = true;
                 break;
             }
@@ -1313,8 +1319,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
             fprintf(stderr, "[gsx] tree: n=%d fine cell %g leaves=%u (%.1f points each) fallback queries=%u, of which descents=%u\n", h.n,
                     h.s, h.nleaves, h.nleaves ? (double)h.n / h.nleaves : 0.0, h.fail_count, h.fail2_count);
         if (getenv("GSX_TRACE_LEVELS"))
-            fprintf(stderr, "[gsx] near: cells>512 %u, dense cell %u (attempt 0/1/2: %u %u %u), M>cap %u, M<k %u, bound M<k %u\n", h.dbg[0], h.dbg[1],
-                    h.dbg[5], h.dbg[6], h.dbg[7], h.dbg[2], h.dbg[3], h.dbg[4]);
+            fprintf(stderr, "[gsx] near: cells>512 %u, dense cell %u (attempt 0/1/2: %u %u %u), M>cap %u, M<k %u, bound M<k %u\n", h.defer_why[0], h.defer_why[1],
+                    h.defer_why[5], h.defer_why[6], h.defer_why[7], h.defer_why[2], h.defer_why[3], h.defer_why[4]);
         if (h.bad_input) return gsx_ctx_check(ctx);
         if (info) {
             info->algo = GSX_KNN_TREE;

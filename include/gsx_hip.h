@@ -91,10 +91,12 @@ int  gsx_ctx_set_timing(gsx_ctx *ctx, int enable);
 int  gsx_ctx_reset_timing(gsx_ctx *ctx);
 /* synchronises, then returns the number of recorded launches and their summed duration */
 int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *total_ms);
-/* knobs: "grid_points_per_cell" (0 = auto), "brute_below", "adaptive" (1: bricks of the KNN grid whose
- * neighbourhood is far denser than the cell size are re-run on a finer grid built for them; costs
- * one host synchronisation inside gsx_sor_knn_dev, so it is ON for the host entry point
- * gsx_sor_filter and OFF by default for contexts driven through the asynchronous _dev calls),
+/* knobs: "grid_points_per_cell" (0 = auto), "brute_below", "adaptive" (1: a cloud that no single grid
+ * resolves -- its coarse histogram is uneven: a scene inside a box inflated by floaters, blobs of very
+ * different density -- takes the Morton-tree path, csrc/sor_tree.hip; costs one host synchronisation
+ * inside gsx_sor_knn_dev, so it is ON for the host entry point gsx_sor_filter and OFF by default for
+ * contexts driven through the asynchronous _dev calls), "tree" (default 1; 0: adaptive mode refines the
+ * grid level by level instead, DESIGN.md 5.5 -- kept for A/B and used by the replicated multi-GPU shares),
  * "filter_mfma" (1 = matrix-core phase-1 filter, default), "timing_mask" (bit s set = slot
  * GSX_T_s records events while timing is enabled; default all -- every event pair costs stream time),
  * "debug_skip" (profiling only) */
