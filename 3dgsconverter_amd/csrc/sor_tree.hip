@@ -67,7 +67,7 @@ constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag 
 constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points hands its queries to knn_tree_query
 constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small array (2.5 MB at 10M points: cache resident) that the
                                        // range look-ups search first; only the last 5 steps touch the 80 MB key array
-constexpr int TQ_STACK = 192;          // 27 roots + 21 levels x 7 siblings
+constexpr int TQ_STACK = 256;          // pending nodes of a descent (best-first: the frontier of the ball, typically a few dozen)
 constexpr int TQ_SCAN = 256;           // a node with at most this many points is scanned, not split
 constexpr int TQ_CAND = 256;           // candidates inside the search ball a wave collects before it ranks them
 
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
     }
 }
 
-__global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
+__global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
     TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
     const float4 *__restrict__ refs,
     const unsigned *__restrict__ faillist, const double *__restrict__ failbound, int k, int q_begin, int out_count,
@@ -962,7 +962,15 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
         // the buffer holds ~k..2k values and nothing is kept sorted on the way.  INSERT (when the buffer overflows: a ball that
         // reaches into a much denser region): the sorted list, one entry per lane, whose k-th entry prunes the descent.
         bool insert_mode = !known;   // a radius to try comes from knn_tree_near, which has done the collecting already
+#ifdef GSX_TREE_PROFILE
+        const unsigned long long t_begin = wall_clock64();
+        int p_pass = 0, p_pop = 0, p_scan = 0, p_split = 0;
+        long long p_pts = 0;
+#endif
         for (;;) {   // one pass per search radius (a known bound needs exactly one)
+#ifdef GSX_TREE_PROFILE
+            ++p_pass;
+#endif
             // The ball's box (one fine cell of margin against the cell rounding) is covered by at most 3^3 cells whose edge is at
             // least R + s: these are the roots of the descent -- NOT their common ancestor, which is the whole cloud whenever the
             // box straddles a high-level boundary of the octree (measured: most descents started from nodes of 10^5..10^7 points).
@@ -1018,14 +1026,8 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                     cell_range(keys, samples, n, (n + KEY_BLOCK - 1) / KEY_BLOCK, keep, code, Lg, rlo, rhi);
                 }
                 keep = keep && rhi > rlo;
-                // nearest root on top of the stack: slot = number of kept roots that are farther (ties by lane)
-                int farther = 0, nkept = 0;
-                for (int o = 0; o < total; ++o) {
-                    const double om = __shfl(m2, o);
-                    const int ok = __shfl((int)keep, o);
-                    nkept += ok;
-                    farther += (ok && (om > m2 || (om == m2 && o > lane))) ? 1 : 0;
-                }
+                // the pending nodes are an unordered set: the nearest is looked for at every step
+                const unsigned long long kb = __ballot(keep);
                 if (keep) {
                     TNode nd;
                     nd.lo = rlo;
@@ -1034,24 +1036,49 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                     nd.mind2 = m2;
                     nd.level = Lg;
                     nd.pad = 0;
-                    stack[farther] = nd;
+                    stack[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))] = nd;
                 }
-                sp = uniform(nkept);
+                sp = (int)__popcll(kb);
             }
             wave_sync();
             while (sp > 0) {
+                // BEST-FIRST: the pending node nearest to the query (a last-in-first-out stack dives to the bottom of the first
+                // dense subtree it meets: a floater 60 units from a scene scanned 330 nodes / 175 000 points of the scene's face
+                // before it ever looked at the floaters 40 units away that are its neighbours -- 2 ms for one query)
+                int mi = -1;
+                double mv = __builtin_inf();
+                for (int i = lane; i < sp; i += 64) {
+                    const double v = stack[i].mind2;
+                    if (v < mv) {
+                        mv = v;
+                        mi = i;
+                    }
+                }
+                const double gmin = wave_min_f64_(mv);
+                const unsigned long long who = __ballot(mi >= 0 && mv == gmin);
+                if (!who) break;   // (cannot happen: sp > 0 and no NaN)
+                const int pick = __shfl(mi, (int)__builtin_ctzll(who));
+                const TNode nd = stack[pick];   // same address in every lane
                 --sp;
-                const TNode nd = stack[sp];   // same address in every lane
+                wave_sync();
+                if (lane == 0 && pick != sp) stack[pick] = stack[sp];
+                wave_sync();
                 const unsigned nlo = (unsigned)uniform((int)nd.lo), nhi = (unsigned)uniform((int)nd.hi);
                 const int level = uniform(nd.level);
                 const double md = bcast_f64(nd.mind2, 0);
-                if (md > T0 || (insert_mode && md >= kv)) continue;
+#ifdef GSX_TREE_PROFILE
+                ++p_pop;
+#endif
+                if (md > T0 || (insert_mode && md >= kv)) break;   // every other pending node is at least as far
                 const unsigned cnt = nhi - nlo;
+#ifdef GSX_TREE_PROFILE
+                if (cnt <= ((insert_mode && kv < 1e300) ? 2048u : (unsigned)TQ_SCAN) || level == 0) { ++p_scan; p_pts += cnt; } else ++p_split;
+#endif
                 // Once the list is full a node's box often undercuts the k-th distance while none of its points does (a far query's
                 // ball grazes a dense face: a thin cap through hundreds of small nodes): scanning a node of up to 2048 points then
                 // costs one round of loads, descending through it a dozen dependent ones.
                 const unsigned scan_cap = (insert_mode && kv < 1e300) ? 2048u : (unsigned)TQ_SCAN;
-                if (cnt <= scan_cap || level == 0) {
+                if (cnt <= scan_cap || level == 0 || sp > TQ_STACK - 8) {   // (a full set: scanning is slow but exact)
                     // ---- scan: 4 x 64 points in flight; the nearest candidate below the running k-th distance is inserted first
                     for (unsigned b4 = nlo; b4 < nhi; b4 += 256u) {
                         float4 p4[4];
@@ -1136,15 +1163,7 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                     }
                     m2 *= (1.0 - 1e-14);
                     const bool keep = chi > clo && !(m2 > T0) && (!insert_mode || m2 < kv);
-                    // nearest child on top of the stack: slot = number of kept children that are farther (ties by index)
-                    int farther = 0, nkept = 0;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const double om = __shfl(m2, 8 * c);
-                        const int ok = __shfl((int)keep, 8 * c);
-                        nkept += ok;
-                        farther += (ok && (om > m2 || (om == m2 && c > g))) ? 1 : 0;
-                    }
+                    const unsigned long long kb = __ballot(keep && u == 0);
                     if (keep && u == 0) {
                         TNode ch;
                         ch.lo = clo;
@@ -1153,9 +1172,9 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                         ch.mind2 = m2;
                         ch.level = level - 1;
                         ch.pad = 0;
-                        stack[sp + farther] = ch;
+                        stack[sp + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))] = ch;
                     }
-                    sp += uniform(nkept);
+                    sp += (int)__popcll(kb);
                     wave_sync();
                 }
             }
@@ -1202,6 +1221,10 @@ __global__ __launch_bounds__(TREE_THREADS, 4) void knn_tree_query_kernel(
                     const double sum = pairwise_sum_le128([&](int i) { return out[i]; }, k);
                     mean_out[qorig] = __double2float_rn(__ddiv_rn(sum, (double)k));
                     if (kth_out) kth_out[qorig] = kv;
+#ifdef GSX_TREE_PROFILE
+                    const unsigned long long dt = wall_clock64() - t_begin;
+                    if (dt > 20000ull) printf("slow descent: %.3f ms q=(%g %g %g) bound %g R %g kth %g passes %d pops %d scans %d splits %d points %lld\n", dt * 1e-5, qd[0], qd[1], qd[2], bound, R, sqrt(kv), p_pass, p_pop, p_scan, p_split, p_pts);
+#endif
                 }
                 wave_sync();
                 break;
@@ -1305,7 +1328,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(knn_tree_near_kernel, dim3(ctx->num_cu * 6), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
                        w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.faillist.as<unsigned>(), w.failbound.as<double>(), k,
                        (int)q_begin, mean_out, kth_out, w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n);
-    hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 4), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
+    hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 3), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
                        w.samples.as<unsigned long long>(), w.refs.as<float4>(),
                        w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n, k, (int)q_begin, (int)q_count, mean_out, kth_out);
     GSX_HIP(hipGetLastError());
