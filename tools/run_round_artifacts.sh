@@ -25,6 +25,12 @@ timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 -d $OUT/pmc_sq3_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 -d $OUT/pmc_sq4_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+# the clouds a uniform grid is bad at: adaptive mode -> Morton-tree path (csrc/sor_tree.hip)
+for C in "clustered 1000000" "floaters 10000000" "clustered 10000000"; do
+  set -- $C
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_tree_$1_$2 -o trace -- python $ROOT/tests/devtools/probe_tree.py time $1 $2 1 > $OUT/tree_trace_${R}_$1_$2.log 2>&1
+  python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_tree_$1_$2/trace_results.db > $OUT/kernel_stats_${R}_tree_$1_$2.txt 2>&1
+done
 cd $ROOT
 for T in "" _km _slab; do python tools/rocpd_summary.py $OUT/prof_${R}${T}/trace_results.db > $OUT/kernel_stats_${R}${T}.txt 2>&1; done
 python tools/rocpd_summary.py --pmc $OUT/pmc_fetch_${R}/pmc_results.db $OUT/pmc_write_${R}/pmc_results.db > $OUT/pmc_${R}_tcc.txt 2>&1
