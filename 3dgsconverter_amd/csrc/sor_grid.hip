@@ -2284,7 +2284,8 @@ int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z
 
 // csrc/sor_tree.hip: the path for clouds this grid cannot resolve
 int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
-                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from);
+                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from, int share,
+                    int nshares);
 
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
@@ -2399,7 +2400,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     // holds several times the average (a scene inside a box inflated by floaters: 2400x; Gaussian blobs: 30x+) goes to the
     // Morton-tree path (sor_tree.hip) at once -- no cell size fits it, and refining level by level costs a host round trip
     // and a re-binning per level (clustered 1M: 16.5 ms against 1.3 ms).
-    const bool tree_ok = adaptive && ctx->tree && level == 0 && nshares == 1 && kk <= 65 && n_ref > k;
+    const bool tree_ok = adaptive && ctx->tree && level == 0 && kk <= 65 && n_ref > k;
     bool hist_done = false;
     if (tree_ok) {
         unsigned *bk_cnt = w.bkcnt.as<unsigned>();
@@ -2421,7 +2422,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
             if (getenv("GSX_TRACE_LEVELS"))
                 fprintf(stderr, "[gsx] level 0: fullest bucket %u of %lld points in %u buckets -> tree path\n", mx, (long long)n_ref, nonzero);
-            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, slab ? ref_only_from : INT32_MAX);
+            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, share, nshares);
         }
     }
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr,
@@ -2478,11 +2479,12 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             fprintf(stderr, "[gsx] level %d: n=%lld h=%.5g dims=%dx%dx%d bricks=%d defer_words=%d deferred=%u extra=%u fail=%u\n", level,
                     (long long)n_ref, hgp.h, hgp.nx, hgp.ny, hgp.nz, hgp.nbricks, hgp.defer_words, hgp.deferred_count,
                     hgp.extra_count, hgp.fail_count);
-        if (hgp.deferred_count > 0 && !hgp.bad_input && tree_ok) {
+        if (hgp.deferred_count > 0 && !hgp.bad_input && tree_ok && nshares == 1) {   // (a share sees only ITS bricks: the ranks of a
+                                                                                    // replicated exchange could decide differently)
             // second decision: the histogram looked even, yet some bricks hold far more than their cells were sized for
             // (density varying inside the buckets).  The tree path takes the whole cloud over; this level's work is lost.
             if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level 0: %u deferred bricks -> tree path\n", hgp.deferred_count);
-            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX);
+            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, 0, 1);
         }
         if (hgp.deferred_count > 0 && !hgp.bad_input) {
             const unsigned nd = hgp.deferred_count;

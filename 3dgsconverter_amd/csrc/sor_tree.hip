@@ -397,7 +397,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
     const float4 *__restrict__ refs, const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k,
     int q_begin, int q_count, float rf_scale, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist,
-    double *__restrict__ failbound)
+    double *__restrict__ failbound, int share, int nshares)
 {
     constexpr int L = KCAP - 1;
     using Net = TopNet<L>;
@@ -418,11 +418,14 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
     const double ox = tp->ox, oy = tp->oy, oz = tp->oz, s = tp->s, slack = tp->slack;
 
+    // multi-GPU (replicated exchange): the leaves [part_lo, part_hi) are this rank's share -- a slab of the Morton order
+    const int part_lo = (int)(((long long)tp->nleaves * share) / nshares), part_hi = (int)(((long long)tp->nleaves * (share + 1)) / nshares);
     WorkQueue wq;
-    wq_init(wq, tp->leaf_ctr, (int)tp->nleaves, TREE_THREADS / 64);
+    wq_init(wq, tp->leaf_ctr, part_hi - part_lo, TREE_THREADS / 64);
     for (;;) {
-        const int item = uniform(wq_next(wq));
-        if (item < 0) break;
+        const int witem = uniform(wq_next(wq));
+        if (witem < 0) break;
+        const int item = witem + part_lo;
         const int ls = uniform((int)leafstart[item]), le = uniform((int)leafstart[item + 1]);
         const int bl = uniform((int)leafbl[item]);
         const int nq = le - ls;
@@ -1242,7 +1245,8 @@ static int tree_blocks(const gsx_ctx *ctx, int64_t n, int per_thread)
 }
 
 template <int KCAP>
-static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_t q_count, float *mean_out, double *kth_out)
+static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_t q_count, float *mean_out, double *kth_out, int share,
+                         int nshares)
 {
     static int occ = 0;
     if (!occ) {
@@ -1254,13 +1258,14 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_
     hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
                        w.keys[1].as<unsigned long long>(), w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
                        w.leafbl.as<unsigned char>(), k, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
-                       w.faillist.as<unsigned>(), w.failbound.as<double>());
+                       w.faillist.as<unsigned>(), w.failbound.as<double>(), share, nshares);
     GSX_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
-                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from)
+                    int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from, int share,
+                    int nshares)
 {
     if (k < 1 || k > 64) GSX_FAIL("sor (tree): k=%d not supported (1 <= k <= 64)", k);
     if (n_ref < 1 || n_ref > (int64_t)INT32_MAX - 64) GSX_FAIL("sor (tree): n=%lld out of range", (long long)n_ref);
@@ -1319,10 +1324,10 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
     const int kk = k + 1;
-    if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
-    else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
-    else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
-    else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out));
+    if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
     hipLaunchKernelGGL(knn_tree_near_kernel, dim3(ctx->num_cu * 6), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
