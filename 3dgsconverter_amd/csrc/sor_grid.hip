@@ -2389,8 +2389,10 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     unsigned *rstart = w.cellstart.as<unsigned>();
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
+    // (adaptive mode may still switch the deferral off below, once the histogram is known: defer_words is then cleared on the device)
     GridParamArgs gpa{(int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0, parent_h, gp,
                       ctx->devflags.as<unsigned>(), h_hint};
+    const bool adaptive_at_bbox = adaptive;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
     GSX_HIP(hipGetLastError());
@@ -2424,6 +2426,13 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
                 fprintf(stderr, "[gsx] level 0: fullest bucket %u of %lld points in %u buckets -> tree path\n", mx, (long long)n_ref, nonzero);
             return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, share, nshares);
         }
+        // an even histogram (fullest bucket within 1.5x of the average): no brick can be far over-full, so none is deferred and
+        // the host does not have to look at the counters again -- the call costs ONE synchronisation, as before the probe existed
+        if (nonzero > 0 && (double)mx <= 1.5 * (double)n_ref / (double)nonzero && nshares == 1) adaptive = false;
+    }
+    if (adaptive_at_bbox && !adaptive) {   // the grid parameters were written with deferral on
+        GSX_HIP(hipMemsetAsync(&gp->defer_words, 0, sizeof(int), ctx->stream));
+        GSX_HIP(hipMemsetAsync(&gp->heavy_limit, 0, sizeof(int), ctx->stream));
     }
     GSX_CHECK(bin_points(ctx, w, x, y, z, stride, 0, n_ref, gp, rstart, refs, cap, adaptive ? w.qcellstart.as<unsigned>() : nullptr,
                          slab ? ref_only_from : INT32_MAX, hist_done));
