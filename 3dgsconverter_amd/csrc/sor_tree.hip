@@ -69,6 +69,7 @@ constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small arr
                                        // range look-ups search first; only the last 5 steps touch the 80 MB key array
 constexpr int TQ_STACK = 256;          // pending nodes of a descent (best-first: the frontier of the ball, typically a few dozen)
 constexpr int TQ_SCAN = 256;           // a node with at most this many points is scanned, not split
+constexpr int TQ_DENSE = 4096;         // points of one cover cell knn_tree_near scans itself (more: handed on to the descent)
 constexpr int TQ_CAND = 256;           // candidates inside the search ball a wave collects before it ranks them
 
 struct TreeParams {
@@ -859,18 +860,32 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
                 unsigned a0, b0;
                 cell_range(keys, samples, n, nblk, keep, keep ? morton63(X[0], X[1], X[2]) : 0ULL, Lg, a0, b0);
                 const unsigned len = b0 - a0;
-                if (__any(len > 64u)) {   // a cell far denser than the ball's own neighbourhood: the pruning descent's job
+                if (__any(len > (unsigned)TQ_DENSE)) {   // a cell far denser than the ball's own neighbourhood: the pruning descent's job
                     defer = true;
                     if (lane == 0) atomicAdd(&tp->defer_why[1], 1u);
                     if (lane == 0) atomicAdd(&tp->defer_why[5 + min(attempt, 2)], 1u);
                     break;
                 }
-                for (unsigned j = 0; j < len; ++j) {   // a handful of points per cell
-                    const float4 p = refs[a0 + j];
-                    const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
-                    if (__float_as_uint(p.w) != self_w && d <= T) {
-                        const unsigned at = atomicAdd(cnt, 1u);
-                        if (at < (unsigned)TQ_CAND) cand[at] = d;
+                if (len <= 64u)
+                    for (unsigned j = 0; j < len; ++j) {   // a handful of points per cell: the lane that found it scans it
+                        const float4 p = refs[a0 + j];
+                        const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                        if (__float_as_uint(p.w) != self_w && d <= T) {
+                            const unsigned at = atomicAdd(cnt, 1u);
+                            if (at < (unsigned)TQ_CAND) cand[at] = d;
+                        }
+                    }
+                // a cell of up to TQ_DENSE points (the query sits at the edge of something denser): the whole wave scans it
+                for (unsigned long long dense = __ballot(len > 64u); dense; dense &= dense - 1) {
+                    const int src = (int)__builtin_ctzll(dense);
+                    const unsigned da = (unsigned)__shfl((int)a0, src), dl = (unsigned)__shfl((int)len, src);
+                    for (unsigned j = (unsigned)lane; j < dl; j += 64u) {
+                        const float4 p = refs[da + j];
+                        const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                        if (__float_as_uint(p.w) != self_w && d <= T) {
+                            const unsigned at = atomicAdd(cnt, 1u);
+                            if (at < (unsigned)TQ_CAND) cand[at] = d;
+                        }
                     }
                 }
             }
