@@ -91,6 +91,7 @@ struct TreeWs {
     DevBuf vals[2];     // u32[n]: original indices (identity | key order)
     DevBuf refs;        // float4[n] points in key order
     DevBuf samples;     // u64[n/32 + 1]: the last key of every 32-key block
+    DevBuf blockboxes;  // float4[2 * (n/64 + 1)]: tight box (minima, maxima) of every 64 consecutive points of the key order
     DevBuf flags;       // u8[n]: leaf bit level | 0x80 on a leaf's first point
     DevBuf tilecnt, tileoff;   // u32[tiles]: leaves starting in a tile, exclusive scan
     DevBuf leafstart;   // u32[leaves + 1]
@@ -102,7 +103,7 @@ struct TreeWs {
     DevBuf temp;        // rocprim temporary storage
     void release_all()
     {
-        DevBuf *all[] = {&keys[0], &keys[1], &vals[0], &vals[1], &refs, &samples, &flags, &tilecnt, &tileoff, &leafstart, &leafbl,
+        DevBuf *all[] = {&keys[0], &keys[1], &vals[0], &vals[1], &refs, &samples, &blockboxes, &flags, &tilecnt, &tileoff, &leafstart, &leafbl,
                          &faillist, &failbound, &bboxpart, &params, &temp};
         for (auto b : all) b->release();
     }

@@ -58,6 +58,9 @@ constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 #ifndef GSX_LEAF_WAVES17
 #define GSX_LEAF_WAVES17 5
 #endif
+#ifndef GSX_TQ_SCAN_FULL   // knn_tree_query: points of a node that is scanned block-wise instead of split once the list is full
+#define GSX_TQ_SCAN_FULL 4096   // measured 2048 .. 65536 on four clouds: one box load per lane covers the node
+#endif
 #ifndef GSX_TREE_ABL   // profiling builds only (results become wrong): 1 = no phase 2, 2 = no phase 1, 4 = no range look-ups, 16 = no word count, 32 = no cbrt
 #define GSX_TREE_ABL 0
 #endif
@@ -255,6 +258,30 @@ __global__ __launch_bounds__(256) void tree_samples_kernel(const unsigned long l
     const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nblk; j += gridDim.x * blockDim.x)
         samples[j] = keys[min(j * KEY_BLOCK + KEY_BLOCK - 1, n - 1)];   // the last key of block j
+}
+
+// tight bounding box of every 64 consecutive points of the key order (two float4: minima, maxima): what knn_tree_query prunes
+// with below a node's own box, which is the box of the NODE -- half of it may be empty space beyond the face of an object
+__global__ __launch_bounds__(256) void tree_block_boxes_kernel(const float4 *__restrict__ refs, int n, float4 *__restrict__ boxes)
+{
+    const int nb = (n + 63) / 64;
+    const int lane = (int)(threadIdx.x & 63);
+    for (int b = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); b < nb; b += (int)gridDim.x * 4) {
+        const int i = b * 64 + lane;
+        const float4 p = refs[i < n ? i : b * 64];
+        float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        if (lane == 0) {
+            boxes[2 * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            boxes[2 * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- leaves
@@ -939,7 +966,7 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
 
 __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
     TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
-    const float4 *__restrict__ refs,
+    const float4 *__restrict__ refs, const float4 *__restrict__ boxes,
     const unsigned *__restrict__ faillist, const double *__restrict__ failbound, int k, int q_begin, int out_count,
     float *__restrict__ mean_out, double *__restrict__ kth_out)
 {
@@ -982,7 +1009,7 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
         bool insert_mode = !known;   // a radius to try comes from knn_tree_near, which has done the collecting already
 #ifdef GSX_TREE_PROFILE
         const unsigned long long t_begin = wall_clock64();
-        int p_pass = 0, p_pop = 0, p_scan = 0, p_split = 0;
+        int p_pass = 0, p_pop = 0, p_scan = 0, p_split = 0, p_scan_full = 0, p_split_full = 0, p_maxsp = 0, p_bigsplit = 0;
         long long p_pts = 0;
 #endif
         for (;;) {   // one pass per search radius (a known bound needs exactly one)
@@ -1090,49 +1117,72 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                 if (md > T0 || (insert_mode && md >= kv)) break;   // every other pending node is at least as far
                 const unsigned cnt = nhi - nlo;
 #ifdef GSX_TREE_PROFILE
-                if (cnt <= ((insert_mode && kv < 1e300) ? 2048u : (unsigned)TQ_SCAN) || level == 0) { ++p_scan; p_pts += cnt; } else ++p_split;
+                if (cnt <= ((insert_mode && kv < 1e300) ? (unsigned)GSX_TQ_SCAN_FULL : (unsigned)TQ_SCAN) || level == 0) { ++p_scan; p_pts += cnt; if (kv < 1e300) ++p_scan_full; } else { ++p_split; if (kv < 1e300) ++p_split_full; if (cnt > 100000u) ++p_bigsplit; }
+                p_maxsp = max(p_maxsp, sp);
 #endif
-                // Once the list is full a node's box often undercuts the k-th distance while none of its points does (a far query's
-                // ball grazes a dense face: a thin cap through hundreds of small nodes): scanning a node of up to 2048 points then
-                // costs one round of loads, descending through it a dozen dependent ones.
-                const unsigned scan_cap = (insert_mode && kv < 1e300) ? 2048u : (unsigned)TQ_SCAN;
+                // Once the list is full a node's box often undercuts the k-th distance while none of its points does: the box is the
+                // NODE's, and a node that straddles the face of a dense object reaches far beyond its points (a query 26 units
+                // above such a face: ~100 nodes within 6 units had boxes nearer than its k-th neighbour, 4 of them points).  So a
+                // node of up to 4096 points is not split any further: the tight boxes of its 64-point blocks are tested (one load
+                // per lane) and only the blocks that can hold a candidate are scanned.
+                const unsigned scan_cap = (insert_mode && kv < 1e300) ? (unsigned)GSX_TQ_SCAN_FULL : (unsigned)TQ_SCAN;
                 if (cnt <= scan_cap || level == 0 || sp > TQ_STACK - 8) {   // (a full set: scanning is slow but exact)
-                    // ---- scan: 4 x 64 points in flight; the nearest candidate below the running k-th distance is inserted first
-                    for (unsigned b4 = nlo; b4 < nhi; b4 += 256u) {
-                        float4 p4[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const unsigned j = b4 + 64u * (unsigned)v + (unsigned)lane;
-                            p4[v] = refs[j < nhi ? j : nlo];
+                    const unsigned blk0 = nlo >> 6, blk1 = (nhi - 1u) >> 6;   // cnt > 0
+                    for (unsigned bb = blk0; bb <= blk1 && !(!insert_mode && M > TQ_CAND); bb += 64u) {
+                        const unsigned myb = bb + (unsigned)lane;
+                        bool need = myb <= blk1;
+                        if (need && cnt > 256u) {   // (small nodes: every block is needed more often than not)
+                            const float4 blo = boxes[2 * myb], bhi = boxes[2 * myb + 1];
+                            const double dx = fmax(fmax((double)blo.x - qd[0], qd[0] - (double)bhi.x), 0.0);
+                            const double dy = fmax(fmax((double)blo.y - qd[1], qd[1] - (double)bhi.y), 0.0);
+                            const double dz = fmax(fmax((double)blo.z - qd[2], qd[2] - (double)bhi.z), 0.0);
+                            const double m2b = (dx * dx + dy * dy + dz * dz) * (1.0 - 1e-14);
+                            need = !(m2b > T0) && (!insert_mode || m2b < kv);
                         }
+                        unsigned long long todo = __ballot(need);
+                        // ---- scan: up to 4 blocks of 64 points in flight; the nearest candidate below the running k-th distance first
+                        while (todo) {
+                            float4 p4[4];
+                            unsigned base4[4];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const unsigned j = b4 + 64u * (unsigned)v + (unsigned)lane;
-                            if (b4 + 64u * (unsigned)v >= nhi) break;   // wave-uniform
-                            const float4 p = p4[v];
-                            const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
-                            bool have = j < nhi && __float_as_uint(p.w) != self_w && d <= T0;
-                            if (!insert_mode) {
-                                const unsigned long long hb = __ballot(have);
-                                const int at = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u));
-                                if (have && at < TQ_CAND) cand[at] = d;
-                                M += (int)__popcll(hb);
-                            } else {
-                                for (;;) {
-                                    const bool cnd = have && d < kv;
-                                    if (!__any(cnd)) break;
-                                    const double dm = wave_min_f64_(cnd ? d : __builtin_inf());
-                                    const unsigned long long pick = __ballot(cnd && d == dm);
-                                    const int src = (int)__builtin_ctzll(pick);
-                                    if (lane == src) have = false;
-                                    const int pos = (int)__popcll(__ballot(best <= dm));
-                                    const double up = __shfl_up(best, 1);
-                                    best = lane < pos ? best : (lane == pos ? dm : up);
-                                    kv = bcast_f64(best, k - 1);
+                            for (int v = 0; v < 4; ++v) {
+                                base4[v] = 0xffffffffu;
+                                if (todo) {
+                                    base4[v] = (bb + (unsigned)__builtin_ctzll(todo)) << 6;
+                                    todo &= todo - 1;
+                                }
+                                const unsigned j = base4[v] + (unsigned)lane;
+                                p4[v] = refs[(base4[v] != 0xffffffffu && j >= nlo && j < nhi) ? j : nlo];
+                            }
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                if (base4[v] == 0xffffffffu) break;   // wave-uniform
+                                const unsigned j = base4[v] + (unsigned)lane;
+                                const float4 p = p4[v];
+                                const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
+                                bool have = j >= nlo && j < nhi && __float_as_uint(p.w) != self_w && d <= T0;
+                                if (!insert_mode) {
+                                    const unsigned long long hb = __ballot(have);
+                                    const int at = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u));
+                                    if (have && at < TQ_CAND) cand[at] = d;
+                                    M += (int)__popcll(hb);
+                                } else {
+                                    for (;;) {
+                                        const bool cnd = have && d < kv;
+                                        if (!__any(cnd)) break;
+                                        const double dm = wave_min_f64_(cnd ? d : __builtin_inf());
+                                        const unsigned long long pick = __ballot(cnd && d == dm);
+                                        const int src = (int)__builtin_ctzll(pick);
+                                        if (lane == src) have = false;
+                                        const int pos = (int)__popcll(__ballot(best <= dm));
+                                        const double up = __shfl_up(best, 1);
+                                        best = lane < pos ? best : (lane == pos ? dm : up);
+                                        kv = bcast_f64(best, k - 1);
+                                    }
                                 }
                             }
+                            if (!insert_mode && M > TQ_CAND) break;   // wave-uniform: the buffer is full
                         }
-                        if (!insert_mode && M > TQ_CAND) break;   // wave-uniform: the buffer is full
                     }
                     if (M > TQ_CAND) {   // wave-uniform
                         overflow = true;
@@ -1241,7 +1291,7 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                     if (kth_out) kth_out[qorig] = kv;
 #ifdef GSX_TREE_PROFILE
                     const unsigned long long dt = wall_clock64() - t_begin;
-                    if (dt > 20000ull) printf("slow descent: %.3f ms q=(%g %g %g) bound %g R %g kth %g passes %d pops %d scans %d splits %d points %lld\n", dt * 1e-5, qd[0], qd[1], qd[2], bound, R, sqrt(kv), p_pass, p_pop, p_scan, p_split, p_pts);
+                    if (dt > 20000ull) printf("slow descent: %.3f ms q=(%g %g %g) bound %g R %g kth %g passes %d pops %d scans %d (%d with a full list) splits %d (%d full, %d of > 100k points) points %lld max pending %d\n", dt * 1e-5, qd[0], qd[1], qd[2], bound, R, sqrt(kv), p_pass, p_pop, p_scan, p_scan_full, p_split, p_split_full, p_bigsplit, p_pts, p_maxsp);
 #endif
                 }
                 wave_sync();
@@ -1296,6 +1346,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     }
     GSX_CHECK(w.refs.reserve(sizeof(float4) * n));
     GSX_CHECK(w.samples.reserve(sizeof(unsigned long long) * (n / KEY_BLOCK + 2)));
+    GSX_CHECK(w.blockboxes.reserve(sizeof(float4) * 2 * (n / 64 + 2)));
     GSX_CHECK(w.flags.reserve(n));
     GSX_CHECK(w.tilecnt.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
     GSX_CHECK(w.tileoff.reserve(sizeof(unsigned) * ((size_t)ntiles + 1)));
@@ -1326,6 +1377,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_HIP(rocprim::radix_sort_pairs(w.temp.p, t_sort, k0, k1, v0, v1, n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(tree_gather_kernel, dim3(tree_blocks(ctx, n_ref, 2)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
                        v1, w.refs.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
+    hipLaunchKernelGGL(tree_block_boxes_kernel, dim3(tree_blocks(ctx, n_ref / 16 + 1, 1)), dim3(256), 0, ctx->stream, w.refs.as<float4>(),
+                       (int)n_ref, w.blockboxes.as<float4>());
     hipLaunchKernelGGL(tree_samples_kernel, dim3(tree_blocks(ctx, n_ref / KEY_BLOCK + 1, 1)), dim3(256), 0, ctx->stream, k1, (int)n_ref,
                        w.samples.as<unsigned long long>());
     hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, w.flags.as<unsigned char>(),
@@ -1349,7 +1402,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
                        w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.faillist.as<unsigned>(), w.failbound.as<double>(), k,
                        (int)q_begin, mean_out, kth_out, w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n);
     hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 3), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
-                       w.samples.as<unsigned long long>(), w.refs.as<float4>(),
+                       w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.blockboxes.as<float4>(),
                        w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n, k, (int)q_begin, (int)q_count, mean_out, kth_out);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_FALLBACK));
