@@ -240,15 +240,32 @@ __global__ __launch_bounds__(256) void tree_keys_kernel(const float *__restrict_
     }
 }
 
+// points in key order + the tight bounding box of every 64 consecutive ones (two float4: minima, maxima): what
+// knn_tree_query prunes with below a node's own box, which is the box of the NODE -- half of it may be empty space beyond the
+// face of an object.  A wave handles 64 consecutive points (256-thread workgroups, strides that are multiples of 256).
 __global__ __launch_bounds__(256) void tree_gather_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ z, int64_t stride, int n,
                                                           const unsigned *__restrict__ order, float4 *__restrict__ refs,
-                                                          int ref_only_from)
+                                                          float4 *__restrict__ boxes, int ref_only_from)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned v = order[i];
+    const int npad = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) {
+        const unsigned v = order[i < n ? i : n - 1];   // (the lanes past the end repeat the last point: harmless for the box)
         const unsigned tag = v | ((int)v >= ref_only_from ? 0x80000000u : 0u);
-        refs[i] = make_float4(x[(int64_t)v * stride], y[(int64_t)v * stride], z[(int64_t)v * stride], __uint_as_float(tag));
+        const float px = x[(int64_t)v * stride], py = y[(int64_t)v * stride], pz = z[(int64_t)v * stride];
+        if (i < n) refs[i] = make_float4(px, py, pz, __uint_as_float(tag));
+        float lo[3] = {px, py, pz}, hi[3] = {px, py, pz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        if ((threadIdx.x & 63) == 0) {
+            boxes[2 * (i >> 6)] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            boxes[2 * (i >> 6) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
     }
 }
 
@@ -258,30 +275,6 @@ __global__ __launch_bounds__(256) void tree_samples_kernel(const unsigned long l
     const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nblk; j += gridDim.x * blockDim.x)
         samples[j] = keys[min(j * KEY_BLOCK + KEY_BLOCK - 1, n - 1)];   // the last key of block j
-}
-
-// tight bounding box of every 64 consecutive points of the key order (two float4: minima, maxima): what knn_tree_query prunes
-// with below a node's own box, which is the box of the NODE -- half of it may be empty space beyond the face of an object
-__global__ __launch_bounds__(256) void tree_block_boxes_kernel(const float4 *__restrict__ refs, int n, float4 *__restrict__ boxes)
-{
-    const int nb = (n + 63) / 64;
-    const int lane = (int)(threadIdx.x & 63);
-    for (int b = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); b < nb; b += (int)gridDim.x * 4) {
-        const int i = b * 64 + lane;
-        const float4 p = refs[i < n ? i : b * 64];
-        float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-            }
-        if (lane == 0) {
-            boxes[2 * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
-            boxes[2 * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-        }
-    }
 }
 
 // ---------------------------------------------------------------- leaves
@@ -1376,9 +1369,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_HIP(hipGetLastError());
     GSX_HIP(rocprim::radix_sort_pairs(w.temp.p, t_sort, k0, k1, v0, v1, n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(tree_gather_kernel, dim3(tree_blocks(ctx, n_ref, 2)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
-                       v1, w.refs.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
-    hipLaunchKernelGGL(tree_block_boxes_kernel, dim3(tree_blocks(ctx, n_ref / 16 + 1, 1)), dim3(256), 0, ctx->stream, w.refs.as<float4>(),
-                       (int)n_ref, w.blockboxes.as<float4>());
+                       v1, w.refs.as<float4>(), w.blockboxes.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
     hipLaunchKernelGGL(tree_samples_kernel, dim3(tree_blocks(ctx, n_ref / KEY_BLOCK + 1, 1)), dim3(256), 0, ctx->stream, k1, (int)n_ref,
                        w.samples.as<unsigned long long>());
     hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, w.flags.as<unsigned char>(),
