@@ -58,6 +58,9 @@ constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 #ifndef GSX_LEAF_WAVES17
 #define GSX_LEAF_WAVES17 5
 #endif
+#ifndef GSX_LEAF_HB   // candidate gathers in flight per lane in knn_leaf's phase 2
+#define GSX_LEAF_HB 4
+#endif
 #ifndef GSX_TQ_SCAN_FULL   // knn_tree_query: points of a node that is scanned block-wise instead of split once the list is full
 #define GSX_TQ_SCAN_FULL 4096   // measured 2048 .. 65536 on four clouds: one box load per lane covers the node
 #endif
@@ -410,6 +413,17 @@ __device__ __forceinline__ void cell_range(const unsigned long long *__restrict_
     b = b0;
 }
 
+// A wave-uniform value computed on the VALU (there is no scalar float64 unit) sits in a VGPR per lane; read back through
+// v_readfirstlane it lives in scalar registers, whose spills cost a VGPR LANE each instead of a scratch dword per lane.
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+
 // ---------------------------------------------------------------- knn_leaf
 constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? 3 : 2); }
 
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
 {
     constexpr int L = KCAP - 1;
     using Net = TopNet<L>;
-    constexpr int BS = Net::BS, HB = 4 < BS ? 4 : BS;
+    constexpr int BS = Net::BS, HB = GSX_LEAF_HB < BS ? GSX_LEAF_HB : BS;
     __shared__ unsigned s_mask[TREE_THREADS / 64][TWCAP][64];
     // per mask word: the (pre-adjusted) first index of up to four key ranges and where in the word each one ends
     __shared__ unsigned s_wb[TREE_THREADS / 64][4][TWCAP];
@@ -507,15 +521,14 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
         ncand = uniform(ncand);
 
         // geometry shared by the batches of this leaf
-        const double cell = s * (double)(1 << Lc);   // cell edge (real units)
-        const float hf = (float)cell, g_inv_h = (float)(1.0 / cell);
-        const float ccx = (float)(ox + ((double)fx + 0.5 * (double)(1 << bxb)) * s);
-        const float ccy = (float)(oy + ((double)fy + 0.5 * (double)(1 << byb)) * s);
-        const float ccz = (float)(oz + ((double)fz + 0.5 * (double)(1 << bzb)) * s);
-        (void)hf;
+        const double cell = uniform_f64(s * (double)(1 << Lc));   // cell edge (real units)
+        const float g_inv_h = uniform_f32((float)(1.0 / cell));
+        const float ccx = uniform_f32((float)(ox + ((double)fx + 0.5 * (double)(1 << bxb)) * s));
+        const float ccy = uniform_f32((float)(oy + ((double)fy + 0.5 * (double)(1 << byb)) * s));
+        const float ccz = uniform_f32((float)(oz + ((double)fz + 0.5 * (double)(1 << bzb)) * s));
         // radius inside which ~2 (k+1) points are expected at the leaf's own density (the uniform grid's cell edge), x rf_scale
         const double vol = s * s * s * ldexp(1.0, bl);
-        const double r_f = (GSX_TREE_ABL & 32) ? 1e30 : (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1));
+        const double r_f = uniform_f64((GSX_TREE_ABL & 32) ? 1e30 : (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1)));
         const bool irregular = ncand > TREE_CAND_LIMIT;
 
         for (int qb = 0; qb < nq; qb += 64) {
@@ -562,8 +575,8 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 const int rr[3] = {rx, ry, rz};
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    if (c0[a] > 0) rs = fmin(rs, (qd[a] - (od[a] + (double)c0[a] * cell)) - slack);
-                    if (c0[a] + rr[a] < cmax) rs = fmin(rs, ((od[a] + (double)(c0[a] + rr[a]) * cell) - qd[a]) - slack);
+                    if (c0[a] > 0) rs = fmin(rs, (qd[a] - uniform_f64(od[a] + (double)c0[a] * cell)) - slack);
+                    if (c0[a] + rr[a] < cmax) rs = fmin(rs, (uniform_f64(od[a] + (double)(c0[a] + rr[a]) * cell) - qd[a]) - slack);
                 }
                 rs = fmax(rs, 0.0);
                 racc_sq = rs * rs;
