@@ -83,7 +83,7 @@ int launch_knn_brute(gsx_ctx *, const float4 *, int64_t, int64_t, int64_t, const
                      int64_t, int, float *);
 int knn_tree_info(gsx_ctx *, gsx_sor_info *);
 int launch_knn_tree(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int, float *, double *,
-                    gsx_sor_info *, int64_t, int, int);
+                    gsx_sor_info *, int64_t, int, int, bool);
 int launch_knn_grid(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, int,
                     float *, gsx_sor_info *, int share = 0, int nshares = 1);
 int launch_sor_stats(gsx_ctx *, const float *, int64_t, double, float *);
@@ -327,7 +327,7 @@ int gsx_sor_knn_dev(gsx_ctx *c, const float *x, const float *y, const float *z, 
     }
     // (adaptive mode: launch_knn_grid itself hands clouds its grid cannot resolve to the tree path, csrc/sor_tree.hip)
     if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, info);
-    if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, INT32_MAX, 0, 1);
+    if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, nullptr, info, INT32_MAX, 0, 1, false);
     GSX_FAIL("gsx_sor_knn_dev: unknown algo %d", algo);
 }
 
@@ -350,7 +350,7 @@ int gsx_sor_knn_share_dev(gsx_ctx *c, const float *x, const float *y, const floa
         return gsx_sor_knn_dev(c, x, y, z, stride, n, q0, q1 - q0, k, GSX_KNN_BRUTE, mean_out + q0, info);
     }
     if (algo == GSX_KNN_GRID) return launch_knn_grid(c, x, y, z, stride, n, 0, n, k, mean_out, info, share, nshares);
-    if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n, 0, n, k, mean_out, nullptr, info, INT32_MAX, share, nshares);
+    if (algo == GSX_KNN_TREE) return launch_knn_tree(c, x, y, z, stride, n, 0, n, k, mean_out, nullptr, info, INT32_MAX, share, nshares, false);
     GSX_FAIL("gsx_sor_knn_share_dev: unknown algo %d", algo);
 }
 

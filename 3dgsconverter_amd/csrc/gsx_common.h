@@ -85,6 +85,8 @@ struct KnnWs {
     }
 };
 
+constexpr int GSX_TREE_UNSUITABLE = 2;   // launch_knn_tree(guard = true): the cloud exhausts the key resolution, nothing was computed
+
 // Buffers of the Morton-tree KNN (sor_tree.hip)
 struct TreeWs {
     DevBuf keys[2];     // u64[n]: Morton keys (unsorted | sorted)

@@ -2285,7 +2285,7 @@ int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z
 // csrc/sor_tree.hip: the path for clouds this grid cannot resolve
 int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
                     int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from, int share,
-                    int nshares);
+                    int nshares, bool guard);
 
 int64_t grid_cell_cap(int64_t n_ref) { return std::max<int64_t>(n_ref / 2, 64) + 64; }
 
@@ -2402,7 +2402,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     // holds several times the average (a scene inside a box inflated by floaters: 2400x; Gaussian blobs: 30x+) goes to the
     // Morton-tree path (sor_tree.hip) at once -- no cell size fits it, and refining level by level costs a host round trip
     // and a re-binning per level (clustered 1M: 16.5 ms against 1.3 ms).
-    const bool tree_ok = adaptive && ctx->tree && level == 0 && kk <= 65 && n_ref > k;
+    bool tree_ok = adaptive && ctx->tree && level == 0 && kk <= 65 && n_ref > k;
     bool hist_done = false;
     if (tree_ok) {
         unsigned *bk_cnt = w.bkcnt.as<unsigned>();
@@ -2424,7 +2424,12 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
             if (getenv("GSX_TRACE_LEVELS"))
                 fprintf(stderr, "[gsx] level 0: fullest bucket %u of %lld points in %u buckets -> tree path\n", mx, (long long)n_ref, nonzero);
-            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, share, nshares);
+            const int rc = launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, share, nshares, true);
+            if (rc != GSX_TREE_UNSUITABLE) return rc;
+            // (tens of thousands of points inside one cell of the tree's finest resolution: the refinement below re-scales)
+            tree_ok = false;
+            ctx->last_knn_algo = GSX_KNN_GRID;
+            GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
         }
         // an even histogram (fullest bucket within 1.5x of the average): no brick can be far over-full, so none is deferred and
         // the host does not have to look at the counters again -- the call costs ONE synchronisation, as before the probe existed
@@ -2493,7 +2498,9 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             // second decision: the histogram looked even, yet some bricks hold far more than their cells were sized for
             // (density varying inside the buckets).  The tree path takes the whole cloud over; this level's work is lost.
             if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] level 0: %u deferred bricks -> tree path\n", hgp.deferred_count);
-            return launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, 0, 1);
+            const int rc = launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, 0, 1, true);
+            if (rc != GSX_TREE_UNSUITABLE) return rc;
+            ctx->last_knn_algo = GSX_KNN_GRID;
         }
         if (hgp.deferred_count > 0 && !hgp.bad_input) {
             const unsigned nd = hgp.deferred_count;

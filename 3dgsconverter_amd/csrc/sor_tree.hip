@@ -75,6 +75,8 @@ constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small arr
                                        // range look-ups search first; only the last 5 steps touch the 80 MB key array
 constexpr int TQ_STACK = 256;          // pending nodes of a descent (best-first: the frontier of the ball, typically a few dozen)
 constexpr int TQ_SCAN = 256;           // a node with at most this many points is scanned, not split
+constexpr unsigned TREE_OVERFULL_LIMIT = 32768;   // points in one fine cell above which adaptive mode does not use this path (their
+                                                   // search is quadratic in that number: the key resolution, extent / 2^21, is exhausted)
 constexpr int TQ_DENSE = 4096;         // points of one cover cell knn_tree_near scans itself (more: handed on to the descent)
 constexpr int TQ_CAND = 256;           // candidates inside the search ball a wave collects before it ranks them
 
@@ -89,7 +91,7 @@ struct TreeParams {
     unsigned ticket_bbox;  // self-resetting arrival ticket of tree_bbox_kernel
     unsigned pad;
     unsigned fail2_count;  // queries knn_tree_near handed on to knn_tree_query
-    unsigned pad2;
+    unsigned max_leaf;     // points of the fullest leaf (> 64: more than 64 points in ONE fine cell -- the key resolution is exhausted)
     unsigned defer_why[8];   // knn_tree_near's reasons for handing a query on (trace output only): 0 too many cells, 1 dense cell,
                              // 2 buffer full, 3 / 4 fewer than k points inside the last radius tried / inside a known bound, 5-7 attempt
     unsigned leaf_ctr[8 * 32];
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
     tp->nleaves = 0;
     tp->fail_count = 0;
     tp->fail2_count = 0;
+    tp->max_leaf = 0;
     for (int i = 0; i < 8; ++i) tp->defer_why[i] = 0;
     if (v[6] != 0.0f) atomicOr(devflags, 1u);
 }
@@ -423,6 +426,15 @@ __device__ __forceinline__ double uniform_f64(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+
+// points of the fullest over-full leaf (a leaf of more than 64 points is ONE fine cell): the host entry of adaptive mode reads it
+__global__ __launch_bounds__(256) void tree_leaf_max_kernel(TreeParams *__restrict__ tp, const unsigned *__restrict__ leafstart)
+{
+    const int nl = (int)tp->nleaves;
+    unsigned mx = 0;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < nl; l += gridDim.x * blockDim.x) mx = max(mx, leafstart[l + 1] - leafstart[l]);
+    if (mx > (unsigned)LEAF_CAP) atomicMax(&tp->max_leaf, mx);
+}
 
 // ---------------------------------------------------------------- knn_leaf
 constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? 3 : 2); }
@@ -1120,7 +1132,8 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
 #ifdef GSX_TREE_PROFILE
                 ++p_pop;
 #endif
-                if (md > T0 || (insert_mode && md >= kv)) break;   // every other pending node is at least as far
+                if (md > T0 || (insert_mode && md >= kv)) break;   // every other pending node is at least as far (kv == 0, k exact
+                                                                   // duplicates of the query: nothing can be nearer)
                 const unsigned cnt = nhi - nlo;
 #ifdef GSX_TREE_PROFILE
                 if (cnt <= ((insert_mode && kv < 1e300) ? (unsigned)GSX_TQ_SCAN_FULL : (unsigned)TQ_SCAN) || level == 0) { ++p_scan; p_pts += cnt; if (kv < 1e300) ++p_scan_full; } else { ++p_split; if (kv < 1e300) ++p_split_full; if (cnt > 100000u) ++p_bigsplit; }
@@ -1324,8 +1337,7 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_
         GSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, knn_leaf_kernel<KCAP>, TREE_THREADS, 0));
         occ = std::max(1, std::min(occ, 8));
     }
-    const char *rf = getenv("GSX_TREE_RF");
-    const float rf_scale = rf ? (float)atof(rf) : 1.1f;
+    static const float rf_scale = getenv("GSX_TREE_RF") ? (float)atof(getenv("GSX_TREE_RF")) : 1.1f;   // (tuning: DESIGN.md 5.8)
     hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
                        w.keys[1].as<unsigned long long>(), w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
                        w.leafbl.as<unsigned char>(), k, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
@@ -1336,7 +1348,7 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_
 
 int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
                     int64_t q_count, int k, float *mean_out, double *kth_out, gsx_sor_info *info, int64_t ref_only_from, int share,
-                    int nshares)
+                    int nshares, bool guard)
 {
     if (k < 1 || k > 64) GSX_FAIL("sor (tree): k=%d not supported (1 <= k <= 64)", k);
     if (n_ref < 1 || n_ref > (int64_t)INT32_MAX - 64) GSX_FAIL("sor (tree): n=%lld out of range", (long long)n_ref);
@@ -1392,6 +1404,20 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     hipLaunchKernelGGL(tree_leaf_compact_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, w.flags.as<unsigned char>(), (int)n_ref,
                        tileoff, tilecnt, w.leafstart.as<unsigned>(), w.leafbl.as<unsigned char>(), tp);
     GSX_HIP(hipGetLastError());
+    if (guard) {
+        // adaptive mode (the caller synchronises anyway): a cloud with tens of thousands of points inside ONE fine cell -- two
+        // scales more than 2^21 apart -- would be searched quadratically there; the caller's grid refinement re-scales instead
+        hipLaunchKernelGGL(tree_leaf_max_kernel, dim3(tree_blocks(ctx, n_ref / 32 + 1, 1)), dim3(256), 0, ctx->stream, tp,
+                           w.leafstart.as<unsigned>());
+        unsigned max_leaf = 0;
+        GSX_HIP(hipMemcpyAsync(&max_leaf, &tp->max_leaf, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        GSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (max_leaf > TREE_OVERFULL_LIMIT) {
+            GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
+            if (getenv("GSX_TRACE_LEVELS")) fprintf(stderr, "[gsx] tree: %u points in one fine cell -> back to the grid\n", max_leaf);
+            return GSX_TREE_UNSUITABLE;
+        }
+    }
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
