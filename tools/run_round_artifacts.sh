@@ -31,6 +31,15 @@ for C in "clustered 1000000" "floaters 10000000" "clustered 10000000"; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_tree_$1_$2 -o trace -- python $ROOT/tests/devtools/probe_tree.py time $1 $2 1 > $OUT/tree_trace_${R}_$1_$2.log 2>&1
   python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_tree_$1_$2/trace_results.db > $OUT/kernel_stats_${R}_tree_$1_$2.txt 2>&1
 done
+# counters of the tree path's kernels on the 10M scene (separate passes; only the text summary travels back)
+TC="python $ROOT/tests/devtools/probe_tree.py time floaters 10000000 1"
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc_tree1 -o pmc -- $TC > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/pmc_tree2 -o pmc -- $TC > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_tree3 -o pmc -- $TC > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_tree4 -o pmc -- $TC > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_tree5 -o pmc -- $TC > /dev/null 2>&1
+python $ROOT/tools/rocpd_summary.py --pmc $OUT/pmc_tree1/pmc_results.db $OUT/pmc_tree2/pmc_results.db $OUT/pmc_tree3/pmc_results.db $OUT/pmc_tree4/pmc_results.db $OUT/pmc_tree5/pmc_results.db 2>&1 | grep -E "^#|^kernel|knn_leaf|knn_tree|tree_" > $OUT/pmc_${R}_tree.txt
+rm -rf $OUT/pmc_tree1 $OUT/pmc_tree2 $OUT/pmc_tree3 $OUT/pmc_tree4 $OUT/pmc_tree5
 cd $ROOT
 for T in "" _km _slab; do python tools/rocpd_summary.py $OUT/prof_${R}${T}/trace_results.db > $OUT/kernel_stats_${R}${T}.txt 2>&1; done
 python tools/rocpd_summary.py --pmc $OUT/pmc_fetch_${R}/pmc_results.db $OUT/pmc_write_${R}/pmc_results.db > $OUT/pmc_${R}_tcc.txt 2>&1
