@@ -46,6 +46,7 @@ SIGNATURES = {
     "gsx_ctx_destroy": (None, [_P]),
     "gsx_ctx_set_stream": (_I, [_P, _P]),
     "gsx_ctx_own_stream": (_I, [_P]),
+    "gsx_ctx_last_knn_algo": (_I, [_P]),
     "gsx_ctx_synchronize": (_I, [_P]),
     "gsx_ctx_check": (_I, [_P]),
     "gsx_ctx_set_timing": (_I, [_P, _I]),
@@ -694,6 +695,10 @@ class Context:
     def check(self):
         """synchronise + raise GsxError if a _dev call met non-finite coordinates since the last check"""
         check(self.lib.gsx_ctx_check(self.handle), "gsx_ctx_check")
+
+    def last_knn_algo(self) -> int:
+        """KNN_* of the path this context's last KNN call took (adaptive mode picks GRID or TREE)"""
+        return int(self.lib.gsx_ctx_last_knn_algo(self.handle))
 
     def set_param(self, name: str, value: float):
         check(self.lib.gsx_ctx_set_param(self.handle, name.encode(), float(value)), "gsx_ctx_set_param")

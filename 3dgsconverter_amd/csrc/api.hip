@@ -182,6 +182,8 @@ int gsx_ctx_set_stream(gsx_ctx *c, void *s)
     return 0;
 }
 
+int gsx_ctx_last_knn_algo(gsx_ctx *c) { return c ? c->last_knn_algo : -1; }
+
 int gsx_ctx_own_stream(gsx_ctx *c)
 {
     if (!c) GSX_FAIL("null ctx");

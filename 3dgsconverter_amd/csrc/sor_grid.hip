@@ -2402,7 +2402,9 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     // holds several times the average (a scene inside a box inflated by floaters: 2400x; Gaussian blobs: 30x+) goes to the
     // Morton-tree path (sor_tree.hip) at once -- no cell size fits it, and refining level by level costs a host round trip
     // and a re-binning per level (clustered 1M: 16.5 ms against 1.3 ms).
-    bool tree_ok = adaptive && ctx->tree && level == 0 && kk <= 65 && n_ref > k;
+    // (slab mode -- one rank's slab + halo of the multi-GPU exchange -- never refines, but an uneven slab still goes to the tree:
+    //  the grid would search its dense cells quadratically)
+    bool tree_ok = (adaptive || (slab && ctx->adaptive)) && ctx->tree && level == 0 && kk <= 65 && n_ref > k;
     bool hist_done = false;
     if (tree_ok) {
         unsigned *bk_cnt = w.bkcnt.as<unsigned>();
@@ -2424,7 +2426,8 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
             GSX_CHECK(timing_end(ctx, GSX_T_SOR_BIN));
             if (getenv("GSX_TRACE_LEVELS"))
                 fprintf(stderr, "[gsx] level 0: fullest bucket %u of %lld points in %u buckets -> tree path\n", mx, (long long)n_ref, nonzero);
-            const int rc = launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info, INT32_MAX, share, nshares, true);
+            const int rc = launch_knn_tree(ctx, x, y, z, stride, n_ref, q_begin, q_count, k, mean_out, kth_out, info,
+                                           slab ? ref_only_from : INT32_MAX, share, nshares, true);
             if (rc != GSX_TREE_UNSUITABLE) return rc;
             // (tens of thousands of points inside one cell of the tree's finest resolution: the refinement below re-scales)
             tree_ok = false;

@@ -161,6 +161,11 @@ class HipSlabBackend:
         from . import _lib
         self._lib = _lib
         self.ctx = ctx if ctx is not None else _lib.Context(device, stream)
+        if ctx is None:
+            # the slab KNN never refines, but with this set an uneven slab (blobs, a dense object) takes the Morton-tree path
+            # instead of searching over-full grid cells quadratically (one more host synchronisation per step; a context the
+            # caller brings keeps the caller's setting -- bench.py times the even case without it)
+            self.ctx.set_param("adaptive", 1)
         self.lib = self.ctx.lib
         self._bufs = {}
 
@@ -389,6 +394,11 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS
     # ---- 3. scatter into the send buffer, exchange the rows (sizes from the histograms: no counting pass)
     own, halo = slab_counts(allhist, cut, halo_bins)
+    # a cloud whose halos amount to most of it (a scene inside a box inflated by far floaters: the halo width comes from the
+    # box-wide density) gains nothing from slabs -- every rank would receive nearly everything, search it, and then fail the
+    # certificate for the floaters anyway.  Decided from the gathered histograms: every rank raises in the same step.
+    if G > 1 and int(halo.sum()) > 0.75 * (G - 1) * n_total:
+        raise SlabUnsupported("the halos hold %d of %d points per neighbour: no slab structure to exploit" % (int(halo.sum()) // (G - 1), n_total))
     own_cnt, halo_cnt = own[r], halo[r]
     assert int(own_cnt.sum()) == n_local
     own_off = np.concatenate([[0], np.cumsum(own_cnt)[:-1]])

@@ -81,6 +81,8 @@ int  gsx_ctx_set_stream(gsx_ctx *ctx, void *hip_stream);
 /* give the context a non-blocking stream of its own (destroyed with it): several contexts then run concurrently on one
  * GPU -- the independent SOG palette chunks (formats/sog.py:536-552) are dealt out to a few such "lanes" */
 int  gsx_ctx_own_stream(gsx_ctx *ctx);
+/* GSX_KNN_* of the path the context's last KNN call ended up in (adaptive mode chooses between GRID and TREE); no synchronisation */
+int  gsx_ctx_last_knn_algo(gsx_ctx *ctx);
 int  gsx_ctx_synchronize(gsx_ctx *ctx);
 /* synchronises, then reports (and clears) errors the asynchronous _dev calls detected ON THE DEVICE since the
  * last check: non-finite coordinates given to gsx_sor_knn_dev / gsx_sor_knn_share_dev (their mean_out was

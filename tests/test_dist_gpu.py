@@ -133,6 +133,58 @@ def test_slab_path_on_shared_gpu_equals_the_unsharded_result(world, kind, n_loca
 def test_slab_path_refuses_floaters_on_every_rank(tmp_path):
     _spawn(_worker, 2, (_free_port(), 40000, 16, 1.0, "floaters", str(tmp_path)))
     assert len(list(tmp_path.glob("uncertain_*"))) == 2 and not list(tmp_path.glob("mask_*"))
+    # (round 3: refused BEFORE anything is exchanged or searched -- the halos would hold the whole cloud)
+    assert "no slab structure" in (tmp_path / "uncertain_0.txt").read_text()
+
+
+def _blob_cloud(n):
+    """blobs strung along x: slabs exist (thin halos), but every slab is very uneven inside"""
+    rng = np.random.default_rng(8)
+    c = np.stack([np.linspace(0.0, 40.0, 9), rng.random(9) * 4, rng.random(9) * 4], 1)
+    which = rng.integers(0, 9, n)
+    sig = np.array([0.02, 0.3, 0.05, 0.6, 0.1, 0.4, 0.03, 0.5, 0.08])[which]
+    return (c[which] + rng.standard_normal((n, 3)) * sig[:, None]).astype(np.float32)[rng.permutation(n)]
+
+
+def _blob_worker(rank, world, port, n_local, k, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    full = _blob_cloud(world * n_local)
+    be = slab.HipSlabBackend(0)
+    comm = slab.TorchHostComm(be)
+    rows = be.buf("rows", 12 * n_local)
+    be.from_host(rows, full[rank * n_local:(rank + 1) * n_local])
+    try:
+        res = slab.slab_sor(be, comm, rows, n_local, k, 1.0, want_host=True)
+        np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
+        np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+        np.save(os.path.join(out_dir, "algo_%d.npy" % rank), np.array([be.ctx.last_knn_algo()]))
+    except slab.SlabUncertain as e:
+        with open(os.path.join(out_dir, "uncertain_%d.txt" % rank), "w") as f:
+            f.write(str(e))
+    dist.destroy_process_group()
+
+
+def test_slab_path_with_uneven_slabs_takes_the_tree_on_every_rank(tmp_path):
+    """a rank's slab + halo is searched by the Morton-tree path when its coarse histogram is uneven (reference-only halo points,
+    k-th distances for the certificate); either the slabs certify and the result equals the unsharded one, or every rank says so"""
+    world, n_local, k = 2, 150000, 16
+    _spawn(_blob_worker, world, (_free_port(), n_local, k, str(tmp_path)))
+    unc = list(tmp_path.glob("uncertain_*"))
+    assert len(unc) in (0, world)
+    if not unc:
+        full = _blob_cloud(world * n_local)
+        ref = osor.sor(full, k, 1.0)
+        md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(world)])
+        assert np.array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
+        masks = np.concatenate([np.load(tmp_path / ("mask_%d.npy" % r)) for r in range(world)]).astype(bool)
+        np.testing.assert_array_equal(masks, ref["mask"])
+        assert all(int(np.load(tmp_path / ("algo_%d.npy" % r))[0]) == 3 for r in range(world))
 
 
 # ---------------------------------------------------------------------------------------------------------------

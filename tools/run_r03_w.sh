@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_sor_tree_gpu.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|NCCL\|^$" | tail -12 | cut -c1-300
+timeout 1500 python -m pytest tests/test_dist_gpu.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|NCCL\|^$" | tail -12 | cut -c1-300
