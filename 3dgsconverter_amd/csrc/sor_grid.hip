@@ -827,7 +827,11 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                 const int dim[3] = {nx, ny, nz};
                 const bool boundary = ulo[0] <= 0 || ulo[1] <= 0 || ulo[2] <= 0 || uhi[0] >= nx - 1 || uhi[1] >= ny - 1 ||
                                       uhi[2] >= nz - 1;
-                if (boundary) {  // wave-uniform
+                // Only for a brick's FIRST batch: the later ones scan a sub-box of the neighbourhood (below) that reaches exactly one
+                // cell beyond their queries' cells -- a radius above h' would certify against points that were never looked at.
+                // (Found by the randomised sweep, round 3: a planar cloud, k = 64, two queries at the rim wrong in ~15 % of the
+                // runs -- which queries land in a later batch depends on the order the binning's atomics leave in a cell.)
+                if (boundary && qb == 0) {  // wave-uniform
                     // f32 is enough: the 1e-3*h' margin dwarfs its rounding (<= dims * 2^-23 * h' ~ 1e-4 h')
                     const float hf = (float)hp;
                     const float rel[3] = {qx - g_ox, qy - g_oy, qz - g_oz};

@@ -58,10 +58,16 @@ def main(cases=40, seed=0):
                 dev_ok &= np.array_equal(got.view(np.uint32), ref["mean_dists"].view(np.uint32))
             for a in d + [out]:
                 a.free()
-        bad += not (ok and dev_ok)
-        print("%3d %-10s n=%7d k=%2d host=%s dev(mf0,mf1)=%s deferred=%d refined=%d" % (
-            c, kind, n, k, "ok" if ok else "MISMATCH", "ok" if dev_ok else "MISMATCH",
-            res["info"]["n_deferred_bricks"], res["info"]["n_refined"]), flush=True)
+        tree_ok, tinfo = True, None
+        if n > k:   # the Morton-tree path asked for explicitly (adaptive mode above only takes it for uneven clouds)
+            rt = L.sor_filter(xyz, k, 1.0, algo=3, want_info=True)
+            tinfo = rt["info"]
+            tree_ok = np.array_equal(rt["mean_dists"].view(np.uint32), ref["mean_dists"].view(np.uint32)) and np.array_equal(rt["mask"], ref["mask"])
+        bad += not (ok and dev_ok and tree_ok)
+        print("%3d %-10s n=%7d k=%2d host=%s(algo %d) dev(mf0,mf1)=%s tree=%s deferred=%d refined=%d%s" % (
+            c, kind, n, k, "ok" if ok else "MISMATCH", res["info"]["algo"], "ok" if dev_ok else "MISMATCH", "ok" if tree_ok else "MISMATCH",
+            res["info"]["n_deferred_bricks"], res["info"]["n_refined"],
+            "" if tinfo is None else " leaves=%d near=%d descents=%d" % (tinfo["n_bricks"], tinfo["n_fallback"], tinfo["n_exhaustive"])), flush=True)
     ctx.close()
     print("fuzz: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t_start))
     return bad
