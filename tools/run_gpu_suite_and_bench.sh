@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: the whole -m gpu suite, then the default bench line with its secondary configurations (summary printed)
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
