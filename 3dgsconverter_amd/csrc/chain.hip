@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void rgb_from_sh_kernel(const float *__restric
             q[0] = q[1] = lin == 0.0f ? 0u : 255u;
         } else {
             const float a = (float)::pow((double)lin, e);
-            const float b[2] = {chain_ulp_step(a, -3), chain_ulp_step(a, 3)};   // libm / SVML powf: <= 1 ulp (measured 0.999)
+            // numpy's float32 power: libm powf (<= 1 ulp, measured 0.999) or, on AVX-512 builds, SVML whose low-accuracy
+            // variants are bounded at 4 ulp -- bracket +-5 like the log of sog.hip
+            const float b[2] = {chain_ulp_step(a, -5), chain_ulp_step(a, 5)};
 #pragma unroll
             for (int s = 0; s < 2; ++s) q[s] = (unsigned)__fmul_rn(fminf(b[s], 1.0f), 255.0f);
         }

@@ -496,17 +496,22 @@ int density_hist_dev(gsx_ctx *c, const float *x, const float *y, const float *z,
     return 0;
 }
 
-__global__ __launch_bounds__(256) void merge_minmax_kernel(const long long *__restrict__ keys3, int64_t m, long long *__restrict__ mm)
+// (entries with count 0 are the padding of the all-gathered lists: their keys are ignored -- a zero key must not stretch
+//  the frame of a scene far from the origin)
+__global__ __launch_bounds__(256) void merge_minmax_kernel(const long long *__restrict__ keys3, const long long *__restrict__ counts,
+                                                           int64_t m, long long *__restrict__ mm)
 {
     long long mn[3] = {0x7fffffffffffffffll, 0x7fffffffffffffffll, 0x7fffffffffffffffll};
     long long mx[3] = {-0x7fffffffffffffffll, -0x7fffffffffffffffll, -0x7fffffffffffffffll};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        if (counts[i] == 0) continue;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const long long v = keys3[3 * i + a];
             mn[a] = v < mn[a] ? v : mn[a];
             mx[a] = v > mx[a] ? v : mx[a];
         }
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -528,6 +533,7 @@ __global__ __launch_bounds__(256) void merge_insert_kernel(const long long *__re
                                                            unsigned *__restrict__ tkb, unsigned *__restrict__ tcnt, unsigned tmask)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        if (counts[i] == 0) continue;   // padding
         const VKey key = pack_key<WIDE>(f, (int)keys3[3 * i], (int)keys3[3 * i + 1], (int)keys3[3 * i + 2]);
         table_add<WIDE>(tkeys, tkb, tcnt, tmask, key, (unsigned)counts[i]);
     }
@@ -548,7 +554,8 @@ int density_merge_dev(gsx_ctx *c, const int64_t *keys3_dev, const int64_t *count
                                -0x7fffffffffffffffll, -0x7fffffffffffffffll, -0x7fffffffffffffffll};
     GSX_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const long long *k3 = reinterpret_cast<const long long *>(keys3_dev);
-    hipLaunchKernelGGL(merge_minmax_kernel, dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, m, mm);
+    const long long *cn = reinterpret_cast<const long long *>(counts_dev);
+    hipLaunchKernelGGL(merge_minmax_kernel, dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, cn, m, mm);
     long long h[6];
     GSX_HIP(hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));
@@ -565,7 +572,6 @@ int density_merge_dev(gsx_ctx *c, const int64_t *keys3_dev, const int64_t *count
     VoxTable t;
     const size_t cap = (size_t)std::max<int64_t>(dense_cap, 1);
     GSX_CHECK(alloc_table(c, hvf, m, 16 * cap + 64, &t));
-    const long long *cn = reinterpret_cast<const long long *>(counts_dev);
     if (t.wide)
         hipLaunchKernelGGL((merge_insert_kernel<true>), dim3(blocks_for(c, m, 1024)), dim3(256), 0, c->stream, k3, cn, m, hvf, t.tkeys, t.tkb,
                            t.tcnt, (unsigned)(t.tsize - 1));

@@ -19,68 +19,12 @@
 // RCCL is loaded with dlopen at gsx_comm_init, so single-GPU users never need it; the calls are
 // the plain collectives (ncclAllReduce / ncclAllGather / grouped ncclSend + ncclRecv over xGMI).
 // The orchestration (sizes, offsets, fallbacks) is host Python in 3dgsconverter_amd/dist.py.
-#include <dlfcn.h>
-
 #include <algorithm>
 #include <cmath>
 
 #include "gsx_common.h"
 
 namespace gsx {
-
-// ---------------------------------------------------------------- RCCL through dlopen
-typedef struct { char internal[128]; } rcclUniqueId;
-typedef void *rcclComm_t;
-enum { RCCL_INT8 = 0, RCCL_INT64 = 4, RCCL_FLOAT32 = 7 };  // ncclDataType_t
-enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_MIN = 3 };         // ncclRedOp_t
-
-struct Rccl {
-    void *h = nullptr;
-    int (*GetUniqueId)(rcclUniqueId *) = nullptr;
-    int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
-    int (*CommDestroy)(rcclComm_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t) = nullptr;
-    int (*Send)(const void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-};
-static Rccl g_rccl;
-
-static int rccl_load()
-{
-    if (g_rccl.h) return 0;
-    // an already loaded librccl (torch bundles one under the same SONAME family) is reused by dlopen
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void *h = nullptr;
-    for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) GSX_FAIL("gsx_comm: cannot load librccl (%s)", dlerror());
-#define GSX_SYM(field, name)                                                          \
-    *reinterpret_cast<void **>(&g_rccl.field) = dlsym(h, name);                       \
-    if (!g_rccl.field) GSX_FAIL("gsx_comm: librccl has no symbol %s", name)
-    GSX_SYM(GetUniqueId, "ncclGetUniqueId");
-    GSX_SYM(CommInitRank, "ncclCommInitRank");
-    GSX_SYM(CommDestroy, "ncclCommDestroy");
-    GSX_SYM(GetErrorString, "ncclGetErrorString");
-    GSX_SYM(AllReduce, "ncclAllReduce");
-    GSX_SYM(AllGather, "ncclAllGather");
-    GSX_SYM(Send, "ncclSend");
-    GSX_SYM(Recv, "ncclRecv");
-    GSX_SYM(GroupStart, "ncclGroupStart");
-    GSX_SYM(GroupEnd, "ncclGroupEnd");
-#undef GSX_SYM
-    g_rccl.h = h;
-    return 0;
-}
-
-#define GSX_RCCL(call)                                                                                  \
-    do {                                                                                                \
-        int r__ = (call);                                                                               \
-        if (r__ != 0) GSX_FAIL("%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "?"); \
-    } while (0)
 
 // ---------------------------------------------------------------- slab kernels
 __device__ __forceinline__ void amax_f32(float *addr, float v)  // finite v; *addr starts at -inf
@@ -277,6 +221,45 @@ __global__ __launch_bounds__(256) void slab_certify_kernel(const float *__restri
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(n_uncertain, bad);
 }
 
+// ---------------------------------------------------------------- the fused step (gsx_sor_slab_step_dev)
+// one launch instead of five memsets / tiny uploads: the box words, the histogram, the partition cursors and the
+// certificate counter of a step start from here
+__global__ __launch_bounds__(256) void slab_clear_kernel(float *__restrict__ b7, unsigned *__restrict__ hist,
+                                                         unsigned *__restrict__ small_words /* cursor[32] | uncertain[2] */)
+{
+    for (int i = threadIdx.x; i < SLAB_BINS; i += 256) hist[i] = 0;
+    if (threadIdx.x < 8) b7[threadIdx.x] = threadIdx.x < 6 ? -__builtin_inff() : 0.0f;
+    if (threadIdx.x < 34) small_words[threadIdx.x] = 0;
+}
+
+// all-gathered piece sums sit at a stride of max_pieces per rank; numpy's sequential fold wants them back to back
+struct PackPlan {
+    int world;
+    int stride;
+    int count[SLAB_MAX_RANKS];
+};
+__global__ __launch_bounds__(256) void slab_pack_pieces_kernel(const float *__restrict__ all, PackPlan p, float *__restrict__ out)
+{
+    int o = 0;
+    for (int q = 0; q < p.world; ++q) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < p.count[q]; i += gridDim.x * 256) out[o + i] = all[(size_t)q * p.stride + i];
+        o += p.count[q];
+    }
+}
+
+int launch_sor_mask(gsx_ctx *ctx, const float *md, int64_t n, const float *thr_dev, uint8_t *mask);
+
+// cell population of the KNN grid for n reference points (the rule of knn_grid_level in sor_grid.hip; Python restates
+// it as dist_slab.pts_per_cell)
+static double slab_pts_per_cell(int k, int64_t n)
+{
+    double m = std::max(2.0, 0.47 * (double)(k + 1));
+    const double fill = n >= 4000000 ? 54.0 : 58.0;
+    for (int cells = 8; cells >= 1; cells /= 2)
+        if (m * cells > fill && m * cells <= 66.0) m = fill / cells;
+    return m;
+}
+
 int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
                     int64_t n_halo, int k, float *mean_out, double *kth_out);
 int launch_sor_piece_sums(gsx_ctx *ctx, const float *a, int64_t n, const float *mean_dev, float *piece_out);
@@ -287,114 +270,7 @@ int launch_sor_stats_from_pieces(gsx_ctx *ctx, const float *pieces, int64_t npie
 
 using namespace gsx;
 
-struct gsx_comm {
-    rcclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-};
-
 extern "C" {
-
-int gsx_comm_unique_id(void *out128)
-{
-    if (!out128) GSX_FAIL("gsx_comm_unique_id: null argument");
-    GSX_CHECK(rccl_load());
-    rcclUniqueId id;
-    GSX_RCCL(g_rccl.GetUniqueId(&id));
-    memcpy(out128, &id, sizeof(id));
-    return 0;
-}
-
-int gsx_comm_init(gsx_ctx *c, int rank, int world, const void *id128)
-{
-    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) GSX_FAIL("gsx_comm_init: bad arguments");
-    if (world > SLAB_MAX_RANKS) GSX_FAIL("gsx_comm_init: at most %d ranks (one node)", SLAB_MAX_RANKS);
-    GSX_CHECK(rccl_load());
-    GSX_HIP(hipSetDevice(c->device));
-    if (c->comm) GSX_FAIL("gsx_comm_init: the context already has a communicator");
-    gsx_comm *m = new gsx_comm();
-    rcclUniqueId id;
-    memcpy(&id, id128, sizeof(id));
-    int r = g_rccl.CommInitRank(&m->comm, world, id, rank);
-    if (r != 0) {
-        delete m;
-        GSX_FAIL("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
-    }
-    m->rank = rank;
-    m->world = world;
-    c->comm = m;
-    return 0;
-}
-
-int gsx_comm_destroy(gsx_ctx *c)
-{
-    if (!c || !c->comm) return 0;
-    gsx_comm *m = static_cast<gsx_comm *>(c->comm);
-    if (m->comm) (void)g_rccl.CommDestroy(m->comm);
-    delete m;
-    c->comm = nullptr;
-    return 0;
-}
-
-static int dtype_of(int elem_bytes, int *out)
-{
-    if (elem_bytes == 1) { *out = RCCL_INT8; return 0; }
-    if (elem_bytes == 4) { *out = RCCL_FLOAT32; return 0; }
-    if (elem_bytes == 8) { *out = RCCL_INT64; return 0; }
-    GSX_FAIL("gsx_comm: element size %d not supported", elem_bytes);
-}
-
-/* in place; kind: 0 = f32 max, 1 = f32 sum, 2 = i64 sum */
-int gsx_comm_all_reduce(gsx_ctx *c, void *buf_dev, int64_t count, int kind)
-{
-    if (!c || !c->comm || !buf_dev) GSX_FAIL("gsx_comm_all_reduce: no communicator / null buffer");
-    gsx_comm *m = static_cast<gsx_comm *>(c->comm);
-    const int dt = kind == 2 ? RCCL_INT64 : RCCL_FLOAT32, op = kind == 0 ? RCCL_MAX : RCCL_SUM;
-    GSX_RCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, dt, op, m->comm, c->stream));
-    return 0;
-}
-
-int gsx_comm_all_gather(gsx_ctx *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank)
-{
-    if (!c || !c->comm || !send_dev || !recv_dev) GSX_FAIL("gsx_comm_all_gather: no communicator / null buffer");
-    gsx_comm *m = static_cast<gsx_comm *>(c->comm);
-    GSX_RCCL(g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, RCCL_INT8, m->comm, c->stream));
-    return 0;
-}
-
-/* offsets and counts in ELEMENTS of elem_bytes, one entry per peer (host arrays); the local block is copied */
-int gsx_comm_all_to_all_v(gsx_ctx *c, const void *send_dev, const int64_t *send_off, const int64_t *send_cnt, void *recv_dev,
-                          const int64_t *recv_off, const int64_t *recv_cnt, int elem_bytes)
-{
-    if (!c || !c->comm || !send_off || !send_cnt || !recv_off || !recv_cnt)
-        GSX_FAIL("gsx_comm_all_to_all_v: no communicator / null argument");
-    gsx_comm *m = static_cast<gsx_comm *>(c->comm);
-    int dt;
-    GSX_CHECK(dtype_of(elem_bytes == 12 ? 4 : elem_bytes, &dt));
-    const size_t mul = elem_bytes == 12 ? 3 : 1;   // rows of 3 floats travel as floats
-    const size_t eb = elem_bytes;
-    bool remote = false;
-    for (int p = 0; p < m->world; ++p) remote |= p != m->rank && (send_cnt[p] > 0 || recv_cnt[p] > 0);
-    if (remote) {   // (an empty group still costs RCCL bookkeeping)
-        GSX_RCCL(g_rccl.GroupStart());
-        for (int p = 0; p < m->world; ++p) {
-            if (p == m->rank) continue;
-            if (send_cnt[p] > 0)
-                GSX_RCCL(g_rccl.Send(static_cast<const char *>(send_dev) + eb * (size_t)send_off[p], (size_t)send_cnt[p] * mul, dt, p,
-                                     m->comm, c->stream));
-            if (recv_cnt[p] > 0)
-                GSX_RCCL(g_rccl.Recv(static_cast<char *>(recv_dev) + eb * (size_t)recv_off[p], (size_t)recv_cnt[p] * mul, dt, p,
-                                     m->comm, c->stream));
-        }
-        GSX_RCCL(g_rccl.GroupEnd());
-    }
-    const int me = m->rank;
-    if (send_cnt[me] != recv_cnt[me]) GSX_FAIL("gsx_comm_all_to_all_v: local block sizes differ");
-    if (send_cnt[me] > 0)
-        GSX_HIP(hipMemcpyAsync(static_cast<char *>(recv_dev) + eb * (size_t)recv_off[me],
-                               static_cast<const char *>(send_dev) + eb * (size_t)send_off[me], eb * (size_t)send_cnt[me],
-                               hipMemcpyDeviceToDevice, c->stream));
-    return 0;
-}
 
 /* ---- slab exchange: device-side pieces (usable without a communicator: world = 1 or an emulated exchange) ---- */
 int gsx_slab_bbox_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, float *out7_dev)
@@ -541,6 +417,292 @@ int gsx_sor_stats_from_pieces_dev(gsx_ctx *c, const float *pieces_dev, int64_t n
     if (!c || !pieces_dev || !stats_dev || npieces <= 0 || n_total <= 0) GSX_FAIL("gsx_sor_stats_from_pieces_dev: bad arguments");
     GSX_HIP(hipSetDevice(c->device));
     return launch_sor_stats_from_pieces(c, pieces_dev, npieces, n_total, mode, threshold_factor, stats_dev);
+}
+
+/* The slab plan of one step from what the step's host synchronisation brings back: words[0..7) = the all-reduced box
+ * words (max of -x,-y,-z,x,y,z; non-finite flag), words[8 + 4096 q ...] = rank q's histogram of the longest axis.
+ * Pure host arithmetic (no device, no communicator): every rank computes the identical plan from identical words.
+ * Python restates it (dist_slab.plan_step) for the CPU tests of the choreography; tests/test_dist_cpu.py pins one
+ * against the other. */
+int gsx_slab_plan(const uint32_t *words, int world, int rank, int64_t n_local, int k, double halo_cells, gsx_slab_plan_t *out)
+{
+    if (!words || !out || world < 1 || world > SLAB_MAX_RANKS || rank < 0 || rank >= world || k < 1) GSX_FAIL("gsx_slab_plan: bad arguments");
+    memset(out, 0, sizeof(*out));
+    const int G = world;
+    float hb[7];
+    memcpy(hb, words, sizeof(hb));
+    const uint32_t *hist = words + 8;
+    out->world = G;
+    out->rank = rank;
+    out->n_local = n_local;
+    // cumulative histograms: per rank and global
+    std::vector<int64_t> cum((size_t)(G + 1) * (SLAB_BINS + 1), 0);
+    int64_t *gc = cum.data() + (size_t)G * (SLAB_BINS + 1);
+    for (int q = 0; q < G; ++q) {
+        int64_t *c = cum.data() + (size_t)q * (SLAB_BINS + 1);
+        for (int b = 0; b < SLAB_BINS; ++b) c[b + 1] = c[b] + (int64_t)hist[(size_t)q * SLAB_BINS + b];
+        out->sizes[q] = c[SLAB_BINS];
+    }
+    for (int b = 0; b <= SLAB_BINS; ++b) {
+        int64_t t = 0;
+        for (int q = 0; q < G; ++q) t += cum[(size_t)q * (SLAB_BINS + 1) + b];
+        gc[b] = t;
+    }
+    const int64_t n_total = gc[SLAB_BINS];
+    out->n_total = n_total;
+    if (n_total == 0) { out->status = GSX_SLAB_EMPTY; return 0; }
+    bool finite = !(hb[6] > 0.0f);
+    for (int a = 0; a < 6; ++a) finite = finite && std::isfinite(hb[a]);
+    if (!finite) { out->status = GSX_SLAB_NONFINITE; return 0; }
+    const float ext[3] = {hb[3] + hb[0], hb[4] + hb[1], hb[5] + hb[2]};   // float32, like the device (slab_axis)
+    int axis = 0;
+    if (ext[1] > ext[0]) axis = 1;
+    if (ext[2] > std::max(ext[0], ext[1])) axis = 2;
+    const float lo = -hb[axis], hi = hb[3 + axis];
+    out->axis = axis;
+    out->lo = lo;
+    out->hi = hi;
+    // equal-count cuts: slab s owns bins [cut[s], cut[s+1])
+    out->cut[0] = 0;
+    for (int s = 1; s < G; ++s) {
+        const int64_t target = (n_total * s) / G;
+        int b = (int)(std::lower_bound(gc, gc + SLAB_BINS + 1, target) - gc);
+        out->cut[s] = std::min(std::max(b, out->cut[s - 1]), SLAB_BINS);
+    }
+    out->cut[G] = SLAB_BINS;
+    if (out->sizes[rank] != n_local) GSX_FAIL("gsx_slab_plan: %lld rows given, %lld binned", (long long)n_local, (long long)out->sizes[rank]);
+    if (G > 1) {
+        int64_t mn = out->sizes[0];
+        for (int q = 1; q < G; ++q) mn = std::min(mn, out->sizes[q]);
+        if (mn < 8192) { out->status = GSX_SLAB_SMALL_SHARD; return 0; }
+    }
+    // halo width: halo_cells KNN cell edges of the global density, in whole bins
+    double vol = 1.0;
+    int nd = 0;
+    for (int a = 0; a < 3; ++a)
+        if ((double)ext[a] > 0.0) {
+            vol *= (double)ext[a];
+            ++nd;
+        }
+    const double per = nd ? vol * slab_pts_per_cell(k, n_total / G) / (double)n_total : 0.0;
+    const double h_est = nd ? std::pow(per, 1.0 / (double)nd) : 0.0;
+    const double bw = hi > lo ? ((double)hi - (double)lo) / SLAB_BINS : 0.0;
+    const int halo_bins = bw > 0.0 ? (int)std::ceil(halo_cells * h_est / bw) + 1 : SLAB_BINS;
+    out->halo_bins = halo_bins;
+    // rows every source sends every slab (membership is decided by bin index: no counting pass)
+    int64_t halo_sum = 0;
+    for (int s = 0; s < G; ++s) {
+        const int a = out->cut[s], b = out->cut[s + 1];
+        const int ha = std::max(a - halo_bins, 0), hbn = std::min(b + halo_bins, SLAB_BINS);
+        for (int q = 0; q < G; ++q) {
+            const int64_t *c = cum.data() + (size_t)q * (SLAB_BINS + 1);
+            const int64_t own = c[b] - c[a], halo = (c[hbn] - c[ha]) - own;
+            halo_sum += halo;
+            if (q == rank) { out->own_cnt[s] = own; out->halo_cnt[s] = halo; }
+            if (s == rank) { out->in_own[q] = own; out->in_halo[q] = halo; }
+        }
+    }
+    out->halo_total = halo_sum;
+    if (G > 1 && (double)halo_sum > 0.75 * (double)(G - 1) * (double)n_total) { out->status = GSX_SLAB_NO_STRUCTURE; return 0; }
+    int64_t o = 0, ho = n_local, ro = 0;
+    for (int s = 0; s < G; ++s) { out->own_off[s] = o; o += out->own_cnt[s]; }
+    for (int s = 0; s < G; ++s) { out->halo_off[s] = ho; ho += out->halo_cnt[s]; }
+    out->n_send = ho;
+    for (int q = 0; q < G; ++q) { out->r_own_off[q] = ro; ro += out->in_own[q]; }
+    out->n_own = ro;
+    for (int q = 0; q < G; ++q) { out->r_halo_off[q] = ro; ro += out->in_halo[q]; }
+    out->n_halo = ro - out->n_own;
+    // slab s holds every point whose bin is in [cut[s] - halo_bins, cut[s+1] + halo_bins).  bin(c) is a monotone f32
+    // function of c whose steps sit within ~1e-3 of a bin of lo + b * bw: half a bin inside is safely inside.
+    {
+        const int b0 = out->cut[rank] - halo_bins, b1 = out->cut[rank + 1] + halo_bins;
+        out->plane_lo = (rank == 0 || b0 <= 0) ? -INFINITY : (float)((double)lo + ((double)b0 + 0.5) * bw);
+        out->plane_hi = (rank == G - 1 || b1 >= SLAB_BINS) ? INFINITY : (float)((double)lo + ((double)b1 - 0.5) * bw);
+    }
+    return 0;
+}
+
+/* One multi-GPU SOR step of this rank, start to finish (the choreography dist_slab.slab_sor spells out, with the
+ * communicator gsx_comm_init gave the context; world = 1 without one): box -> all-reduce -> histogram -> all-gather ->
+ * [the step's one host synchronisation: plan] -> partition -> rows to the slab owners (+ halo) -> exact KNN -> certificate
+ * -> all-reduce -> means back -> un-permute -> numpy-exact statistics from all-gathered piece sums -> mask.
+ * Returns 0 with out->status != 0 when the step declines (decided from gathered data: every rank declines together). */
+int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, int k, double threshold_factor, double halo_cells,
+                          uint8_t *mask_out_dev, gsx_slab_step_t *out)
+{
+    if (!c || !out || n_local < 0 || (n_local > 0 && !rows_dev)) GSX_FAIL("gsx_sor_slab_step_dev: bad arguments");
+    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_slab_step_dev: k=%d not supported (1 <= k <= 64)", k);
+    if (n_local >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_slab_step_dev: shard too large");
+    GSX_HIP(hipSetDevice(c->device));
+    memset(out, 0, sizeof(*out));
+    int G = 1, r = 0;
+    GSX_CHECK(gsx_comm_rank(c, &r, &G));
+    const bool wire = gsx_comm_transport(c) != 0;
+    SlabWs &w = c->slab_ws;
+    const float *x = rows_dev, *y = rows_dev + 1, *z = rows_dev + 2;
+    // ---- 1./2. box, histogram (device-resident between them), gathered into plan_in
+    const size_t plan_words = 8 + (size_t)SLAB_BINS * G;
+    GSX_CHECK(w.plan_in.reserve(4 * plan_words));
+    GSX_CHECK(w.hist.reserve(4 * SLAB_BINS));
+    GSX_CHECK(w.small.reserve(1024));
+    if (w.host_cap < 4 * plan_words) {
+        if (w.host) (void)hipHostFree(w.host);
+        w.host = nullptr;
+        GSX_HIP(hipHostMalloc(&w.host, 4 * plan_words, hipHostMallocDefault));
+        w.host_cap = 4 * plan_words;
+    }
+    float *b7 = w.plan_in.as<float>();
+    unsigned *hist_all = w.plan_in.as<unsigned>() + 8;
+    unsigned *hist_mine = G > 1 ? w.hist.as<unsigned>() : hist_all;
+    unsigned *cursor = w.small.as<unsigned>();
+    unsigned *unc = cursor + 32;
+    float *stats = reinterpret_cast<float *>(cursor + 36);
+    hipLaunchKernelGGL(slab_clear_kernel, dim3(1), dim3(256), 0, c->stream, b7, hist_mine, cursor);
+    if (n_local > 0) {
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 2048), (int64_t)c->num_cu * 2));
+        hipLaunchKernelGGL(slab_bbox_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, b7);
+    }
+    GSX_HIP(hipGetLastError());
+    if (G > 1) GSX_CHECK(gsx_comm_all_reduce(c, b7, 7, GSX_COMM_F32_MAX));
+    if (n_local > 0) {
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 4096), (int64_t)c->num_cu * 4));
+        hipLaunchKernelGGL(slab_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, b7, hist_mine);
+        GSX_HIP(hipGetLastError());
+    }
+    if (G > 1) GSX_CHECK(gsx_comm_all_gather(c, hist_mine, hist_all, 4 * SLAB_BINS));
+    GSX_HIP(hipMemcpyAsync(w.host, w.plan_in.p, 4 * plan_words, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));                                    // <- the step's host synchronisation
+    gsx_slab_plan_t &p = out->plan;
+    GSX_CHECK(gsx_slab_plan(static_cast<const uint32_t *>(w.host), G, r, n_local, k, halo_cells, &p));
+    out->status = p.status;
+    if (p.status != 0) return 0;
+    // ---- 3. scatter into the send buffer, rows to the slab owners (own + reference-only halo) in ONE group
+    const int64_t n_own = p.n_own, n_halo = p.n_halo;
+    GSX_CHECK(w.send.reserve(12 * (size_t)std::max<int64_t>(p.n_send, 1)));
+    GSX_CHECK(w.send_src.reserve(4 * (size_t)std::max<int64_t>(n_local, 1)));
+    GSX_CHECK(w.slab.reserve(12 * (size_t)std::max<int64_t>(n_own + n_halo, 1)));
+    SlabPlan sp;
+    sp.world = G;
+    sp.axis = p.axis;
+    sp.lo = p.lo;
+    sp.inv_w = p.hi > p.lo ? (float)SLAB_BINS / (p.hi - p.lo) : 0.0f;
+    sp.halo_bins = p.halo_bins;
+    for (int s = 0; s <= G; ++s) sp.cut[s] = p.cut[s];
+    for (int s = 0; s < G; ++s) {
+        sp.off[2 * s] = (unsigned)p.own_off[s];
+        sp.off[2 * s + 1] = (unsigned)p.halo_off[s];
+    }
+    if (n_local > 0) {
+        hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n_local, 2048)), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, sp,
+                           cursor, w.send.as<float>(), w.send_src.as<unsigned>());
+        GSX_HIP(hipGetLastError());
+    }
+    const float *slab_rows = w.slab.as<float>();
+    if (wire) {
+        int64_t so[2 * SLAB_MAX_RANKS], sc[2 * SLAB_MAX_RANKS], ro[2 * SLAB_MAX_RANKS], rc[2 * SLAB_MAX_RANKS];
+        for (int q = 0; q < G; ++q) {
+            so[q] = p.own_off[q]; sc[q] = p.own_cnt[q]; ro[q] = p.r_own_off[q]; rc[q] = p.in_own[q];
+            so[G + q] = p.halo_off[q]; sc[G + q] = p.halo_cnt[q]; ro[G + q] = p.r_halo_off[q]; rc[G + q] = p.in_halo[q];
+        }
+        GSX_CHECK(gsx_comm_all_to_all_segs(c, w.send.p, w.slab.p, 2, so, sc, ro, rc, 12));
+    } else {
+        slab_rows = w.send.as<float>();   // no communicator: the (permuted) send buffer IS the slab
+    }
+    // ---- 4./5. exact KNN on the slab; certificate (device-side count, summed over the ranks, read lazily by the caller)
+    GSX_CHECK(w.md_slab.reserve(4 * (size_t)std::max<int64_t>(n_own, 1)));
+    GSX_CHECK(w.kth.reserve(8 * (size_t)std::max<int64_t>(n_own, 1)));
+    if (n_own > 0) {
+        GSX_CHECK(launch_knn_slab(c, slab_rows, slab_rows + 1, slab_rows + 2, 3, n_own, n_halo, k, w.md_slab.as<float>(), w.kth.as<double>()));
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_own, 1024), (int64_t)c->num_cu * 8));
+        hipLaunchKernelGGL(slab_certify_kernel, dim3(blocks), dim3(256), 0, c->stream, slab_rows + p.axis, (int64_t)3, n_own, w.kth.as<double>(),
+                           p.plane_lo, p.plane_hi, unc);
+        GSX_HIP(hipGetLastError());
+    }
+    if (G > 1) GSX_CHECK(gsx_comm_all_reduce(c, unc, 1, GSX_COMM_I64_SUM));
+    // ---- 6. mean distances back to the index owners, original order
+    GSX_CHECK(w.md.reserve(4 * (size_t)(n_local + 8192 + 4)));
+    const float *ret = w.md_slab.as<float>();
+    if (wire) {
+        GSX_CHECK(w.ret.reserve(4 * (size_t)std::max<int64_t>(n_local, 1)));
+        GSX_CHECK(gsx_comm_all_to_all_segs(c, w.md_slab.p, w.ret.p, 1, p.r_own_off, p.in_own, p.own_off, p.own_cnt, 4));
+        ret = w.ret.as<float>();
+    }
+    float *md = w.md.as<float>();
+    if (n_local > 0) {
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 1024), (int64_t)c->num_cu * 8));
+        hipLaunchKernelGGL(slab_unpermute_kernel, dim3(blocks), dim3(256), 0, c->stream, ret, w.send_src.as<unsigned>(), n_local, md);
+        GSX_HIP(hipGetLastError());
+    }
+    // ---- 7. numpy-exact statistics from 8192-element piece sums (pieces are cut at the true GLOBAL offsets: the
+    // < 8192 leading elements of a shard belong to the left neighbour's last piece and are handed over)
+    int64_t starts[SLAB_MAX_RANKS + 1], heads[SLAB_MAX_RANKS + 1];
+    starts[0] = 0;
+    for (int q = 0; q < G; ++q) starts[q + 1] = starts[q] + p.sizes[q];
+    for (int q = 0; q < G; ++q) heads[q] = (8192 - starts[q] % 8192) % 8192;
+    heads[G] = 0;
+    const int64_t head = heads[r], nxt_head = heads[r + 1];
+    const float *st_in;
+    float *st_tail;
+    if (head % 4 == 0) {
+        st_in = md + head;
+        st_tail = md + n_local;
+    } else {   // piece sums read 16 bytes at a time: an aligned copy (4 B/point, device copy)
+        GSX_CHECK(w.md_stats.reserve(4 * (size_t)(n_local + 8192 + 4)));
+        GSX_HIP(hipMemcpyAsync(w.md_stats.p, md + head, 4 * (size_t)(n_local - head), hipMemcpyDeviceToDevice, c->stream));
+        st_in = w.md_stats.as<float>();
+        st_tail = w.md_stats.as<float>() + (n_local - head);
+    }
+    if (G > 1) {
+        int64_t so[SLAB_MAX_RANKS] = {0}, sc[SLAB_MAX_RANKS] = {0}, ro[SLAB_MAX_RANKS] = {0}, rc[SLAB_MAX_RANKS] = {0};
+        if (r > 0) sc[r - 1] = head;
+        if (r + 1 < G) rc[r + 1] = nxt_head;
+        // (send from md[0..head), receive behind the own elements: st_tail is addressed relative to md / md_stats)
+        if (head % 4 == 0) {
+            for (int q = 0; q < G; ++q) ro[q] = n_local;
+            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, md, 1, so, sc, ro, rc, 4));
+        } else {
+            for (int q = 0; q < G; ++q) ro[q] = n_local - head;
+            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, w.md_stats.p, 1, so, sc, ro, rc, 4));
+        }
+    }
+    (void)st_tail;
+    const int64_t n_mine = n_local - head + nxt_head;
+    PackPlan pk;
+    pk.world = G;
+    int max_pieces = 0, total_pieces = 0;
+    for (int q = 0; q < G; ++q) {
+        const int64_t nq = p.sizes[q] - heads[q] + heads[q + 1];
+        pk.count[q] = (int)((nq + 8191) / 8192);
+        max_pieces = std::max(max_pieces, pk.count[q]);
+        total_pieces += pk.count[q];
+    }
+    pk.stride = max_pieces;
+    GSX_CHECK(w.pieces.reserve(4 * (size_t)std::max(max_pieces, 1)));
+    GSX_CHECK(w.allpieces.reserve(4 * (size_t)std::max(max_pieces, 1) * G));
+    GSX_CHECK(w.packed.reserve(4 * (size_t)std::max(total_pieces, 1)));
+    for (int mode = 0; mode < 2; ++mode) {
+        if (n_mine > 0) GSX_CHECK(launch_sor_piece_sums(c, st_in, n_mine, mode ? stats : nullptr, w.pieces.as<float>()));
+        const float *pieces = w.pieces.as<float>();
+        if (G > 1) {
+            GSX_CHECK(gsx_comm_all_gather(c, w.pieces.p, w.allpieces.p, 4 * (int64_t)max_pieces));
+            hipLaunchKernelGGL(slab_pack_pieces_kernel, dim3(4), dim3(256), 0, c->stream, w.allpieces.as<float>(), pk, w.packed.as<float>());
+            GSX_HIP(hipGetLastError());
+            pieces = w.packed.as<float>();
+        }
+        GSX_CHECK(launch_sor_stats_from_pieces(c, pieces, total_pieces, p.n_total, mode, threshold_factor, stats));
+    }
+    // ---- 8. mask of the local index range
+    uint8_t *mask = mask_out_dev;
+    if (!mask) {
+        GSX_CHECK(w.mask.reserve((size_t)n_local + 16));
+        mask = w.mask.as<uint8_t>();
+    }
+    GSX_CHECK(launch_sor_mask(c, md, n_local, stats + 2, mask));
+    out->mask_dev = mask;
+    out->mean_dists_dev = md;
+    out->stats_dev = stats;
+    out->uncertain_dev = reinterpret_cast<const int64_t *>(unc);
+    return 0;
 }
 
 }  // extern "C"

@@ -111,6 +111,33 @@ struct TreeWs {
     }
 };
 
+// Buffers of one multi-GPU slab step (dist_slab.hip: gsx_sor_slab_step_dev); grow-only like the rest
+struct SlabWs {
+    DevBuf plan_in;    // 8 words (global box) + 4096 u32 per rank (all-gathered histograms)
+    DevBuf hist;       // u32[4096]: this rank's histogram (send side of the all-gather)
+    DevBuf small;      // u32 cursor[32] | u32 uncertain[2] (all-reduced as one int64) | f32 stats[4] | i64 pack table
+    DevBuf send;       // float[3 * n_send]: rows grouped by destination slab (own rows, then halo copies)
+    DevBuf send_src;   // u32[n_local]: local index of every own row of the send buffer
+    DevBuf slab;       // float[3 * (n_own + n_halo)]: what this rank received
+    DevBuf md_slab;    // f32[n_own]
+    DevBuf kth;        // f64[n_own]
+    DevBuf ret;        // f32[n_local]: mean distances in send order
+    DevBuf md;         // f32[n_local + 8192 + 4]: ... in index order (+ the right neighbour's head elements)
+    DevBuf md_stats;   // aligned copy for piece sums when the first own piece starts off a 16-byte boundary
+    DevBuf pieces, allpieces, packed;   // numpy's 8192-element piece sums: mine | all-gathered (padded) | packed
+    DevBuf mask;       // u8[n_local] when the caller brings no buffer
+    void *host = nullptr;   // pinned staging of plan_in (the step's one host synchronisation)
+    size_t host_cap = 0;
+    void release_all()
+    {
+        DevBuf *all[] = {&plan_in, &hist, &small, &send, &send_src, &slab, &md_slab, &kth, &ret, &md, &md_stats, &pieces, &allpieces, &packed, &mask};
+        for (auto b : all) b->release();
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
+        host_cap = 0;
+    }
+};
+
 struct TimingSlot {
     std::vector<hipEvent_t> ev;  // pairs: start, stop
     size_t used = 0;
@@ -147,6 +174,8 @@ struct gsx_ctx {
     // SOR workspace: one KnnWs per refinement level of the KNN grid (level 0 = the whole cloud)
     gsx::KnnWs ws[gsx::KNN_MAX_LEVELS];
     gsx::TreeWs tree_ws;     // Morton-tree KNN workspace
+    gsx::SlabWs slab_ws;     // multi-GPU slab step
+    gsx::DevBuf commscratch; // gsx_comm_barrier's word
     gsx::DevBuf devflags;    // u32[16]: device-side error word (bit 0: non-finite coordinates), read by gsx_ctx_check
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging

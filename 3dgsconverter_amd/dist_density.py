@@ -60,9 +60,9 @@ def sharded_density(be, comm, rows, n_local: int, voxel_size=1.0, threshold_perc
         if umax == 0:
             return out
         gk, gc = be.buf("dd_gkeys", 24 * umax * G), be.buf("dd_gcounts", 8 * umax * G)
-        keys = be.buf("dd_keys", 24 * umax)       # (grow-only: the first u_local entries are kept)
-        counts = be.buf("dd_counts", 8 * umax)
-        if u_local < umax:                        # padding entries carry count 0 and key of entry 0: they add nothing
+        keys = be.buf("dd_keys", 24 * umax, keep=24 * u_local)       # (a reallocation keeps the first u_local entries:
+        counts = be.buf("dd_counts", 8 * umax, keep=8 * u_local)     #  a tiny shard next to a large one)
+        if u_local < umax:                        # padding entries carry count 0: the merge ignores them, keys included
             be.pad_density_list(keys, counts, u_local, umax)
         comm.all_gather(keys, gk, 24 * umax)
         comm.all_gather(counts, gc, 8 * umax)

@@ -30,8 +30,11 @@ csrc/dist_slab.hip), this module only moves sizes and offsets around:
      all-gathered: bit-identical mean / std / threshold without gathering the array;
   8. mask of the local index range.
 
-``Comm`` / backend are injectable: ``RcclComm`` + ``HipSlabBackend`` is the product; tests/ run the
-same choreography on CPU with gloo and a numpy backend built on the oracle (never the product).
+The product runs the whole step as ONE C call (``gsx_sor_slab_step_dev``, csrc/dist_slab.hip: ``LibSlab`` below /
+``slab_sor`` on a ``HipSlabBackend``), with the collectives of ``gsx_comm_*`` (csrc/comm.hip: RCCL, or the shared-memory
+"hostwire" when ranks share a GPU).  ``slab_sor_steps`` spells the same choreography out call by call over an injectable
+``Comm`` / backend: tests/ run it on CPU with gloo and a numpy backend built on the oracle (never the product), and on the
+GPU against the fused call.  No torch anywhere in this module.
 """
 from __future__ import annotations
 
@@ -39,7 +42,7 @@ import ctypes as C
 
 import numpy as np
 
-KIND_F32_MAX, KIND_F32_SUM, KIND_I64_SUM = 0, 1, 2
+KIND_F32_MAX, KIND_F32_SUM, KIND_I64_SUM, KIND_F64_MAX, KIND_I64_MIN = 0, 1, 2, 3, 4   # GSX_COMM_* (include/gsx_hip.h)
 NP_PIECE = 8192   # numpy's reduction buffer (elements): see csrc/sor_stats.hip
 BINS = 4096
 
@@ -61,7 +64,8 @@ class SlabUnsupported(SlabUncertain):
 
 # ------------------------------------------------------------------------------------------ communicators
 class RcclComm:
-    """RCCL through the C ABI (gsx_comm_*), on the backend context's stream.  Buffers: anything with ``.ptr``."""
+    """The C library's communicator (gsx_comm_*) on the backend context's stream: RCCL, or -- when the unique id was made
+    under GSX_COMM_TRANSPORT=hostwire -- shared-memory outboxes for ranks that share a GPU.  Buffers: anything with ``.ptr``."""
 
     def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
         from . import _lib
@@ -72,17 +76,41 @@ class RcclComm:
         atexit.register(self.close)   # before the interpreter tears the HIP / RCCL libraries down
 
     def close(self):
-        """ncclCommDestroy (idempotent)"""
+        """ncclCommDestroy / unlink of the shared-memory outbox (idempotent)"""
         if self.ctx is not None and getattr(self.ctx, "handle", None):
             self.ctx.lib.gsx_comm_destroy(self.ctx.handle)
         self.ctx = None
 
+    def abort(self):
+        """tell the peers this rank gives up (hostwire: their barriers fail at once instead of timing out)"""
+        if self.ctx is not None and getattr(self.ctx, "handle", None):
+            self.ctx.lib.gsx_comm_abort(self.ctx.handle)
+
+    @property
+    def transport(self) -> str:
+        return {0: "none", 1: "rccl", 2: "hostwire"}[int(self.ctx.lib.gsx_comm_transport(self.ctx.handle))]
+
     @staticmethod
-    def unique_id() -> bytes:
+    def unique_id(transport: str | None = None) -> bytes:
+        """128 bytes made on rank 0 and handed to every rank (launch.py).  transport: None = GSX_COMM_TRANSPORT or rccl"""
+        import os
         from . import _lib
         buf = C.create_string_buffer(128)
-        _lib.check(_lib.load().gsx_comm_unique_id(buf), "gsx_comm_unique_id")
+        old = os.environ.get("GSX_COMM_TRANSPORT")
+        if transport is not None:
+            os.environ["GSX_COMM_TRANSPORT"] = transport
+        try:
+            _lib.check(_lib.load().gsx_comm_unique_id(buf), "gsx_comm_unique_id")
+        finally:
+            if transport is not None:
+                if old is None:
+                    os.environ.pop("GSX_COMM_TRANSPORT", None)
+                else:
+                    os.environ["GSX_COMM_TRANSPORT"] = old
         return buf.raw
+
+    def barrier(self):
+        self._lib.check(self.ctx.lib.gsx_comm_barrier(self.ctx.handle), "gsx_comm_barrier")
 
     def all_reduce(self, buf, count: int, kind: int):
         self._lib.check(self.ctx.lib.gsx_comm_all_reduce(self.ctx.handle, buf.ptr, int(count), int(kind)), "gsx_comm_all_reduce")
@@ -95,55 +123,20 @@ class RcclComm:
         self._lib.check(self.ctx.lib.gsx_comm_all_to_all_v(self.ctx.handle, send.ptr, arr(send_off), arr(send_cnt), recv.ptr,
                                                           arr(recv_off), arr(recv_cnt), int(elem_bytes)), "gsx_comm_all_to_all_v")
 
+    def all_to_all_segs(self, send, recv, segs, elem_bytes: int):
+        """segs: up to two (send_off, send_cnt, recv_off, recv_cnt) exchanges issued as ONE group"""
+        flat = lambda i: (C.c_int64 * (self.world * len(segs)))(*[int(x) for sg in segs for x in sg[i]])
+        self._lib.check(self.ctx.lib.gsx_comm_all_to_all_segs(self.ctx.handle, send.ptr, recv.ptr, len(segs), flat(0), flat(1), flat(2),
+                                                             flat(3), int(elem_bytes)), "gsx_comm_all_to_all_segs")
 
-class TorchHostComm:
-    """torch.distributed (gloo) on host memory: CPU tests of the choreography, and 2-process runs on a one-GPU box
-    (device buffers are staged through the host).  Never used by bench.py."""
-
-    def __init__(self, backend, group=None):
-        import torch.distributed as dist
-        self.dist, self.group, self.be = dist, group, backend
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-
-    def all_reduce(self, buf, count, kind):
-        import torch
-        dt = np.int64 if kind == KIND_I64_SUM else np.float32
-        a = self.be.to_host(buf, dt, count)
-        t = torch.from_numpy(a)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if kind == KIND_F32_MAX else self.dist.ReduceOp.SUM, group=self.group)
-        self.be.from_host(buf, t.numpy())
-
-    def all_gather(self, send, recv, nbytes):
-        import torch
-        a = torch.from_numpy(self.be.to_host(send, np.uint8, nbytes))
-        out = torch.empty(self.world * nbytes, dtype=torch.uint8)
-        self.dist.all_gather_into_tensor(out, a, group=self.group)
-        self.be.from_host(recv, out.numpy())
-
-    def all_to_all_v(self, send, send_off, send_cnt, recv, recv_off, recv_cnt, elem_bytes):
-        import torch
-        total_s = max(int(o + c) for o, c in zip(send_off, send_cnt))
-        total_r = max(int(o + c) for o, c in zip(recv_off, recv_cnt))
-        s = self.be.to_host(send, np.uint8, total_s * elem_bytes)
-        r = self.be.to_host(recv, np.uint8, total_r * elem_bytes) if total_r else np.zeros(0, np.uint8)
-        reqs, bufs = [], []
-        for p in range(self.world):
-            so, sc, ro, rc = int(send_off[p]), int(send_cnt[p]), int(recv_off[p]), int(recv_cnt[p])
-            if p == self.rank:
-                r[ro * elem_bytes:(ro + rc) * elem_bytes] = s[so * elem_bytes:(so + sc) * elem_bytes]
-                continue
-            if sc:
-                reqs.append(self.dist.isend(torch.from_numpy(s[so * elem_bytes:(so + sc) * elem_bytes].copy()), p, group=self.group))
-            if rc:
-                t = torch.empty(rc * elem_bytes, dtype=torch.uint8)
-                bufs.append((ro, rc, t))
-                reqs.append(self.dist.irecv(t, p, group=self.group))
-        for q in reqs:
-            q.wait()
-        for ro, rc, t in bufs:
-            r[ro * elem_bytes:(ro + rc) * elem_bytes] = t.numpy()
-        if total_r:
-            self.be.from_host(recv, r)
+    # host scalars through the device communicator (launchers: agreement flags, the MAX of the ranks' times)
+    def reduce_scalar(self, value, kind: int):
+        dt = np.float32 if kind in (KIND_F32_MAX, KIND_F32_SUM) else (np.float64 if kind == KIND_F64_MAX else np.int64)
+        if getattr(self, "_scalar", None) is None:
+            self._scalar = self.ctx.alloc(64)
+        self._scalar.upload(np.array([value], dtype=dt))
+        self.all_reduce(self._scalar, 1, kind)
+        return self._scalar.download(dt, 1)[0].item()
 
 
 # ------------------------------------------------------------------------------------------ device backend
@@ -169,14 +162,37 @@ class HipSlabBackend:
         self.lib = self.ctx.lib
         self._bufs = {}
 
-    def buf(self, name: str, nbytes: int):
+    def buf(self, name: str, nbytes: int, keep: int = 0):
+        """grow-only named buffer; `keep`: bytes of the old contents that survive a reallocation"""
         cur = self._bufs.get(name)
         if cur is None or cur.nbytes < nbytes:
+            new = self.ctx.alloc(int(nbytes * 1.125) + 256)
             if cur is not None:
+                if keep:
+                    self._chk(self.lib.gsx_dev_copy(self.ctx.handle, new.ptr, cur.ptr, min(int(keep), cur.nbytes)), "gsx_dev_copy")
+                    self.ctx.synchronize()
                 cur.free()
-            cur = self.ctx.alloc(int(nbytes * 1.125) + 256)
+            cur = new
             self._bufs[name] = cur
         return cur
+
+    def set_adaptive(self, on: bool):
+        """adaptive KNN for the calls below: exact and fast on clouds with far floaters -- what the
+        replicated exchange is the fallback for -- at the price of one host synchronisation per call"""
+        self.ctx.set_param("adaptive", 1 if on else 0)
+
+    # ---- the replicated exchange (dist.py)
+    def knn_share(self, xyz_all, n_total, k, share, nshares, md_all, algo=0):
+        """md_all[f32 n_total]: this share's mean distances at their original indices, +0.0 elsewhere"""
+        p = xyz_all.ptr
+        self.ctx.sor_knn_share(p, p + 4, p + 8, 3, int(n_total), int(k), int(share), int(nshares), md_all.ptr, algo=algo)
+
+    def knn_all(self, xyz_all, n, k, md, algo=0):
+        p = xyz_all.ptr
+        self.ctx.sor_knn(p, p + 4, p + 8, 3, int(n), 0, int(n), int(k), md.ptr, algo=algo)
+
+    def stats(self, md_all, n_total, threshold_factor, stats):
+        self.ctx.sor_stats(md_all.ptr, int(n_total), float(threshold_factor), stats.ptr)
 
     @staticmethod
     def at(buf, byte_off: int):
@@ -225,6 +241,17 @@ class HipSlabBackend:
     def copy(self, dst, src, nbytes):
         self._chk(self.lib.gsx_dev_copy(self.ctx.handle, dst.ptr, src.ptr, int(nbytes)), "gsx_dev_copy")
 
+    def slab_step(self, rows, n_local, k, threshold_factor, halo_cells=1.5, mask_out=None):
+        """the whole step in ONE C call (gsx_sor_slab_step_dev), with the context's communicator (none: world 1)"""
+        st = self._lib.SlabStep()
+        self._chk(self.lib.gsx_sor_slab_step_dev(self.ctx.handle, rows.ptr, int(n_local), int(k), float(threshold_factor), float(halo_cells),
+                                                 mask_out.ptr if mask_out is not None else None, C.byref(st)), "gsx_sor_slab_step_dev")
+        p = st.plan.as_dict()
+        _decline(p)
+        return SlabResult({"mask": _View(st.mask_dev), "mean_dists": _View(st.mean_dists_dev), "stats": _View(st.stats_dev),
+                           "uncertain": _View(st.uncertain_dev), "_be": self, "n_total": p["n_total"], "n_own": p["n_own"],
+                           "n_halo": p["n_halo"], "plan": p, "info": {"axis": p["axis"], "halo_bins": p["halo_bins"], "cut": p["cut"]}})
+
     def knn_slab(self, rows, n_own, n_halo, k, mean_out, kth_out):
         self._chk(self.lib.gsx_sor_knn_slab_dev(self.ctx.handle, rows.ptr, int(n_own), int(n_halo), int(k), mean_out.ptr, kth_out.ptr),
                   "gsx_sor_knn_slab_dev")
@@ -256,7 +283,7 @@ class HipSlabBackend:
         return int(nu.value)
 
     def pad_density_list(self, keys, counts, used, upto):
-        """entries [used, upto): count 0 (and any valid key: zeros)"""
+        """entries [used, upto): count 0 (gsx_density_merge_dev ignores the keys of such entries)"""
         self._chk(self.lib.gsx_dev_memset(self.ctx.handle, keys.ptr + 24 * int(used), 0, 24 * int(upto - used)), "gsx_dev_memset")
         self._chk(self.lib.gsx_dev_memset(self.ctx.handle, counts.ptr + 8 * int(used), 0, 8 * int(upto - used)), "gsx_dev_memset")
 
@@ -323,6 +350,82 @@ def slab_counts(allhist: np.ndarray, cut, halo_bins: int):
     return own, halo
 
 
+SLAB_OK, SLAB_EMPTY, SLAB_NONFINITE, SLAB_SMALL_SHARD, SLAB_NO_STRUCTURE = range(5)   # gsx_slab_plan_t.status
+
+
+def plan_step(words: np.ndarray, G: int, r: int, n_local: int, k: int, halo_cells: float = 1.5) -> dict:
+    """The plan of one step from what its host synchronisation brings back: words[0:7] = the all-reduced box words,
+    words[8:] = every rank's histogram.  The Python restatement of ``gsx_slab_plan`` (csrc/dist_slab.hip) -- same fields,
+    same arithmetic (tests/test_dist_cpu.py pins one against the other); every rank computes the identical plan."""
+    hb = words[:7].view(np.float32)
+    allhist = words[8:8 + BINS * G].reshape(G, BINS)
+    sizes = allhist.sum(1).astype(np.int64)          # every rank's shard size: the histograms hold every point once
+    p = {"status": SLAB_OK, "world": G, "rank": r, "n_local": int(n_local), "sizes": [int(v) for v in sizes], "n_total": int(sizes.sum())}
+    if p["n_total"] == 0:
+        p["status"] = SLAB_EMPTY
+        return p
+    if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
+        p["status"] = SLAB_NONFINITE
+        return p
+    ext = hb[3:6] + hb[:3]                                                     # float32, like the device (slab_axis)
+    axis = 0
+    if ext[1] > ext[0]:
+        axis = 1
+    if ext[2] > max(ext[0], ext[1]):
+        axis = 2
+    lo, hi = np.float32(-hb[axis]), np.float32(hb[3 + axis])
+    cut, n_total = plan_slabs(allhist.sum(0), G)
+    p.update(axis=axis, lo=float(lo), hi=float(hi), cut=cut)
+    if int(sizes[r]) != int(n_local):
+        raise ValueError("slab_sor: %d rows given, %d binned" % (n_local, int(sizes[r])))
+    if G > 1 and int(sizes.min()) < NP_PIECE:
+        p["status"] = SLAB_SMALL_SHARD
+        return p
+    ext64 = ext.astype(np.float64)
+    nd = int((ext64 > 0).sum())
+    vol = 1.0
+    for a in range(3):
+        if ext64[a] > 0:
+            vol *= float(ext64[a])
+    per = vol * pts_per_cell(k, n_total // G) / n_total if nd else 0.0        # (slabs are equal-COUNT)
+    h_est = per ** (1.0 / nd) if nd else 0.0
+    bw = (float(hi) - float(lo)) / BINS if hi > lo else 0.0
+    halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS
+    own, halo = slab_counts(allhist, cut, halo_bins)
+    p.update(halo_bins=halo_bins, halo_total=int(halo.sum()))
+    # a cloud whose halos amount to most of it (a scene inside a box inflated by far floaters: the halo width comes from the
+    # box-wide density) gains nothing from slabs -- every rank would receive nearly everything, search it, and then fail the
+    # certificate for the floaters anyway.  Decided from the gathered histograms: every rank declines in the same step.
+    if G > 1 and int(halo.sum()) > 0.75 * (G - 1) * n_total:
+        p["status"] = SLAB_NO_STRUCTURE
+        return p
+    own_cnt, halo_cnt = own[r], halo[r]
+    in_own, in_halo = own[:, r], halo[:, r]                                    # rows every source sends me
+    n_own, n_halo = int(in_own.sum()), int(in_halo.sum())
+    ex = lambda c, base=0: [int(v) for v in base + np.concatenate([[0], np.cumsum(c)[:-1]])]
+    p.update(own_cnt=[int(v) for v in own_cnt], halo_cnt=[int(v) for v in halo_cnt], own_off=ex(own_cnt), halo_off=ex(halo_cnt, int(n_local)),
+             in_own=[int(v) for v in in_own], in_halo=[int(v) for v in in_halo], r_own_off=ex(in_own), r_halo_off=ex(in_halo, n_own),
+             n_own=n_own, n_halo=n_halo, n_send=int(n_local) + int(halo_cnt.sum()))
+    lo64, hi64 = np.float64(lo), np.float64(hi)
+    b0, b1 = cut[r] - halo_bins, cut[r + 1] + halo_bins
+    p["plane_lo"] = float("-inf") if (r == 0 or b0 <= 0) else float(np.float32(lo64 + (b0 + 0.5) * bw))
+    p["plane_hi"] = float("inf") if (r == G - 1 or b1 >= BINS) else float(np.float32(lo64 + (b1 - 0.5) * bw))
+    return p
+
+
+def _decline(p: dict):
+    st = p["status"]
+    if st == SLAB_EMPTY:
+        raise SlabUnsupported("empty cloud")
+    if st == SLAB_NONFINITE:
+        raise ValueError("sor: coordinates are not finite (NaN/inf)")
+    if st == SLAB_SMALL_SHARD:
+        raise SlabUnsupported("index shards of %s points: the slab exchange needs >= %d per rank" % (p["sizes"], NP_PIECE))
+    if st == SLAB_NO_STRUCTURE:
+        raise SlabUnsupported("the halos hold %d of %d points per neighbour: no slab structure to exploit"
+                              % (p["halo_total"] // max(p["world"] - 1, 1), p["n_total"]))
+
+
 class SlabResult(dict):
     """buffers of one step.  The certificate is evaluated on the device and read back lazily: call ``check()`` (one
     synchronisation) before trusting the buffers; it raises SlabUncertain when the slabs could not certify every query."""
@@ -336,13 +439,51 @@ class SlabResult(dict):
         return self
 
 
-def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 1.5, want_host: bool = False):
+def _finish(out: SlabResult, be, n_local: int, want_host: bool):
+    if want_host:
+        out.check()
+        out["mask_host"] = be.to_host(out["mask"], np.uint8, n_local).view(np.bool_)
+        out["mean_dists_host"] = be.to_host(out["mean_dists"], np.float32, n_local)
+        out["stats_host"] = be.to_host(out["stats"], np.float32, 3)
+    return out
+
+
+def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 1.5, want_host: bool = False,
+             fused: bool | None = None):
     """rows: backend buffer holding this rank's (n_local,3) float32 index shard -- consecutive index ranges of the cloud in
-    rank order, of ANY sizes >= 8192 (round 3: unequal shards, e.g. what a density filter leaves behind on every rank).
+    rank order, of ANY sizes >= 8192 (unequal shards, e.g. what a density filter leaves behind on every rank).
     -> SlabResult(mask, mean_dists, stats: backend buffers of the LOCAL index range; n_total, n_own, n_halo, info).
     ONE host synchronisation inside the step (the histograms, from which every size follows).
+    On a HipSlabBackend whose context carries the communicator the whole step is ONE C call (``gsx_sor_slab_step_dev``);
+    ``fused=False`` (and every other backend / communicator) takes the spelled-out ``slab_sor_steps``.
     halo_cells: halo width in KNN cell edges h of the global density.  On uniform data a query's k-th neighbour is at
     ~0.82 h and beyond 1.3 h with probability < 1e-13; the certificate catches whatever the halo does not cover."""
+    can_fuse = hasattr(be, "slab_step") and (comm is None or (isinstance(comm, RcclComm) and comm.ctx is be.ctx))
+    if fused is None:
+        fused = can_fuse
+    if fused:
+        if not can_fuse:
+            raise ValueError("slab_sor(fused=True) needs a HipSlabBackend and the RcclComm of its context")
+        return _finish(be.slab_step(rows, n_local, k, threshold_factor, halo_cells), be, int(n_local), want_host)
+    return slab_sor_steps(be, comm, rows, n_local, k, threshold_factor, halo_cells, want_host)
+
+
+class _OneRank:
+    """no communicator: world 1, the local block of an exchange is a device copy"""
+    rank, world = 0, 1
+
+    def __init__(self, be):
+        self.be = be
+
+    def all_to_all_v(self, send, send_off, send_cnt, recv, recv_off, recv_cnt, elem_bytes):
+        if int(send_cnt[0]):
+            self.be.copy(self.be.at(recv, int(recv_off[0]) * elem_bytes), self.be.at(send, int(send_off[0]) * elem_bytes), int(send_cnt[0]) * elem_bytes)
+
+
+def slab_sor_steps(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo_cells: float = 1.5, want_host: bool = False):
+    """the step, call by call (what gsx_sor_slab_step_dev does inside the library)"""
+    if comm is None:
+        comm = _OneRank(be)
     G, r = comm.world, comm.rank
     n_local = int(n_local)
     # ---- 1. bounding box (device-resident), 2. histogram of the longest axis; all-gathered: cuts AND every row count.
@@ -361,62 +502,32 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
         else:
             be.zero(hist, 4 * BINS)
         comm.all_gather(hist, be.at(plan_in, 32), 4 * BINS)
-    else:
+    elif n_local:
         be.hist(rows, n_local, b7, be.at(plan_in, 32))
+    else:
+        be.zero(be.at(plan_in, 32), 4 * BINS)
     words = be.to_host(plan_in, np.uint32, 8 + BINS * G)                       # <- the step's host synchronisation
-    hb = words[:7].view(np.float32)
-    allhist = words[8:].reshape(G, BINS)
-    if int(allhist.sum()) == 0:
-        raise SlabUnsupported("empty cloud")
-    if hb[6] > 0 or not np.all(np.isfinite(hb[:6])):
-        raise ValueError("sor: coordinates are not finite (NaN/inf)")
-    ext = hb[3:6] + hb[:3]                                                     # float32, like the device (slab_axis)
-    axis = 0
-    if ext[1] > ext[0]:
-        axis = 1
-    if ext[2] > max(ext[0], ext[1]):
-        axis = 2
-    lo, hi = np.float32(-hb[axis]), np.float32(hb[3 + axis])
-    sizes = allhist.sum(1).astype(np.int64)          # every rank's shard size: the histograms hold every point once
-    cut, n_total = plan_slabs(allhist.sum(0), G)
-    if int(sizes[r]) != n_local:
-        raise ValueError("slab_sor: %d rows given, %d binned" % (n_local, int(sizes[r])))
-    if G > 1 and int(sizes.min()) < NP_PIECE:
-        raise SlabUnsupported("index shards of %s points: the slab exchange needs >= %d per rank" % (sizes.tolist(), NP_PIECE))
-    if n_total == 0:
-        raise SlabUnsupported("empty cloud")
+    p = plan_step(words, G, r, n_local, k, halo_cells)
+    _decline(p)
+    axis, cut, halo_bins, n_total = p["axis"], p["cut"], p["halo_bins"], p["n_total"]
+    sizes = np.array(p["sizes"], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(sizes)])  # global index of every shard's first row
-    ext64 = ext.astype(np.float64)
-    nd = int((ext64 > 0).sum())
-    per = float(np.prod(ext64[ext64 > 0])) * pts_per_cell(k, n_total // max(G, 1)) / max(n_total, 1) if nd else 0.0   # (slabs are equal-COUNT)
-    h_est = per ** (1.0 / nd) if nd else 0.0
-    bw = (float(hi) - float(lo)) / BINS if hi > lo else 0.0
-    halo_bins = int(np.ceil(halo_cells * h_est / bw)) + 1 if bw > 0 else BINS
     # ---- 3. scatter into the send buffer, exchange the rows (sizes from the histograms: no counting pass)
-    own, halo = slab_counts(allhist, cut, halo_bins)
-    # a cloud whose halos amount to most of it (a scene inside a box inflated by far floaters: the halo width comes from the
-    # box-wide density) gains nothing from slabs -- every rank would receive nearly everything, search it, and then fail the
-    # certificate for the floaters anyway.  Decided from the gathered histograms: every rank raises in the same step.
-    if G > 1 and int(halo.sum()) > 0.75 * (G - 1) * n_total:
-        raise SlabUnsupported("the halos hold %d of %d points per neighbour: no slab structure to exploit" % (int(halo.sum()) // (G - 1), n_total))
-    own_cnt, halo_cnt = own[r], halo[r]
-    assert int(own_cnt.sum()) == n_local
-    own_off = np.concatenate([[0], np.cumsum(own_cnt)[:-1]])
-    halo_off = n_local + np.concatenate([[0], np.cumsum(halo_cnt)[:-1]])
-    n_send = n_local + int(halo_cnt.sum())
+    own_off, own_cnt, halo_off, halo_cnt = p["own_off"], p["own_cnt"], p["halo_off"], p["halo_cnt"]
     cursor = be.buf("cursor", 4 * 2 * G)
     cur = np.empty(2 * G, np.uint32)
     cur[0::2], cur[1::2] = own_off, halo_off
-    send = be.buf("send", 12 * max(n_send, 1))
+    send = be.buf("send", 12 * max(p["n_send"], 1))
     send_src = be.buf("send_src", 4 * max(n_local, 1))
-    planes = be.partition(rows, n_local, G, axis, lo, hi, cut, halo_bins, cur, cursor, send, send_src)
-    in_own, in_halo = own[:, r], halo[:, r]                                    # rows every source sends me
-    n_own, n_halo = int(in_own.sum()), int(in_halo.sum())
-    r_own_off = np.concatenate([[0], np.cumsum(in_own)[:-1]])
-    r_halo_off = n_own + np.concatenate([[0], np.cumsum(in_halo)[:-1]])
+    be.partition(rows, n_local, G, axis, np.float32(p["lo"]), np.float32(p["hi"]), cut, halo_bins, cur, cursor, send, send_src)
+    in_own, in_halo, r_own_off, r_halo_off = p["in_own"], p["in_halo"], p["r_own_off"], p["r_halo_off"]
+    n_own, n_halo = p["n_own"], p["n_halo"]
     slab = be.buf("slab", 12 * max(n_own + n_halo, 1))
-    comm.all_to_all_v(send, own_off, own_cnt, slab, r_own_off, in_own, 12)
-    comm.all_to_all_v(send, halo_off, halo_cnt, slab, r_halo_off, in_halo, 12)
+    if hasattr(comm, "all_to_all_segs"):   # own rows and halo rows in ONE group of sends / receives
+        comm.all_to_all_segs(send, slab, [(own_off, own_cnt, r_own_off, in_own), (halo_off, halo_cnt, r_halo_off, in_halo)], 12)
+    else:
+        comm.all_to_all_v(send, own_off, own_cnt, slab, r_own_off, in_own, 12)
+        comm.all_to_all_v(send, halo_off, halo_cnt, slab, r_halo_off, in_halo, 12)
     # ---- 4./5. exact KNN on the slab; certificate (device-side count, summed over the ranks, read by check())
     md_slab = be.buf("md_slab", 4 * max(n_own, 1))
     kth = be.buf("kth", 8 * max(n_own, 1))
@@ -424,7 +535,7 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
         be.knn_slab(slab, n_own, n_halo, k, md_slab, kth)
     unc = be.buf("unc", 8)
     if n_own:
-        be.certify(slab, axis, n_own, kth, planes[r, 0], planes[r, 1], unc)   # (zeroes the counter itself)
+        be.certify(slab, axis, n_own, kth, p["plane_lo"], p["plane_hi"], unc)   # (zeroes the counter itself)
     else:
         be.zero(unc, 8)
     if G > 1:
@@ -475,9 +586,4 @@ def slab_sor(be, comm, rows, n_local: int, k: int, threshold_factor: float, halo
     be.mask(md, n_local, stats, mask)
     out = SlabResult({"mask": mask, "mean_dists": md, "stats": stats, "uncertain": unc, "_be": be, "n_total": n_total,
                       "n_own": n_own, "n_halo": n_halo, "info": {"axis": axis, "halo_bins": halo_bins, "cut": cut}})
-    if want_host:
-        out.check()
-        out["mask_host"] = be.to_host(mask, np.uint8, n_local).view(np.bool_)
-        out["mean_dists_host"] = be.to_host(md, np.float32, n_local)
-        out["stats_host"] = be.to_host(stats, np.float32, 3)
-    return out
+    return _finish(out, be, n_local, want_host)

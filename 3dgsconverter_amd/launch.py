@@ -1,0 +1,141 @@
+"""One process per GPU without torch: rank discovery, spawning, and the hand-over of the communicator's unique id.
+
+The reference is a single process; this is launcher plumbing of its MI355X scale-out.  Two ways in:
+
+  * a launcher already started the ranks (``python -m torch.distributed.run --nproc-per-node N ...`` or any other that
+    sets RANK / LOCAL_RANK / WORLD_SIZE): ``rank_env()`` reads them; the 128-byte id of ``gsx_comm_unique_id`` travels
+    through a small file that rank 0 writes atomically and the others poll (one node: /tmp is shared) -- torch's TCP store
+    is not needed and torch is not imported;
+  * nobody did: ``spawn_ranks()`` starts N copies of the calling script with those variables set (``bench.py --gpus N``
+    run plainly).
+
+Device per rank: ``LOCAL_RANK`` when the node shows at least WORLD_SIZE GPUs (every rank sees every GPU, as under torchrun:
+RCCL needs the peers visible), otherwise ``LOCAL_RANK % device_count`` -- ranks then SHARE GPUs, which RCCL refuses, and the
+communicator uses the shared-memory "hostwire" transport (csrc/comm.hip): a functional run of the same code, not a scaling
+measurement.  ``GSX_COMM_TRANSPORT=hostwire|rccl`` overrides the choice.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+
+def rank_env():
+    """(rank, local_rank, world) from the launcher's environment; (0, 0, 1) when there is none"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, local, world
+
+
+def _parent_tag() -> str:
+    """names the job for ranks started by one launcher process: its pid and start time (a recycled pid differs in the latter)"""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]   # field 22: starttime
+    except Exception:   # noqa: BLE001 -- no /proc: the pid and port alone
+        pass
+    return "%d_%s" % (ppid, start)
+
+
+def rendezvous_path() -> str:
+    """the file the unique id travels through: GSX_RDZV_FILE (spawn_ranks sets it) or a name every rank of one launcher
+    derives identically (parent process identity + MASTER_PORT + torchrun's run id)"""
+    p = os.environ.get("GSX_RDZV_FILE")
+    if p:
+        return p
+    tag = "%s_%s_%s" % (_parent_tag(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    return os.path.join(tempfile.gettempdir(), "gsx_rdzv_" + "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in tag))
+
+
+def exchange_unique_id(rank: int, make_id, path: str | None = None, timeout_s: float = 300.0) -> bytes:
+    """rank 0 calls make_id() -> 128 bytes and publishes them; every rank returns the same bytes"""
+    path = path or rendezvous_path()
+    if rank == 0:
+        uid = make_id()
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(uid)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)   # atomic: a reader sees nothing or all 128 bytes
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("rank %d: no unique id at %s after %.0f s (did rank 0 start?)" % (rank, path, timeout_s))
+        time.sleep(0.01)
+
+
+def retire_unique_id(rank: int, path: str | None = None):
+    """after every rank has initialised its communicator (a barrier later): the file has done its job"""
+    if rank == 0:
+        try:
+            os.unlink(path or rendezvous_path())
+        except OSError:
+            pass
+
+
+def pick_device_and_transport(local_rank: int, world: int, device_count: int):
+    """-> (device index, transport name)"""
+    forced = os.environ.get("GSX_COMM_TRANSPORT")
+    if device_count >= world:
+        return local_rank, forced or "rccl"
+    return local_rank % max(device_count, 1), forced or "hostwire"
+
+
+def spawn_ranks(world: int, argv=None, env_extra=None, timeout_s: float | None = None) -> int:
+    """start `world` copies of the calling script (same arguments), one rank each, and wait for them.  stdout / stderr are
+    inherited (only rank 0 prints the result line).  -> the first non-zero exit code, else 0"""
+    argv = list(sys.argv if argv is None else argv)
+    rdzv_dir = tempfile.mkdtemp(prefix="gsx_job_")
+    procs = []
+    try:
+        for r in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                        "GSX_RDZV_FILE": os.path.join(rdzv_dir, "unique_id"), "GSX_SPAWNED": "1"})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+            if env_extra:
+                env.update(env_extra)
+            procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+        rc, t0 = 0, time.time()
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:      # a rank died: the others would wait for it in a collective
+                        q.terminate()
+            if timeout_s is not None and time.time() - t0 > timeout_s:
+                for q in pending:
+                    q.kill()
+                return 124
+            time.sleep(0.02)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            for f in os.listdir(rdzv_dir):
+                os.unlink(os.path.join(rdzv_dir, f))
+            os.rmdir(rdzv_dir)
+        except OSError:
+            pass

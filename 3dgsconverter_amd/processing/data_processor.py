@@ -82,6 +82,12 @@ class DataProcessor:
 
     @data.setter
     def data(self, value):
+        # a deferred cap_sh_degree belongs to the table it was called on: the reference zeroes that table at once
+        # (data_processor.py:313), so it is applied to the OLD table before the new one replaces it
+        if self._pending_zero and isinstance(self._data, np.ndarray):
+            names, self._pending_zero = self._pending_zero, []
+            _lib.host_zero_columns(self._data, names)
+        self._pending_zero = []
         self._drop_chain()
         self._data = value
 

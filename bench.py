@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- the point-cloud filtering hot path of 3dgsconverter on MI355X, every BASELINE.json config on one line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n SPLATS_PER_GPU] [--k 16]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n SPLATS_PER_GPU] [--k 16]      (N > 1: starts its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from a launcher)
     python bench.py --workload kmeans [--gpus N]   # BASELINE.json configs[4] alone (strong scaling over the chunks)
 
 HEADLINE (the top-level fields; BASELINE.json's metric): one SOR step = one pass of the hot path over one batch of
@@ -21,9 +21,10 @@ uniform grid is bad at -- each with its own roofline and CPU baseline:
     host_to_host  the 10M SOR call from a contiguous host xyz array to a host mask (gsx_sor_filter, PCIe included)
     clustered_1m / floaters_10m   Gaussian blobs of very different density / a scene + 0.5 % far floaters (adaptive mode:
                   the Morton-tree path)
-The N=1 run does not import torch: device memory comes from gsx_dev_malloc / gsx_dev_upload (include/gsx_hip.h), the
-clock is time.perf_counter around gsx_ctx_synchronize.  With N > 1 torch.distributed hands out the RCCL unique id and
-provides the barrier around the timed region; the data path is the C library's.  Prints ONE JSON line (rank 0).
+No run of this file loads PyTorch: device memory comes from gsx_dev_malloc / gsx_dev_upload (include/gsx_hip.h), the clock is
+time.perf_counter around gsx_ctx_synchronize.  With N > 1 every rank is a process of its own (3dgsconverter_amd/launch.py),
+the communicator's unique id travels through a file, the barriers around the timed region and the MAX over the ranks' clocks
+are gsx_comm_* calls like the data path's collectives.  Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -522,7 +523,7 @@ def main_slab_one_rank(args, gsx, L, ctx):
     res = {}
 
     def step():
-        res["r"] = gslab.slab_sor(be, comm, gslab._View(dev.ptr), args.n, args.k, args.sigma)
+        res["r"] = gslab.slab_sor(be, comm, dev, args.n, args.k, args.sigma)    # ONE C call: gsx_sor_slab_step_dev
 
     step()
     res["r"].check()
@@ -544,150 +545,127 @@ def main_slab_one_rank(args, gsx, L, ctx):
     os.write(args.json_fd, (json.dumps(out) + "\n").encode())
 
 
-# --------------------------------------------------------------------------------------------------- N > 1 (torch.distributed)
+# --------------------------------------------------------------------------------------------------- N > 1: one process per GPU
 def main_multi(args):
-    import torch  # first: its bundled HIP runtime (same SONAME) is the one the .so binds to in this process
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    """`python bench.py --gpus N` run plainly becomes the launcher of its own N ranks (3dgsconverter_amd/launch.py); under
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks already exist.  Either way: numpy +
+    ctypes on libgsx_hip.so, every collective a gsx_comm_* call of the C library (RCCL over xGMI; the shared-memory hostwire
+    when the ranks have to share GPUs), the unique id through a file."""
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    rank, local_rank, world = launch.rank_env()
+    if world == 1:
+        sys.exit(launch.spawn_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # stdout carries exactly ONE JSON line: RCCL (banner, warnings) and other libraries print to the C stdout, so
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a private copy of the real one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     gsx = importlib.import_module("3dgsconverter_amd")
     gdist = importlib.import_module("3dgsconverter_amd.dist")
     gslab = importlib.import_module("3dgsconverter_amd.dist_slab")
     L = gsx._lib
-    compute = gdist.HipCompute(local_rank)
-    ctx = compute.ctx
+    device, transport = launch.pick_device_and_transport(local_rank, world, L.device_count())
+    ctx = L.Context(device)
     for kv in args.param:
         name, val = kv.split("=")
         ctx.set_param(name, float(val))
-    # spatial slabs: every collective of the data path is RCCL called from libgsx_hip.so on the library's stream
-    # (3dgsconverter_amd/dist_slab.py); torch.distributed only hands the 128-byte unique id out and times
-    slab_be = slab_comm = None
-    exchange = {"path": "replicated (requested)"}
-    if args.exchange != "replicated":
-        uid = [gslab.RcclComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        slab_be = gslab.HipSlabBackend(ctx=ctx)
-        slab_comm = gslab.RcclComm(ctx, rank, world, uid[0])
-        exchange["path"] = "slab"
-
-    def barrier():
-        ctx.synchronize()          # the library's stream (its RCCL calls too) is drained before torch's communicator runs
-        dist.barrier()
-        torch.cuda.synchronize()
+    be = gslab.HipSlabBackend(ctx=ctx)
+    uid = launch.exchange_unique_id(rank, lambda: gslab.RcclComm.unique_id(transport))
+    comm = gslab.RcclComm(ctx, rank, world, uid)
+    comm.barrier()                      # every rank holds its communicator: the id file has done its job
+    launch.retire_unique_id(rank)
+    exchange = {"path": "replicated (requested)" if args.exchange == "replicated" else "slab"}
 
     def run(n, extent, steps, warmup, k=None):
         """Time `steps` SOR steps on a fresh n-splat shard; returns a dict of raw measurements."""
         k = args.k if k is None else k
-        xyz_host = synth_uniform(n, extent, rank)
-        xyz_local = torch.from_numpy(xyz_host).to(dev)
-        torch.cuda.synchronize()
+        rows = ctx.alloc(12 * n + 16).upload(synth_uniform(n, extent, rank))
         exchange.pop("certified", None)
-
-        class _SlabRes:   # the fields the report below reads, from the slab path's device buffers
-            def __init__(self, r):
-                self.r = r
-
-            @property
-            def mask_local(self):
-                return torch.from_numpy(slab_be.to_host(self.r["mask"], np.uint8, n))
-
-            @property
-            def stats(self):
-                return torch.from_numpy(slab_be.to_host(self.r["stats"], np.float32, 3))
 
         def step():
             if exchange["path"] == "slab":
                 try:
-                    r = gslab.slab_sor(slab_be, slab_comm, gslab._View(xyz_local.data_ptr()), n, k, args.sigma)
+                    r = gslab.slab_sor(be, comm, rows, n, k, args.sigma)    # ONE C call: gsx_sor_slab_step_dev
                     if not exchange.get("certified"):   # first step on this cloud: read the certificate before relying on
                         r.check()                        # the slab path (later steps read it after the timed region)
                         exchange["certified"] = True
-                    return _SlabRes(r)
-                except gslab.SlabUncertain as e:   # raised on every rank together (the count is all-reduced)
+                    return r
+                except gslab.SlabUncertain as e:   # raised on every rank together (decided from all-reduced / gathered data)
                     exchange["path"] = "replicated (slab exchange declined: %s)" % e
-                    compute.set_adaptive(True)     # the clouds that get here are the ones the adaptive grid exists for
-            return gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
+                    be.set_adaptive(True)          # the clouds that get here are the ones the adaptive paths exist for
+            return gdist.replicated_sor(be, comm, rows, n, k, args.sigma, algo=args.algo)
+
+        def host(res):
+            return be.to_host(res["mask"], np.uint8, n).astype(bool), be.to_host(res["stats"], np.float32, 3)
 
         if exchange["path"] == "slab" and not exchange.get("cross_checked"):
             # the slab exchange and the replicated one (all-gather of the rows, every rank bins everything) must agree
             # bit for bit -- statistics and this rank's survivor mask -- before the slab path is what gets timed
-            ref = gdist.sharded_sor(xyz_local, k, args.sigma, compute, algo=args.algo)
+            ref_mask, ref_stats = host(gdist.replicated_sor(be, comm, rows, n, k, args.sigma, algo=args.algo).check())
             ok = 1
             try:
                 got = step()
-                if isinstance(got, _SlabRes):
-                    same_stats = bool(np.array_equal(got.stats.numpy().view(np.uint32), ref.stats.cpu().numpy().view(np.uint32)[:3]))
-                    same_mask = bool(np.array_equal(got.mask_local.numpy().astype(bool), ref.mask_local.cpu().numpy().astype(bool)))
-                    ok = 1 if (same_stats and same_mask) else 0
-            except gslab.SlabUncertain:
-                ok = 1
-            except Exception as e:   # noqa: BLE001 -- anything the exchange raises on this rank
+                if exchange["path"] == "slab":
+                    mask, stats = host(got)
+                    ok = 1 if (np.array_equal(stats.view(np.uint32), ref_stats.view(np.uint32)) and np.array_equal(mask, ref_mask)) else 0
+            except Exception as e:   # noqa: BLE001 -- anything the exchange raises on this rank alone
                 sys.stderr.write("[bench] rank %d: slab exchange failed its cross-check: %r\n" % (rank, e))
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+                comm.abort()
+                raise
+            if int(comm.reduce_scalar(ok, gslab.KIND_I64_MIN)) == 0:
                 exchange["path"] = "replicated (slab exchange disagreed with the replicated exchange on this cloud)"
             exchange["cross_checked"] = True
-            del ref
+        res = None
         for _ in range(warmup):
             res = step()
-        barrier()
+        comm.barrier()
         ctx.set_param("timing_mask", 1 << L.T_SOR_KNN)
         ctx.set_timing(True)
         ctx.reset_timing()
-        barrier()
+        comm.barrier()                  # (drains this rank's stream, then every rank's)
         t0 = time.perf_counter()
         for i in range(steps):
             ctx.set_timing(i % EVENT_EVERY == 0)
             res = step()
-        barrier()
+        comm.barrier()
         dt = time.perf_counter() - t0
         ctx.set_timing(True)
-        t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dt = float(t_max.item())
-        if isinstance(res, _SlabRes):
-            res.r.check()   # the certificate of the last timed step (same cloud every step)
+        dt = float(comm.reduce_scalar(dt, gslab.KIND_F64_MAX))   # the slowest rank's clock
+        res.check()                     # the certificate of the last timed step (same cloud every step)
         n_knn, ms_knn = ctx.timing(L.T_SOR_KNN)
         ctx.set_timing(False)
-        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "res": res}
+        mask, stats = host(res)
+        rows.free()
+        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "survivors": int(mask.sum()), "threshold": float(stats[2])}
 
-    main_run = run(args.n, args.extent, args.steps, args.warmup)
-    res = main_run["res"]
-    survivors_main = int(res.mask_local.sum().item())
-    threshold_main = float(res.stats[2].item())
-    config3 = None
-    if not args.no_secondary:
-        # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
-        # other N the same 50M are split N ways).  Reported next to the headline, never instead of it.
-        try:
-            n3 = max(8192, (50_000_000 // world) // 4 * 4)
-            s3, w3 = max(3, min(args.steps, 10)), 2
-            r3 = run(n3, 10.0, s3, w3, k=32)
-            config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, seed=rank) over %d GPU(s), SOR k=32 "
-                                   "sigma=%g" % (n3 * world, world, args.sigma),
-                       "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
-                       "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
-                       "knn_kernel_ms": round(r3["knn_ms"], 4)}
-            del r3
-        except Exception as e:   # noqa: BLE001 -- the headline line must survive a failure here
-            config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}
-    if slab_comm is not None:
+    try:
+        main_run = run(args.n, args.extent, args.steps, args.warmup)
+        config3 = None
+        if not args.no_secondary:
+            # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
+            # other N the same 50M are split N ways).  Reported next to the headline, never instead of it.
+            try:
+                n3 = max(8192, (args.n3 // world) // 4 * 4)
+                s3, w3 = max(3, min(args.steps, 10)), 2
+                r3 = run(n3, 10.0, s3, w3, k=32)
+                config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, seed=rank) over %d GPU(s), SOR k=32 "
+                                       "sigma=%g" % (n3 * world, world, args.sigma),
+                           "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
+                           "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
+                           "knn_kernel_ms": round(r3["knn_ms"], 4), "survivors_rank0": r3["survivors"]}
+            except gsx._lib.GsxError as e:   # the headline line must survive a failure here (a GsxError is raised by every
+                config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}   # rank that hits it; anything else aborts)
         ctx.check()
-        slab_comm.close()
+    except BaseException:
+        comm.abort()
+        raise
     if rank == 0:
         dt = main_run["dt"]
         n_total = world * args.n
+        shared = L.device_count() < world
         out = {
             "metric": "Msplats/sec SOR k=%d" % args.k, "value": round(n_total * args.steps / dt / 1e6, 2), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -695,14 +673,19 @@ def main_multi(args):
             "config": {"workload": "%d uniform-random splats per GPU (L=%g, seed=rank), SOR k=%d sigma=%g, exact KNN, xyz resident in HBM"
                                    % (args.n, args.extent, args.k, args.sigma),
                        "splats_per_gpu": args.n, "k": args.k, "sigma": args.sigma, "algo": "grid-binned exact KNN",
-                       "parallelism": gslab.PARALLELISM if exchange["path"] == "slab" else gdist.PARALLELISM + " -- " + exchange["path"]},
+                       "parallelism": gslab.PARALLELISM if exchange["path"] == "slab" else gdist.PARALLELISM + " -- " + exchange["path"],
+                       "transport": comm.transport + (" (%d ranks share %d GPU(s): a functional run of the N-rank code, not a scaling "
+                                                      "measurement)" % (world, L.device_count()) if shared else " over xGMI, one rank per GPU"),
+                       "launcher": "bench.py's own ranks (3dgsconverter_amd/launch.py)" if os.environ.get("GSX_SPAWNED") else "external (RANK / WORLD_SIZE)",
+                       "host_runtime": "numpy + ctypes on libgsx_hip.so; torch is not imported"},
             "roofline": sor_roofline(args.n, args.k, main_run["knn_ms"], args.algo, n_total=n_total, single=False),
             "kernel_ms_per_step": {"knn": round(main_run["knn_ms"], 4)},
-            "survivors_rank0": survivors_main, "threshold": threshold_main}
+            "survivors_rank0": main_run["survivors"], "threshold": main_run["threshold"]}
         if config3 is not None:
             out["config3"] = config3
-        os.write(args.json_fd, (json.dumps(out) + "\n").encode())
-    dist.destroy_process_group()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    comm.barrier()
+    comm.close()
 
 
 def main():
@@ -723,19 +706,21 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "slab", "replicated"],
                     help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
                          "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
+    ap.add_argument("--n3", type=int, default=50_000_000, help="N>1: total splats of the configs[3] line (k=32), split over the ranks")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:   # (either spawns its own ranks when no launcher did)
+        if args.workload == "kmeans":
+            return importlib.import_module("tools.bench_kmeans").main(args)
+        return main_multi(args)
     # stdout carries exactly ONE JSON line: RCCL (banner, warnings) and other libraries print to the C stdout, so
     # file descriptor 1 is pointed at stderr for the whole run and the JSON goes to a private copy of the real one
     sys.stdout.flush()
     args.json_fd = os.dup(1)
     os.dup2(2, 1)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.workload == "kmeans":
         return importlib.import_module("tools.bench_kmeans").main(args)
-    if world > 1 or args.gpus > 1:
-        return main_multi(args)
     return main_single(args)
 
 

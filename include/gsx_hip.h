@@ -209,18 +209,60 @@ int gsx_sor_mask_dev(gsx_ctx *ctx, const float *mean_dists_dev, int64_t n, const
  * mean/std over the whole mean-distance array (:176-178).  One process per GPU, splats sharded by index; the
  * host (3dgsconverter_amd/dist.py: slab_sor) drives these entry points; DESIGN.md section 7 has the protocol.
  *
- * gsx_comm_*: RCCL collectives on the context's stream (librccl is dlopen'ed at gsx_comm_init).  The unique id
- * is created on rank 0 (gsx_comm_unique_id) and handed to the other ranks by the launcher (128 bytes). */
+ * gsx_comm_*: the collectives of the data path, on the context's stream.  Two transports behind the same calls
+ * (csrc/comm.hip): "rccl" -- librccl dlopen'ed at first use, plain ncclAllReduce / ncclAllGather / grouped ncclSend +
+ * ncclRecv over xGMI, one rank per GPU (the product) -- and "hostwire" -- POSIX shared-memory outboxes for ranks that SHARE
+ * a GPU, which RCCL refuses (the full N-rank choreography on a one-GPU box: tests, `bench.py --gpus N` there).  The unique
+ * id is created on rank 0 (under GSX_COMM_TRANSPORT=hostwire it names the shared-memory job) and handed to the other
+ * ranks by the launcher (128 bytes; 3dgsconverter_amd/launch.py: a file next to the job). */
+enum { GSX_COMM_F32_MAX = 0, GSX_COMM_F32_SUM = 1, GSX_COMM_I64_SUM = 2, GSX_COMM_F64_MAX = 3, GSX_COMM_I64_MIN = 4 };
 int gsx_comm_unique_id(void *out128);
 int gsx_comm_init(gsx_ctx *ctx, int rank, int world, const void *id128);
 int gsx_comm_destroy(gsx_ctx *ctx);
-/* in place on device memory; kind 0 = float32 max, 1 = float32 sum, 2 = int64 sum */
+int gsx_comm_abort(gsx_ctx *ctx);                 /* this rank gives up: peers waiting on it fail at once (hostwire) */
+int gsx_comm_transport(gsx_ctx *ctx);             /* 0 = no communicator, 1 = rccl, 2 = hostwire */
+int gsx_comm_rank(gsx_ctx *ctx, int *rank_out, int *world_out);   /* (0, 1) without a communicator */
+int gsx_comm_barrier(gsx_ctx *ctx);               /* all stream work of every rank up to here has completed */
+/* in place on device memory; kind: GSX_COMM_* above */
 int gsx_comm_all_reduce(gsx_ctx *ctx, void *buf_dev, int64_t count, int kind);
 int gsx_comm_all_gather(gsx_ctx *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
 /* grouped ncclSend/ncclRecv: offsets and counts (host arrays, one entry per peer) in elements of elem_bytes
  * (1, 4, 8 or 12 = a row of three floats) */
 int gsx_comm_all_to_all_v(gsx_ctx *ctx, const void *send_dev, const int64_t *send_off, const int64_t *send_cnt,
                           void *recv_dev, const int64_t *recv_off, const int64_t *recv_cnt, int elem_bytes);
+/* nseg <= 2 such exchanges in ONE group (own rows and halo rows of the slab partition): entry [s * world + p] of the four
+ * arrays = segment s to / from peer p */
+int gsx_comm_all_to_all_segs(gsx_ctx *ctx, const void *send_dev, void *recv_dev, int nseg, const int64_t *send_off,
+                             const int64_t *send_cnt, const int64_t *recv_off, const int64_t *recv_cnt, int elem_bytes);
+
+/* ---- the slab step as ONE call (what bench.py --gpus N and dist_slab.LibSlab drive) ----
+ * Why a rank may decline a step (status != 0; decided from all-gathered data, so every rank declines together and the
+ * caller's replicated exchange -- dist.replicated_sor, exact for any cloud -- takes over): */
+enum { GSX_SLAB_OK = 0, GSX_SLAB_EMPTY = 1, GSX_SLAB_NONFINITE = 2, GSX_SLAB_SMALL_SHARD = 3, GSX_SLAB_NO_STRUCTURE = 4 };
+typedef struct gsx_slab_plan_t {
+    int32_t status, world, rank, axis, halo_bins;
+    float   lo, hi;                  /* binned range of the partition axis (the all-reduced box words)          */
+    float   plane_lo, plane_hi;      /* this rank holds EVERY point of the cloud between these (+-inf at the ends) */
+    int32_t cut[17];                 /* slab s owns the bins [cut[s], cut[s+1]) of 4096                          */
+    int64_t n_local, n_total, n_own, n_halo, n_send, halo_total;
+    int64_t sizes[16];               /* index-shard size of every rank                                           */
+    int64_t own_cnt[16], halo_cnt[16], own_off[16], halo_off[16];       /* rows this rank sends slab s ...        */
+    int64_t in_own[16], in_halo[16], r_own_off[16], r_halo_off[16];     /* ... and receives from source q         */
+} gsx_slab_plan_t;
+typedef struct gsx_slab_step_t {
+    int32_t status;                  /* = plan.status                                                            */
+    gsx_slab_plan_t plan;
+    const uint8_t *mask_dev;         /* u8[n_local]: survivor mask of the local index range                      */
+    const float   *mean_dists_dev;   /* f32[n_local], index order (context workspace: valid until the next step) */
+    const float   *stats_dev;        /* mean, std, threshold: numpy's bits for the WHOLE cloud                    */
+    const int64_t *uncertain_dev;    /* all-reduced number of queries the slabs could not certify: read it (one
+                                        synchronisation) before trusting the buffers; non-zero = use the fallback */
+} gsx_slab_step_t;
+/* host-only: the plan from the step's gathered words (box words [0,7), histograms from word 8) */
+int gsx_slab_plan(const uint32_t *words, int world, int rank, int64_t n_local, int k, double halo_cells, gsx_slab_plan_t *out);
+/* rows_dev: this rank's (n_local,3) float32 index shard; replaces data_processor.py:156-180 across ranks */
+int gsx_sor_slab_step_dev(gsx_ctx *ctx, const float *rows_dev, int64_t n_local, int k, double threshold_factor,
+                          double halo_cells, uint8_t *mask_out_dev /* nullable */, gsx_slab_step_t *out);
 
 /* out7_dev = max over the points of (-x,-y,-z,x,y,z) and a non-finite flag: ONE float32 max all-reduce gives the
  * global bounding box (the per-rank half of gpu_ops.py:203-206) */

@@ -36,10 +36,13 @@ class NumpySlabBackend:
     def __init__(self):
         self._bufs = {}
 
-    def buf(self, name, nbytes):
+    def buf(self, name, nbytes, keep=0):
         cur = self._bufs.get(name)
         if cur is None or cur.nbytes < nbytes:
-            cur = _Buf(int(nbytes) + 64)
+            new = _Buf(int(nbytes) + 64)
+            if cur is not None and keep:
+                new.a[:min(int(keep), cur.nbytes)] = cur.a[:min(int(keep), cur.nbytes)]
+            cur = new
             self._bufs[name] = cur
         return cur
 
@@ -208,6 +211,76 @@ class NumpySlabBackend:
 
     def check(self):
         pass
+
+    # ---- the replicated exchange (3dgsconverter_amd/dist.py)
+    def knn_share(self, xyz_all, n_total, k, share, nshares, md_all, algo=0):
+        # any partition of the queries works for the choreography; like the GPU one this is spatial (slabs along z),
+        # i.e. scattered in index space
+        xyz = xyz_all.view(np.float32, 3 * n_total).reshape(n_total, 3)
+        md = osor.mean_dists_ckdtree(xyz, k, workers=2)
+        order = np.argsort(xyz[:, 2], kind="stable")
+        mine = order[n_total * share // nshares: n_total * (share + 1) // nshares]
+        out = md_all.view(np.float32, n_total)
+        out[:] = 0
+        out[mine] = md[mine]
+
+    def knn_all(self, xyz_all, n, k, md, algo=0):
+        xyz = xyz_all.view(np.float32, 3 * n).reshape(n, 3)
+        md.view(np.float32, n)[:] = osor.mean_dists_ckdtree(xyz, k, workers=2)
+
+    def stats(self, md_all, n_total, threshold_factor, stats):
+        stats.view(np.float32, 3)[:] = [np.float32(v) for v in osor.threshold_numpy(md_all.view(np.float32, n_total), threshold_factor)]
+
+
+class GlooHostComm:
+    """torch.distributed (gloo) on host memory: the wire of the CPU tests of the multi-GPU choreography (the product's is
+    gsx_comm_*: RCCL, or the shared-memory hostwire).  Buffers go through the backend's to_host / from_host."""
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.be = dist, group, backend
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce(self, buf, count, kind):
+        import torch
+        dt = {0: np.float32, 1: np.float32, 2: np.int64, 3: np.float64, 4: np.int64}[kind]
+        op = {0: self.dist.ReduceOp.MAX, 1: self.dist.ReduceOp.SUM, 2: self.dist.ReduceOp.SUM, 3: self.dist.ReduceOp.MAX,
+              4: self.dist.ReduceOp.MIN}[kind]
+        t = torch.from_numpy(self.be.to_host(buf, dt, count))
+        self.dist.all_reduce(t, op=op, group=self.group)
+        self.be.from_host(buf, t.numpy())
+
+    def all_gather(self, send, recv, nbytes):
+        import torch
+        a = torch.from_numpy(self.be.to_host(send, np.uint8, nbytes))
+        out = torch.empty(self.world * nbytes, dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(out, a, group=self.group)
+        self.be.from_host(recv, out.numpy())
+
+    def all_to_all_v(self, send, send_off, send_cnt, recv, recv_off, recv_cnt, elem_bytes):
+        import torch
+        total_s = max(int(o + c) for o, c in zip(send_off, send_cnt))
+        total_r = max(int(o + c) for o, c in zip(recv_off, recv_cnt))
+        s = self.be.to_host(send, np.uint8, total_s * elem_bytes)
+        r = self.be.to_host(recv, np.uint8, total_r * elem_bytes) if total_r else np.zeros(0, np.uint8)
+        reqs, bufs = [], []
+        for p in range(self.world):
+            so, sc, ro, rc = int(send_off[p]), int(send_cnt[p]), int(recv_off[p]), int(recv_cnt[p])
+            if p == self.rank:
+                r[ro * elem_bytes:(ro + rc) * elem_bytes] = s[so * elem_bytes:(so + sc) * elem_bytes]
+                continue
+            if sc:
+                reqs.append(self.dist.isend(torch.from_numpy(s[so * elem_bytes:(so + sc) * elem_bytes].copy()), p, group=self.group))
+            if rc:
+                t = torch.empty(rc * elem_bytes, dtype=torch.uint8)
+                bufs.append((ro, rc, t))
+                reqs.append(self.dist.irecv(t, p, group=self.group))
+        for q in reqs:
+            q.wait()
+        for ro, rc, t in bufs:
+            r[ro * elem_bytes:(ro + rc) * elem_bytes] = t.numpy()
+        if total_r:
+            self.be.from_host(recv, r)
 
 
 def reference_result(xyz_all, k, threshold_factor):

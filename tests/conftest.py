@@ -15,6 +15,8 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suite asserts bit-exact masks: a numpy whose float32 reductions are ordered differently must FAIL here, not warn
+    os.environ.setdefault("GSX_STRICT_NUMPY", "1")
 
 
 def pytest_sessionstart(session):

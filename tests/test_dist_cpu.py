@@ -20,56 +20,28 @@ def _free_port():
     return p
 
 
-class OracleCompute:
-    def knn(self, xyz_all, q_begin, q_count, k, algo=0):
-        import torch
-        from oracle import sor as osor
-        md = osor.mean_dists_ckdtree(xyz_all.numpy(), k, workers=2)
-        return torch.from_numpy(md[q_begin:q_begin + q_count].copy())
-
-    def knn_share(self, xyz_all, k, share, nshares, algo=0):
-        # any partition of the queries works for the choreography; like the GPU one this is
-        # spatial (slabs along z), i.e. scattered in index space
-        import torch
-        from oracle import sor as osor
-        xyz = xyz_all.numpy()
-        md = osor.mean_dists_ckdtree(xyz, k, workers=2)
-        order = np.argsort(xyz[:, 2], kind="stable")
-        n = len(xyz)
-        mine = order[n * share // nshares: n * (share + 1) // nshares]
-        out = np.zeros(n, np.float32)
-        out[mine] = md[mine]
-        return torch.from_numpy(out)
-
-    def stats(self, md_all, factor):
-        import torch
-        from oracle import sor as osor
-        return torch.tensor([np.float32(v) for v in osor.threshold_numpy(md_all.numpy(), factor)], dtype=torch.float32)
-
-    def mask(self, md_local, stats):
-        return (md_local < stats[2]).to(dtype=__import__("torch").uint8)
-
-
 def _worker(rank, world, port, n_local, k, sigma, out_dir):
     sys.path.insert(0, ROOT)
     import importlib
-    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gdist = importlib.import_module("3dgsconverter_amd.dist")
     from oracle import datasets
+    from oracle.slab_backend import GlooHostComm, NumpySlabBackend
     full = datasets.uniform(world * n_local, 10.0, 42)
-    local = torch.from_numpy(full[rank * n_local:(rank + 1) * n_local].copy())
-    res = gdist.sharded_sor(local, k, sigma, OracleCompute())
-    np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res.mask_local.numpy())
-    np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res.stats.numpy())
+    be = NumpySlabBackend()
+    res = gdist.replicated_sor(be, GlooHostComm(be), be.rows_buffer(full[rank * n_local:(rank + 1) * n_local]), n_local, k, sigma,
+                               want_host=True)
+    np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+    np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_sor_equals_single_process(world, tmp_path):
+    """the replicated exchange (dist.replicated_sor: north_star's all-gather design, torch-free in the product)"""
     import torch.multiprocessing as mp
     from oracle import datasets, sor as osor
     n_local, k, sigma = 4000, 16, 1.0
@@ -86,12 +58,27 @@ def test_sharded_sor_equals_single_process(world, tmp_path):
 
 def test_single_process_path_needs_no_process_group():
     import importlib
-    import torch
     from oracle import datasets, sor as osor
+    from oracle.slab_backend import NumpySlabBackend
     gdist = importlib.import_module("3dgsconverter_amd.dist")
     xyz = datasets.uniform(3000, 10.0, 1)
-    res = gdist.sharded_sor(torch.from_numpy(xyz), 8, 1.0, OracleCompute())
-    np.testing.assert_array_equal(res.mask_local.numpy().astype(bool), osor.sor(xyz, 8, 1.0, workers=2)["mask"])
+    be = NumpySlabBackend()
+    res = gdist.replicated_sor(be, None, be.rows_buffer(xyz), len(xyz), 8, 1.0, want_host=True)
+    np.testing.assert_array_equal(res["mask_host"], osor.sor(xyz, 8, 1.0, workers=2)["mask"])
+
+
+def test_multi_gpu_modules_do_not_import_torch():
+    """north_star: numpy + ctypes over the C ABI, no PyTorch -- also on the N > 1 path"""
+    import subprocess
+    code = ("import sys, importlib; sys.path.insert(0, %r);"
+            "[importlib.import_module('3dgsconverter_amd.' + m) for m in ('dist', 'dist_slab', 'dist_density', 'dist_palette', 'launch')];"
+            "assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+    for name in ("dist.py", "dist_slab.py", "dist_density.py", "dist_palette.py", "launch.py"):
+        src = open(os.path.join(ROOT, "3dgsconverter_amd", name)).read()
+        assert "import torch" not in src, name
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in bench
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -105,10 +92,10 @@ def _slab_worker(rank, world, port, n_local, k, sigma, kind, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
-    from oracle.slab_backend import NumpySlabBackend
+    from oracle.slab_backend import GlooHostComm, NumpySlabBackend
     full = _slab_cloud(kind, world * n_local)
     be = NumpySlabBackend()
-    comm = slab.TorchHostComm(be)
+    comm = GlooHostComm(be)
     rows = be.rows_buffer(full[rank * n_local:(rank + 1) * n_local])
     try:
         res = slab.slab_sor(be, comm, rows, n_local, k, sigma, want_host=True)
@@ -166,21 +153,20 @@ def _unequal_worker(rank, world, port, sizes, k, sigma, mode, out_dir):
     """shards of different sizes: `mode` slab = dist_slab.slab_sor, replicated = dist.sharded_sor (the fallback)"""
     sys.path.insert(0, ROOT)
     import importlib
-    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import datasets
+    from oracle.slab_backend import GlooHostComm, NumpySlabBackend
     full = datasets.uniform(sum(sizes), 10.0, 42)
     lo = sum(sizes[:rank])
     mine = full[lo:lo + sizes[rank]]
+    be = NumpySlabBackend()
     if mode == "slab":
         slab = importlib.import_module("3dgsconverter_amd.dist_slab")
-        from oracle.slab_backend import NumpySlabBackend
-        be = NumpySlabBackend()
         try:
-            res = slab.slab_sor(be, slab.TorchHostComm(be), be.rows_buffer(mine), sizes[rank], k, sigma, want_host=True)
+            res = slab.slab_sor(be, GlooHostComm(be), be.rows_buffer(mine), sizes[rank], k, sigma, want_host=True)
             np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
             np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
             np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
@@ -189,15 +175,20 @@ def _unequal_worker(rank, world, port, sizes, k, sigma, mode, out_dir):
                 f.write(str(e))
     else:
         gdist = importlib.import_module("3dgsconverter_amd.dist")
-        res = gdist.sharded_sor(torch.from_numpy(mine.copy()), k, sigma, OracleCompute())
-        np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res.mask_local.numpy())
-        np.save(os.path.join(out_dir, "md_%d.npy" % rank), res.mean_dists_local.numpy())
-        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res.stats.numpy())
+        rows = be.rows_buffer(mine) if len(mine) else be.buf("rows_empty", 16)
+        if mode == "either":   # dist.sharded_sor: the slab exchange, else (declined on every rank together) the replicated one
+            res, path = gdist.sharded_sor(be, GlooHostComm(be), rows, sizes[rank], k, sigma, want_host=True)
+            open(os.path.join(out_dir, "path_%d_%s" % (rank, path)), "w").close()
+        else:
+            res = gdist.replicated_sor(be, GlooHostComm(be), rows, sizes[rank], k, sigma, want_host=True)
+        np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+        np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
+        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("mode,sizes", [("slab", (16384, 9001)), ("slab", (12000, 8192, 20003)), ("replicated", (7001, 3000)),
-                                        ("replicated", (5000, 0, 6001))])
+                                        ("replicated", (5000, 0, 6001)), ("either", (9000, 3000)), ("either", (9000, 9500))])
 def test_unequal_index_shards_equal_single_process(mode, sizes, tmp_path):
     """round 3: shards of different sizes (what a per-rank density filter leaves behind), starts that are not multiples of
     4 (unaligned piece sums) -- mean distances, statistics and masks == the un-sharded oracle, bit for bit; the replicated
@@ -207,6 +198,9 @@ def test_unequal_index_shards_equal_single_process(mode, sizes, tmp_path):
     world, k, sigma = len(sizes), 16, 1.0
     mp.spawn(_unequal_worker, args=(world, _free_port(), list(sizes), k, sigma, mode, str(tmp_path)), nprocs=world, join=True)
     assert not list(tmp_path.glob("unsupported_*"))
+    if mode == "either":   # a shard below 8192 points: every rank falls back together; otherwise the slabs serve it
+        want = "replicated" if min(sizes) < 8192 else "slab"
+        assert len(list(tmp_path.glob("path_*_" + want))) == world
     ref = osor.sor(datasets.uniform(sum(sizes), 10.0, 42), k, sigma, workers=2)
     md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(world)])
     np.testing.assert_array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
@@ -242,12 +236,12 @@ def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     dd = importlib.import_module("3dgsconverter_amd.dist_density")
     from oracle import datasets
-    from oracle.slab_backend import NumpySlabBackend
+    from oracle.slab_backend import GlooHostComm, NumpySlabBackend
     full = datasets.make(spec)
     lo = sum(sizes[:rank])
     mine = full[lo:lo + sizes[rank]]
     be = NumpySlabBackend()
-    comm = slab.TorchHostComm(be)
+    comm = GlooHostComm(be)
     rows = be.rows_buffer(mine) if len(mine) else be.buf("rows_empty", 16)
     res = dd.sharded_density(be, comm, rows, sizes[rank], **kwargs)
     mask = np.zeros(sizes[rank], bool) if res["empty"] else be.to_host(res["mask"], np.uint8, sizes[rank]).astype(bool)
@@ -272,6 +266,9 @@ def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
     ((9000, 0, 21000), {"kind": "two_blobs", "n": 30000, "seed": 2}, {"voxel_size": 0.5, "threshold_percentage": 0.05, "keep_multicluster": True}),
     ((15000, 15000), {"kind": "clustered", "n": 30000, "seed": 5}, {"voxel_size": 1.0, "threshold_percentage": 0.32}),
     ((10000, 10000), {"kind": "uniform", "n": 20000, "extent": 10.0, "seed": 4}, {"sensitivity": 0.5}),        # removes everything
+    # a tiny shard next to a large one: the large rank's unique-voxel count exceeds the tiny rank's list capacity, so its
+    # list buffers are re-allocated AFTER the histogram was written (contents must survive the growth)
+    ((20, 29980), {"kind": "uniform", "n": 30000, "extent": 10.0, "seed": 6}, {"voxel_size": 0.5, "threshold_percentage": 0.01}),
 ])
 def test_sharded_density_equals_the_reference_filter(sizes, spec, kwargs, tmp_path):
     """masks of the index shards (unequal, one EMPTY) == oracle/density.py (pinned to the reference's own
@@ -358,11 +355,11 @@ def _palette_worker(rank, world, port, n, d, level, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     pal = importlib.import_module("3dgsconverter_amd.dist_palette")
-    from oracle.slab_backend import NumpySlabBackend
+    from oracle.slab_backend import GlooHostComm, NumpySlabBackend
     be = NumpySlabBackend()
     sh = (np.random.default_rng(5).standard_normal((n, d)) * 0.1).astype(np.float32)
     np.random.seed(77)
-    cen, lab = pal.palette_kmeans(sh, level, 4, kmeans=_oracle_kmeans, comm=slab.TorchHostComm(be), be=be)
+    cen, lab = pal.palette_kmeans(sh, level, 4, kmeans=_oracle_kmeans, comm=GlooHostComm(be), be=be)
     np.save(os.path.join(out_dir, "cen_%d.npy" % rank), cen)
     np.save(os.path.join(out_dir, "lab_%d.npy" % rank), lab)
     dist.destroy_process_group()
@@ -384,3 +381,81 @@ def test_palette_chunks_across_ranks_equal_the_single_process_loop(world, tmp_pa
     for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / ("cen_%d.npy" % r)), cen)
         np.testing.assert_array_equal(np.load(tmp_path / ("lab_%d.npy" % r)), lab)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the step's plan: C (gsx_slab_plan, what gsx_sor_slab_step_dev uses) == Python (dist_slab.plan_step, what the CPU
+# choreography above uses), field by field; and the launcher plumbing (3dgsconverter_amd/launch.py)
+def test_c_plan_equals_python_plan():
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("3dgsconverter_amd._lib")
+    S = importlib.import_module("3dgsconverter_amd.dist_slab")
+    lib = L.load()
+    rng = np.random.default_rng(0)
+    statuses = set()
+    for trial in range(120):
+        G = int(rng.integers(1, 9))
+        kind = trial % 5
+        words = np.zeros(8 + 4096 * G, np.uint32)
+        box = np.zeros(8, np.float32)
+        mn = rng.normal(size=3).astype(np.float32) * 10
+        ext = rng.random(3).astype(np.float32) * np.float32([5, 50, 1][trial % 3])
+        if kind == 4:
+            ext[1] = 0
+        box[:3], box[3:6] = -mn, mn + ext
+        if trial == 7:
+            box[4] = np.inf
+        words[:8] = box.view(np.uint32)
+        h = rng.integers(0, 50, (G, 4096)).astype(np.uint32)
+        if kind == 1:
+            h[:, 1000:1010] += 5000            # a dense sheet
+        if kind == 2:
+            h[:] = 0
+            h[:, 100:140] = rng.integers(0, 3000, (G, 40))   # everything inside 40 bins: halos cover most of it
+        if kind == 3:
+            h = (h * rng.integers(0, 2, (G, 1))).astype(np.uint32)   # empty shards
+        words[8:] = h.reshape(-1)
+        k = int(rng.choice([8, 16, 25, 32]))
+        for r in range(G):
+            n_local = int(h[r].sum())
+            plan = L.SlabPlan()
+            assert lib.gsx_slab_plan(words.ctypes.data, G, r, n_local, k, 1.5, C.byref(plan)) == 0, L.last_error()
+            c, p = plan.as_dict(), S.plan_step(words, G, r, n_local, k, 1.5)
+            assert p["status"] == c["status"]
+            statuses.add(p["status"])
+            if p["status"] == 0:
+                for key, a in p.items():
+                    same = (np.float32(a).tobytes() == np.float32(c[key]).tobytes()) if isinstance(a, float) else a == c[key]
+                    assert same, (trial, G, r, key, a, c[key])
+                assert sum(p["own_cnt"]) == n_local and p["n_send"] == n_local + sum(p["halo_cnt"])
+    assert statuses == {S.SLAB_OK, S.SLAB_EMPTY, S.SLAB_NONFINITE, S.SLAB_SMALL_SHARD, S.SLAB_NO_STRUCTURE}
+
+
+def _rdzv_rank(rank, path, out):
+    sys.path.insert(0, ROOT)
+    import importlib
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    uid = launch.exchange_unique_id(rank, lambda: bytes(range(128)), path, timeout_s=30)
+    with open(out + ".%d" % rank, "wb") as f:
+        f.write(uid)
+
+
+def test_unique_id_rendezvous_through_a_file(tmp_path):
+    import importlib
+    import multiprocessing as mp
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    path, out = str(tmp_path / "uid"), str(tmp_path / "got")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rdzv_rank, args=(r, path, out)) for r in (2, 1, 0)]   # rank 0 last: the others wait for it
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert [p.exitcode for p in procs] == [0, 0, 0]
+    for r in range(3):
+        assert open(out + ".%d" % r, "rb").read() == bytes(range(128))
+    launch.retire_unique_id(0, path)
+    assert not os.path.exists(path)
+    assert launch.pick_device_and_transport(3, 8, 8)[:2] == (3, os.environ.get("GSX_COMM_TRANSPORT") or "rccl")
+    assert launch.pick_device_and_transport(1, 2, 1)[:2] == (0, os.environ.get("GSX_COMM_TRANSPORT") or "hostwire")

@@ -3,14 +3,15 @@ a test box has:
 
   * world 1 through RcclComm -- librccl is dlopen'ed, a one-rank communicator is created and every collective of the
     step (all-reduce, all-gather, grouped send/recv) goes through RCCL on the library's stream;
-  * world 2 and 3 as separate processes that share the GPU, collectives through gloo on staged host copies
-    (TorchHostComm): the partition with halos, the slab KNN with reference-only rows, the certificate, the return
-    path and the piece-sum statistics run in HIP, only the wire is emulated.  The 8-GPU run over xGMI is the driver's.
+  * world 2 and 3 as separate processes that share the GPU, with the library's OWN communicator on its shared-memory
+    "hostwire" transport (csrc/comm.hip; RCCL refuses two ranks on one device): the whole step is the ONE C call the
+    8-GPU job makes (gsx_sor_slab_step_dev) -- partition with halos, slab KNN with reference-only rows, certificate,
+    return path, piece-sum statistics -- only the wire differs.  No torch in any of these processes.  The 8-GPU run
+    over xGMI is the driver's.
 
 Bar: identical to the single-GPU result, which is itself pinned to the reference's golden vectors."""
 import importlib
 import os
-import socket
 import sys
 
 import numpy as np
@@ -23,12 +24,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_JOB = [0]
+
+
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """(historic name) a fresh rendezvous file for one multi-process job: the unique id travels through it"""
+    import tempfile
+    _JOB[0] += 1
+    return os.path.join(tempfile.gettempdir(), "gsx_test_rdzv_%d_%d" % (os.getpid(), _JOB[0]))
+
+
+def _hostwire(slab, be, rank, world, rdzv):
+    """this rank's communicator on the shared-memory transport (ranks share the one GPU of the box)"""
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    uid = launch.exchange_unique_id(rank, lambda: slab.RcclComm.unique_id("hostwire"), rdzv, timeout_s=120)
+    comm = slab.RcclComm(be.ctx, rank, world, uid)
+    assert comm.transport == "hostwire"
+    comm.barrier()
+    launch.retire_unique_id(rank, rdzv)
+    return comm
 
 
 def test_slab_path_world1_through_rccl_matches_the_golden_1m(gsx, golden_cases):
@@ -59,10 +73,7 @@ def test_slab_path_world1_through_rccl_matches_the_golden_1m(gsx, golden_cases):
 
 
 def _spawn(target, world, args):
-    """world processes through the standard library's spawn context.  NOT torch.multiprocessing: importing torch into
-    this (pytest) process after libgsx_hip.so has bound ROCm's own libamdhip64 / librccl puts two HIP runtimes into
-    one process, which corrupts the heap at exit (torch must be imported FIRST where both are used --
-    the workers do that)."""
+    """world processes through the standard library's spawn context (no torch anywhere: numpy + ctypes)"""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=target, args=(r, world) + tuple(args)) for r in range(world)]
@@ -75,15 +86,10 @@ def _spawn(target, world, args):
 
 def _worker(rank, world, port, n_local, k, sigma, kind, out_dir):
     sys.path.insert(0, ROOT)
-    import torch  # noqa: F401  (first: see _spawn)
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     full = _cloud(kind, world * n_local)
     be = slab.HipSlabBackend(0)
-    comm = slab.TorchHostComm(be)
+    comm = _hostwire(slab, be, rank, world, port)
     rows = be.buf("rows", 12 * n_local)
     be.from_host(rows, full[rank * n_local:(rank + 1) * n_local])
     try:
@@ -95,7 +101,8 @@ def _worker(rank, world, port, n_local, k, sigma, kind, out_dir):
     except slab.SlabUncertain as e:
         with open(os.path.join(out_dir, "uncertain_%d.txt" % rank), "w") as f:
             f.write(str(e))
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def _cloud(kind, n):
@@ -148,15 +155,10 @@ def _blob_cloud(n):
 
 def _blob_worker(rank, world, port, n_local, k, out_dir):
     sys.path.insert(0, ROOT)
-    import torch  # noqa: F401
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     full = _blob_cloud(world * n_local)
     be = slab.HipSlabBackend(0)
-    comm = slab.TorchHostComm(be)
+    comm = _hostwire(slab, be, rank, world, port)
     rows = be.buf("rows", 12 * n_local)
     be.from_host(rows, full[rank * n_local:(rank + 1) * n_local])
     try:
@@ -167,7 +169,8 @@ def _blob_worker(rank, world, port, n_local, k, out_dir):
     except slab.SlabUncertain as e:
         with open(os.path.join(out_dir, "uncertain_%d.txt" % rank), "w") as f:
             f.write(str(e))
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def test_slab_path_with_uneven_slabs_takes_the_tree_on_every_rank(tmp_path):
@@ -211,18 +214,13 @@ def test_sharded_density_world1_through_rccl_matches_the_golden_masks(gsx, golde
 
 def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
     sys.path.insert(0, ROOT)
-    import torch  # noqa: F401  (first: see _spawn)
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     dd = importlib.import_module("3dgsconverter_amd.dist_density")
     full = datasets.make(spec)
     lo = sum(sizes[:rank])
     mine = full[lo:lo + sizes[rank]]
     be = slab.HipSlabBackend(0)
-    comm = slab.TorchHostComm(be)
+    comm = _hostwire(slab, be, rank, world, port)
     rows = be.buf("rows", 12 * max(sizes[rank], 1))
     if sizes[rank]:
         be.from_host(rows, mine)
@@ -239,7 +237,8 @@ def _density_worker(rank, world, port, sizes, spec, kwargs, then_sor, out_dir):
         np.save(os.path.join(out_dir, "final_%d.npy" % rank), final)
         np.save(os.path.join(out_dir, "stats_%d.npy" % rank), r2["stats_host"])
     be.check()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 @pytest.mark.parametrize("sizes,name", [((600000, 400000), "dens_u1m_L5_s0p5"), ((120001, 0, 79999), "dens_clustered_default")])
@@ -274,22 +273,19 @@ def test_config2_sharded_density_then_slab_sor_equals_the_reference_chain(tmp_pa
 
 def _unequal_worker(rank, world, port, sizes, k, out_dir):
     sys.path.insert(0, ROOT)
-    import torch  # noqa: F401
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     slab = importlib.import_module("3dgsconverter_amd.dist_slab")
     full = datasets.uniform(sum(sizes), 10.0, 42)
     lo = sum(sizes[:rank])
     be = slab.HipSlabBackend(0)
     rows = be.buf("rows", 12 * sizes[rank])
     be.from_host(rows, full[lo:lo + sizes[rank]])
-    res = slab.slab_sor(be, slab.TorchHostComm(be), rows, sizes[rank], k, 1.0, want_host=True)
+    comm = _hostwire(slab, be, rank, world, port)
+    res = slab.slab_sor(be, comm, rows, sizes[rank], k, 1.0, want_host=True)
     np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
     np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
     np.save(os.path.join(out_dir, "stats_%d.npy" % rank), res["stats_host"])
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 @pytest.mark.parametrize("sizes", [(300001, 199999), (100003, 250000, 8192)])
@@ -303,3 +299,129 @@ def test_slab_path_unequal_shards_on_shared_gpu(sizes, tmp_path):
     np.testing.assert_array_equal(masks, ref["mask"])
     for r in range(len(sizes)):
         assert np.float32(np.load(tmp_path / ("stats_%d.npy" % r))[2]).tobytes() == np.float32(ref["threshold"]).tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the fused C step against its spelled-out choreography, the torch-free replicated exchange, the launcher
+def _both_worker(rank, world, port, sizes, k, out_dir):
+    """every path a multi-GPU job can take, on the same shards: the fused C step, the call-by-call choreography over the same
+    communicator, the replicated exchange (dist.replicated_sor)"""
+    sys.path.insert(0, ROOT)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    gdist = importlib.import_module("3dgsconverter_amd.dist")
+    full = datasets.uniform(sum(sizes), 10.0, 42)
+    lo = sum(sizes[:rank])
+    be = slab.HipSlabBackend(0)
+    rows = be.buf("rows", 12 * sizes[rank])
+    be.from_host(rows, full[lo:lo + sizes[rank]])
+    comm = _hostwire(slab, be, rank, world, port)
+    out = {}
+    for name, fn in (("fused", lambda: slab.slab_sor(be, comm, rows, sizes[rank], k, 1.0, want_host=True)),
+                     ("steps", lambda: slab.slab_sor(be, comm, rows, sizes[rank], k, 1.0, want_host=True, fused=False)),
+                     ("replicated", lambda: gdist.replicated_sor(be, comm, rows, sizes[rank], k, 1.0, want_host=True))):
+        res = fn()
+        out[name] = (res["mask_host"].copy(), res["mean_dists_host"].copy(), res["stats_host"].copy())
+        if name == "fused":
+            assert res["plan"]["sizes"] == list(sizes) and res["n_own"] > 0
+    for name in ("steps", "replicated"):
+        for a, b in zip(out["fused"], out[name]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    np.save(os.path.join(out_dir, "mask_%d.npy" % rank), out["fused"][0])
+    np.save(os.path.join(out_dir, "md_%d.npy" % rank), out["fused"][1])
+    # scalars through the device communicator (what bench.py times with)
+    assert comm.reduce_scalar(float(rank), slab.KIND_F64_MAX) == float(world - 1)
+    assert comm.reduce_scalar(rank + 5, slab.KIND_I64_MIN) == 5
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("sizes", [(200000, 200000), (90001, 150000, 60003)])
+def test_fused_step_equals_its_choreography_and_the_replicated_exchange(sizes, tmp_path):
+    _spawn(_both_worker, len(sizes), (_free_port(), list(sizes), 16, str(tmp_path)))
+    ref = osor.sor(datasets.uniform(sum(sizes), 10.0, 42), 16, 1.0)
+    md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(len(sizes))])
+    np.testing.assert_array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
+    masks = np.concatenate([np.load(tmp_path / ("mask_%d.npy" % r)) for r in range(len(sizes))]).astype(bool)
+    np.testing.assert_array_equal(masks, ref["mask"])
+
+
+def _fallback_worker(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    gdist = importlib.import_module("3dgsconverter_amd.dist")
+    full = datasets.scene_with_floaters(world * n_local, 3)
+    be = slab.HipSlabBackend(0)
+    rows = be.buf("rows", 12 * n_local)
+    be.from_host(rows, full[rank * n_local:(rank + 1) * n_local])
+    comm = _hostwire(slab, be, rank, world, port)
+    res, path = gdist.sharded_sor(be, comm, rows, n_local, 16, 1.0, want_host=True)
+    assert path == "replicated"
+    np.save(os.path.join(out_dir, "mask_%d.npy" % rank), res["mask_host"])
+    np.save(os.path.join(out_dir, "md_%d.npy" % rank), res["mean_dists_host"])
+    comm.barrier()
+    comm.close()
+
+
+def test_sharded_sor_falls_back_to_the_replicated_exchange_on_floaters(tmp_path):
+    """dist.sharded_sor: the slab exchange declines a scene with far floaters on every rank together, the replicated exchange
+    (all-gather of the rows through gsx_comm_all_gather, share of the tree's leaves, sum all-reduce) is exact for it"""
+    world, n_local = 2, 60000
+    _spawn(_fallback_worker, world, (_free_port(), n_local, str(tmp_path)))
+    ref = osor.sor(datasets.scene_with_floaters(world * n_local, 3), 16, 1.0)
+    md = np.concatenate([np.load(tmp_path / ("md_%d.npy" % r)) for r in range(world)])
+    np.testing.assert_array_equal(md.view(np.uint32), ref["mean_dists"].view(np.uint32))
+    masks = np.concatenate([np.load(tmp_path / ("mask_%d.npy" % r)) for r in range(world)]).astype(bool)
+    np.testing.assert_array_equal(masks, ref["mask"])
+
+
+def test_sharded_density_with_a_tiny_shard_on_shared_gpu(tmp_path):
+    """a 20-point shard next to a 29 980-point one -- the tiny rank's voxel lists are re-allocated to the
+    large rank's length AFTER its histogram was written; the contents must survive"""
+    from oracle import density as oden
+    spec = {"kind": "uniform", "n": 30000, "extent": 10.0, "seed": 6}
+    sizes = [20, 29980]
+    kwargs = {"voxel_size": 0.5, "threshold_percentage": 0.01}
+    _spawn(_density_worker, 2, (_free_port(), sizes, spec, kwargs, None, str(tmp_path)))
+    ref = oden.density_filter(datasets.make(spec), 0.5, 0.01)
+    got = np.concatenate([np.load(tmp_path / ("dmask_%d.npy" % r)) for r in range(2)])
+    np.testing.assert_array_equal(got, ref["mask"])
+
+
+@pytest.mark.parametrize("launcher", ["self", "external"])
+def test_bench_gpus_2_end_to_end(launcher, tmp_path):
+    """`python bench.py --gpus 2` as the driver invokes it: the file starts its own two ranks (launcher "self"), or ranks a
+    launcher started find each other through RANK / WORLD_SIZE (launcher "external": two plain subprocesses with torchrun's
+    environment).  On this one-GPU box the ranks share the GPU over the hostwire transport; the JSON contract, the slab
+    exchange (cross-checked against the replicated one inside the run) and configs[3] are the same code an 8-GPU node runs."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "400000", "--n3", "600000"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GSX_RDZV_FILE"):
+        env.pop(k, None)
+    if launcher == "self":
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    else:
+        env.update({"WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29417", "TORCHELASTIC_RUN_ID": "t%d" % os.getpid()})
+        procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(2)]
+        outs = [p.communicate(timeout=900) for p in procs]
+        assert [p.returncode for p in procs] == [0, 0], outs[0][1][-2000:] + outs[1][1][-2000:]
+        lines = [ln for o in outs for ln in o[0].splitlines() if ln.strip()]
+    assert len(lines) == 1, lines            # exactly ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Msplats/s" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert "hostwire" in d["config"]["transport"] and "slab" in d["config"]["parallelism"]
+    assert d["config"]["host_runtime"].endswith("torch is not imported")
+    assert abs(d["value"] - 2 * 400000 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) < 0.01 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_ms"] > 0
+    c3 = d["config3"]
+    assert "error" not in c3 and c3["value"] > 0 and c3["exchange"] == "slab"
+    # the survivors of rank 0's shard of the 2 x 400 000 cloud, against the oracle on the whole cloud
+    full = np.concatenate([datasets.uniform(400000, 5.0, r) for r in range(2)])
+    ref = osor.sor(full, 16, 1.0)
+    assert d["survivors_rank0"] == int(ref["mask"][:400000].sum())
+    assert np.float32(d["threshold"]).tobytes() == np.float32(ref["threshold"]).tobytes()

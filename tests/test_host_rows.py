@@ -140,3 +140,19 @@ def test_zero_columns_and_append_columns_equal_numpy(gsx):
     b["f_rest_3"] = 0.0
     b["rot_3"] = 0.0
     assert a.tobytes() == b.tobytes()
+
+
+def test_lazy_cap_sh_degree_belongs_to_the_table_it_was_called_on():
+    """a deferred cap_sh_degree followed by `processor.data = other` must zero the ORIGINAL table (the
+    reference zeroes it at once, data_processor.py:313) and leave `other` alone"""
+    import importlib
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    dt = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4")] + [("f_rest_%d" % i, "f4") for i in range(45)])
+    a, b = np.ones(50, dtype=dt), np.ones(30, dtype=dt)
+    for name in dt.names:
+        a[name], b[name] = 1.0, 2.0
+    proc = dp.DataProcessor(a, lazy=True)
+    assert proc.cap_sh_degree(1) is None and float(a["f_rest_9"].sum()) == 50.0      # deferred: nothing written yet
+    proc.data = b
+    assert float(a["f_rest_9"].sum()) == 0.0 and float(a["f_rest_44"].sum()) == 0.0 and float(a["f_rest_8"].sum()) == 50.0
+    assert proc.data is b and float(b["f_rest_9"].sum()) == 60.0                     # the new table is untouched

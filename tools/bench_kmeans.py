@@ -22,24 +22,30 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (~
 
 
 def main(args):
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    """no torch: ranks from 3dgsconverter_amd/launch.py (own ranks when run plainly with --gpus N), barrier and the MAX of the
+    ranks' clocks through the C library's communicator"""
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    rank, local_rank, world = launch.rank_env()
+    if world == 1 and args.gpus > 1:
+        sys.exit(launch.spawn_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not hasattr(args, "json_fd"):
+        sys.stdout.flush()
+        args.json_fd = os.dup(1)
+        os.dup2(2, 1)
 
     gsx = importlib.import_module("3dgsconverter_amd")
     pal = importlib.import_module("3dgsconverter_amd.dist_palette")
+    gslab = importlib.import_module("3dgsconverter_amd.dist_slab")
     L = gsx._lib
-    ctx = L.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    device, transport = launch.pick_device_and_transport(local_rank, world, L.device_count())
+    ctx = L.Context(device)
+    comm = None
+    if world > 1:
+        comm = gslab.RcclComm(ctx, rank, world, launch.exchange_unique_id(rank, lambda: gslab.RcclComm.unique_id(transport)))
+        comm.barrier()
+        launch.retire_unique_id(rank)
 
     n_scene = args.n if args.n != 10_000_000 or True else args.n
     d, iters, level = 45, 10, 2
@@ -54,28 +60,31 @@ def main(args):
     # stream as bench.py's config4, walked by every rank so that a chunk's data does not depend on the number of GPUs
     rng = np.random.default_rng(0)
     np.random.seed(0)
-    chunks, inits = [], []
+    chunks, inits, first_host = [], [], None
     for i in range(nch):
         rows = min(cs, n_scene - i * cs)
         x = rng.standard_normal((rows, d), dtype=np.float32) * np.float32(0.1)
         pick = np.random.choice(rows, k, replace=False)
         if i in mine:
-            chunks.append(torch.from_numpy(x).to(dev))
-            inits.append(torch.from_numpy(np.ascontiguousarray(x[pick])).to(dev))
-    cents = [t.clone() for t in inits]
-    labels = [torch.empty(c.shape[0], dtype=torch.int32, device=dev) for c in chunks]
-    torch.cuda.synchronize()
+            if not chunks:
+                first_host = x
+            chunks.append((ctx.alloc(x.nbytes).upload(x), rows))
+            inits.append(ctx.alloc(4 * k * d).upload(np.ascontiguousarray(x[pick])))
+    cents = [ctx.alloc(4 * k * d) for _ in inits]
+    labels = [ctx.alloc(4 * r + 16) for _, r in chunks]
+    ctx.synchronize()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+        else:
+            ctx.synchronize()
 
     def step():
         for j in range(len(mine)):
-            cents[j].copy_(inits[j])
-            L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j].data_ptr(), chunks[j].shape[0], d, k, iters,
-                                                 cents[j].data_ptr(), labels[j].data_ptr()), "gsx_kmeans_lloyd_dev")
+            L.check(ctx.lib.gsx_dev_copy(ctx.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
+            L.check(ctx.lib.gsx_kmeans_lloyd_dev(ctx.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
+                    "gsx_kmeans_lloyd_dev")
 
     for kv in getattr(args, "param", []) or []:
         name, val = kv.split("=")
@@ -92,22 +101,20 @@ def main(args):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    if comm is not None:
+        dt = float(comm.reduce_scalar(dt, gslab.KIND_F64_MAX))
     n_as, ms_as = ctx.timing(L.T_KMEANS_ASSIGN)
     n_up, ms_up = ctx.timing(L.T_KMEANS_UPDATE)
     ctx.set_timing(False)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
         return
 
     ms_step = dt / steps * 1e3
     value = n_scene * steps / dt / 1e6
     assign_ms = ms_as / max(n_as, 1)            # one timing interval = operand prep + matrix-core assign + exact list, one chunk iteration
-    rows0 = chunks[0].shape[0]
+    rows0 = chunks[0][1]
     ktiles, ns = (k + 31) // 32, 3              # 32-centroid tiles, three 16-wide slices of the 45 (+3) dimensions
     # three v_mfma_f32_32x32x16_bf16 per slice (xh.ch + xh.cl + xl.ch), 2*32*32*16 flops each, per (32 points x 32 centroids)
     flops = -(-rows0 // 32) * ktiles * ns * 3 * 2 * 32 * 32 * 16
@@ -135,18 +142,19 @@ def main(args):
     if world == 1 and not args.no_cpu_baseline:
         # the reference's CPU path for the same call (gpu_ops.py:48-52: MiniBatchKMeans, batch 16384, n_init auto), ONE chunk
         from sklearn.cluster import MiniBatchKMeans
-        x = chunks[0].cpu().numpy()
+        x = first_host
         t0 = time.perf_counter()
         km = MiniBatchKMeans(n_clusters=k, max_iter=iters, batch_size=min(4096 * 4, len(x)), n_init="auto", compute_labels=True)
         km.fit(x)
         cpu_dt = time.perf_counter() - t0
         from oracle import kmeans as okm
         i_cpu = okm.inertia(x, km.cluster_centers_, km.labels_)
-        i_gpu = okm.inertia(x, cents[0].cpu().numpy(), labels[0].cpu().numpy())
+        i_gpu = okm.inertia(x, cents[0].download(np.float32, k * d).reshape(k, d), labels[0].download(np.int32, rows0))
         out["cpu_baseline"] = {"value": round(rows0 / cpu_dt / 1e6, 4), "unit": "Msplats/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": "one of the %d chunks (%d x %d, K=%d, max_iter=%d), once (%.2f s): sklearn MiniBatchKMeans "
                                          "called as the reference's _kmeans_sklearn does" % (nch, rows0, d, k, iters, cpu_dt),
                                "inertia_cpu": round(i_cpu, 2), "inertia_gpu_same_chunk": round(i_gpu, 2)}
     os.write(args.json_fd, (json.dumps(out) + "\n").encode())   # bench.py pointed fd 1 at stderr; this is the real stdout
-    if world > 1:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
