@@ -23,6 +23,7 @@
 #include <cmath>
 
 #include "gsx_common.h"
+#include "sor_grid_params.h"
 
 namespace gsx {
 
@@ -110,8 +111,15 @@ __global__ __launch_bounds__(256) void slab_hist_kernel(const float *__restrict_
     const float *__restrict__ c = axis == 0 ? x : (axis == 1 ? y : z);
     for (int i = threadIdx.x; i < SLAB_BINS; i += 256) h[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&h[slab_bin(c[i * stride], lo, inv_w)], 1u);
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * step) {   // 8 loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c[(i0 + u * step < n ? i0 + u * step : i0) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * step < n) atomicAdd(&h[slab_bin(v[u], lo, inv_w)], 1u);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < SLAB_BINS; i += 256)
         if (h[i]) atomicAdd(&hist[i], h[i]);
@@ -261,7 +269,7 @@ static double slab_pts_per_cell(int k, int64_t n)
 }
 
 int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
-                    int64_t n_halo, int k, float *mean_out, double *kth_out);
+                    int64_t n_halo, int k, float *mean_out, double *kth_out, const SlabKnn *sk = nullptr);
 int launch_sor_piece_sums(gsx_ctx *ctx, const float *a, int64_t n, const float *mean_dev, float *piece_out);
 int launch_sor_stats_from_pieces(gsx_ctx *ctx, const float *pieces, int64_t npieces, int64_t n_total, int mode, double factor,
                                  float *stats_dev);
@@ -612,11 +620,27 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     GSX_CHECK(w.md_slab.reserve(4 * (size_t)std::max<int64_t>(n_own, 1)));
     GSX_CHECK(w.kth.reserve(8 * (size_t)std::max<int64_t>(n_own, 1)));
     if (n_own > 0) {
-        GSX_CHECK(launch_knn_slab(c, slab_rows, slab_rows + 1, slab_rows + 2, 3, n_own, n_halo, k, w.md_slab.as<float>(), w.kth.as<double>()));
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_own, 1024), (int64_t)c->num_cu * 8));
-        hipLaunchKernelGGL(slab_certify_kernel, dim3(blocks), dim3(256), 0, c->stream, slab_rows + p.axis, (int64_t)3, n_own, w.kth.as<double>(),
-                           p.plane_lo, p.plane_hi, unc);
-        GSX_HIP(hipGetLastError());
+        // the grid path's kernels count the uncertified queries themselves (no 8-byte k-th distance array, no kernel of its
+        // own reading it back) and take the box from the all-reduced one: along the partition axis the rows lie between the
+        // outer edges of the received bins (one bin of margin for the f32 binning arithmetic)
+        SlabKnn sk;
+        sk.cert_axis = p.axis;
+        sk.cert_lo = p.plane_lo;
+        sk.cert_hi = p.plane_hi;
+        sk.cert_count = unc;
+        const double bw = p.hi > p.lo ? ((double)p.hi - (double)p.lo) / SLAB_BINS : 0.0;
+        const int b0 = p.cut[r] - p.halo_bins, b1 = p.cut[r + 1] + p.halo_bins;
+        sk.box.b7 = b7;
+        sk.box.axis = p.axis;
+        sk.box.lo = (r == 0 || b0 <= 1) ? -INFINITY : std::nextafter((float)((double)p.lo + ((double)b0 - 1.0) * bw), -INFINITY);
+        sk.box.hi = (r == G - 1 || b1 >= SLAB_BINS - 1) ? INFINITY : std::nextafter((float)((double)p.lo + ((double)b1 + 1.0) * bw), INFINITY);
+        GSX_CHECK(launch_knn_slab(c, slab_rows, slab_rows + 1, slab_rows + 2, 3, n_own, n_halo, k, w.md_slab.as<float>(), w.kth.as<double>(), &sk));
+        if (c->last_knn_algo == GSX_KNN_TREE) {   // an uneven slab took the Morton-tree path, which hands the k-th distances over
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_own, 1024), (int64_t)c->num_cu * 8));
+            hipLaunchKernelGGL(slab_certify_kernel, dim3(blocks), dim3(256), 0, c->stream, slab_rows + p.axis, (int64_t)3, n_own,
+                               w.kth.as<double>(), p.plane_lo, p.plane_hi, unc);
+            GSX_HIP(hipGetLastError());
+        }
     }
     if (G > 1) GSX_CHECK(gsx_comm_all_reduce(c, unc, 1, GSX_COMM_I64_SUM));
     // ---- 6. mean distances back to the index owners, original order

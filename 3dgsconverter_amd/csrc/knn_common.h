@@ -310,5 +310,11 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // wave-uniform value known to the compiler as scalar
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Values the optimiser must not hoist out of a loop or a branch: whatever is computed from the result stays where the
+// call is (knn_brick: loop-invariant setup arithmetic hoisted to the kernel entry and parked in scratch cost 0.8 GB of
+// spill traffic per 10M-splat launch; recomputing it is a handful of instructions)
+__device__ __forceinline__ int pinned_here(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float pinned_here(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int pinned_here_s(int v) { asm volatile("" : "+s"(v)); return v; }
 
 }  // namespace gsx

@@ -66,6 +66,10 @@ struct GridParamArgs {   // what grid_params needs besides the partial boxes
     GridParams *gp;
     unsigned *devflags;
     double h_hint;   // > 0: cell edge suggested by the density probe of the parent level (never above the bbox-volume edge)
+    // multi-GPU slab step (launch_knn_slab): the certificate's planes and counter (axis < 0: off) ...
+    int cert_axis;
+    float cert_lo, cert_hi;
+    unsigned *cert_count;
 };
 __device__ void grid_params_body(const float *part, int nparts, const GridParamArgs &a);
 
@@ -262,6 +266,10 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
     gp->sub_count = 0;
     gp->sub_queries = 0;
     gp->refined_count = 0;
+    gp->cert_axis = a.cert_axis;
+    gp->cert_lo = a.cert_lo;
+    gp->cert_hi = a.cert_hi;
+    gp->cert_count = a.cert_count;
     for (int i = 0; i < 8; ++i) {
         gp->brick_ctr[i * 32] = 0;
         gp->extra_ctr[i * 32] = 0;
@@ -269,6 +277,22 @@ __device__ void grid_params_body(const float *part, int nparts, const GridParamA
         gp->ringf_ctr[i * 32] = 0;
     }
 
+}
+
+// The box is known (multi-GPU slab step: the all-reduced global box, cut to the slab's bins along the partition axis):
+// no pass over the rows, one wave writes the grid parameters.
+__global__ __launch_bounds__(64) void grid_params_known_box_kernel(KnownBox kb, float *__restrict__ part, GridParamArgs gpa)
+{
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        float v = a < 3 ? -kb.b7[a] : kb.b7[a];          // minima | maxima | non-finite flag
+        if (a == kb.axis) v = fmaxf(v, kb.lo);
+        if (a == 3 + kb.axis) v = fminf(v, kb.hi);
+        __hip_atomic_store(&part[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    grid_params_body(part, 1, gpa);
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int dim)
@@ -746,10 +770,16 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
         // lane r < 16: candidate row r (bdx+2 cells along x); lanes 16..19: query rows (bdx cells)
         int v_start = 0, v_len = 0;
         {
-            const bool isq = lane >= 16;
-            const int r = isq ? lane - 16 : lane;
-            const int yy = isq ? by * bdy + (r % bdy) : by * bdy - 1 + (r % cry);
-            const int zz = isq ? bz * bdz + (r / bdy) : bz * bdz - 1 + (r / cry);
+            // (recomputed per brick from a pinned lane id: as loop invariants these five values, the division magic behind
+            //  them and a dozen more were kept in scratch across the whole kernel.  bdy is 1 or 2, cry = bdy + 2 is 3 or 4)
+            const int ln = pinned_here(lane);
+            const bool isq = ln >= 16;
+            const int r = isq ? ln - 16 : ln;
+            const int r_mod_bdy = bdy == 2 ? (r & 1) : 0, r_div_bdy = bdy == 2 ? (r >> 1) : r;
+            const int r_div_cry = cry == 4 ? (r >> 2) : (r * 11) >> 5;       // r < 16
+            const int r_mod_cry = r - r_div_cry * cry;
+            const int yy = isq ? by * bdy + r_mod_bdy : by * bdy - 1 + r_mod_cry;
+            const int zz = isq ? bz * bdz + r_div_bdy : bz * bdz - 1 + r_div_cry;
             const int xa = isq ? bx * bdx : max(bx * bdx - 1, 0);
             const int xb = isq ? min(bx * bdx + bdx - 1, nx - 1) : min(bx * bdx + bdx, nx - 1);
             const bool valid = (isq ? (lane < 20 && r < nqrows) : r < ncrows) && yy >= 0 && yy < ny && zz >= 0 && zz < nz;
@@ -833,7 +863,13 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                 // runs -- which queries land in a later batch depends on the order the binning's atomics leave in a cell.)
                 if (boundary && qb == 0) {  // wave-uniform
                     // f32 is enough: the 1e-3*h' margin dwarfs its rounding (<= dims * 2^-23 * h' ~ 1e-4 h')
-                    const float hf = (float)hp;
+                    // (pinned: 8 % of the bricks get here; hoisted, its per-brick operands were computed and parked in
+                    //  scratch for every brick)
+                    const float hf = pinned_here((float)hp);
+                    // (the faces again, from pinned brick coordinates: their float conversions stay in here too)
+                    const int pbx = pinned_here_s(bx), pby = pinned_here_s(by), pbz = pinned_here_s(bz);
+                    const int ulo[3] = {pbx * bdx - 1, pby * bdy - 1, pbz * bdz - 1};
+                    const int uhi[3] = {pbx * bdx + bdx, pby * bdy + bdy, pbz * bdz + bdz};
                     const float rel[3] = {qx - g_ox, qy - g_oy, qz - g_oz};
                     const float r1 = hf * (1.0f - 1e-3f);
                     float rsafe = 3.0e38f, frac = 1.0f;
@@ -880,8 +916,10 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                 rs_start = 0;
                 rs_len = 0;
                 if (lane < ncrows) {
-                    const int yy = by * bdy - 1 + (lane % cry);
-                    const int zz = bz * bdz - 1 + (lane / cry);
+                    const int ln = pinned_here(lane);
+                    const int l_div_cry = cry == 4 ? (ln >> 2) : (ln * 11) >> 5;     // ln < 16
+                    const int yy = by * bdy - 1 + (ln - l_div_cry * cry);
+                    const int zz = bz * bdz - 1 + l_div_cry;
                     const int xa = max(max(bx * bdx - 1, 0), lo[0] - 1);
                     const int xb = min(min(bx * bdx + bdx, nx - 1), hi[0] + 1);
                     const bool need = yy >= max(lo[1] - 1, 0) && yy <= min(hi[1] + 1, ny - 1) &&
@@ -1020,7 +1058,8 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                 if (nwords <= WCAP && !(dbg & 2)) {
                 mf_done = true;
                 // cell-unit coordinates relative to the brick centre; see the MFMA notes at the top
-                const float hf = (float)hp;
+                // (pinned: computed here, per batch -- nine instructions -- instead of per brick with a round trip through scratch)
+                const float hf = pinned_here((float)hp);
                 const float ccx = g_ox + ((float)(bx * bdx) + 0.5f * (float)bdx) * hf;
                 const float ccy = g_oy + ((float)(by * bdy) + 0.5f * (float)bdy) * hf;
                 const float ccz = g_oz + ((float)(bz * bdz) + 0.5f * (float)bdz) * hf;
@@ -1154,7 +1193,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                 } else if (dbg & 4) {
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = (float)kth_d2;
                 } else if (kth_d2 <= racc_sq) {
-                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth_d2;
+                    kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, kth_d2, qx, qy, qz);
                     if constexpr (NET) mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_net(lst, k);
                     else mean_out[(int)__float_as_uint(qp.w) - q_begin] = mean_from_list<KCAP>(lst, k);
                 } else {
@@ -1334,7 +1373,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_ring_kernel(
                     if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
                     double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
                     mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
-                    if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+                    kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, kth, qp.x, qp.y, qp.z);
                 }
                 wave_sync();
                 break;
@@ -2175,7 +2214,7 @@ __global__ __launch_bounds__(BRICK_THREADS, KCAP <= 33 ? RINGF_WAVES : 3) void k
             if (lane == 0) {   // out[0] = the query itself
                 double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
                 mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
-                if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+                kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, kth, qp.x, qp.y, qp.z);
             }
             wave_sync();
             solved = true;
@@ -2284,7 +2323,7 @@ static int dispatch_ring(gsx_ctx *ctx, const BrickLaunch &a)
 // Multi-GPU slab: points [0, n_own) are queries, [n_own, n_own + n_halo) reference-only; kth_out (nullable) receives
 // every query's (k+1)-th squared distance so that the caller can certify it against the slab's open faces.
 int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
-                    int64_t n_halo, int k, float *mean_out, double *kth_out);
+                    int64_t n_halo, int k, float *mean_out, double *kth_out, const SlabKnn *sk = nullptr);
 
 // csrc/sor_tree.hip: the path for clouds this grid cannot resolve
 int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_ref, int64_t q_begin,
@@ -2329,7 +2368,7 @@ static int bin_points(gsx_ctx *ctx, KnnWs &w, const float *x, const float *y, co
 static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *y, const float *z, int64_t stride,
                           int64_t n_ref, int64_t q_begin, int64_t q_count, int k, float *mean_out, double *kth_out,
                           gsx_sor_info *info, int share, int nshares, bool adaptive, float parent_h,
-                          int64_t ref_only_from = INT32_MAX, double h_hint = 0.0)
+                          int64_t ref_only_from = INT32_MAX, double h_hint = 0.0, const SlabKnn *sk = nullptr)
 {
     KnnWs &w = ctx->ws[level];
     if (level == 0) ctx->last_knn_algo = GSX_KNN_GRID;
@@ -2395,10 +2434,14 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
     // (adaptive mode may still switch the deferral off below, once the histogram is known: defer_words is then cleared on the device)
     GridParamArgs gpa{(int)n_ref, pts_per_cell, (int)cap, ctx->debug_skip, share, nshares, adaptive ? ctx->defer_words : 0, parent_h, gp,
-                      ctx->devflags.as<unsigned>(), h_hint};
+                      ctx->devflags.as<unsigned>(), h_hint, sk ? sk->cert_axis : -1, sk ? sk->cert_lo : 0.0f, sk ? sk->cert_hi : 0.0f,
+                      sk ? sk->cert_count : nullptr};
     const bool adaptive_at_bbox = adaptive;
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
-                       w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
+    if (sk && sk->box.b7)
+        hipLaunchKernelGGL(grid_params_known_box_kernel, dim3(1), dim3(64), 0, ctx->stream, sk->box, w.bboxpart.as<float>(), gpa);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
+                           w.bboxpart.as<float>(), gpa);   // its last workgroup computes the grid parameters
     GSX_HIP(hipGetLastError());
     if (adaptive) GSX_CHECK(w.qcellstart.reserve(sizeof(unsigned) * (size_t)(cap + 1)));  // free in this mode: the cursors
     // Adaptive mode, first decision: can ONE grid resolve this cloud at all?  The coarse histogram of the two-level sort (one
@@ -2757,11 +2800,13 @@ int launch_knn_grid(gsx_ctx *ctx, const float *x, const float *y, const float *z
                           ctx->adaptive != 0, 0.0f);
 }
 
+// sk (optional): the certificate evaluated inside the grid path's kernels (kth_out is then only written by the tree path:
+// ctx->last_knn_algo says which ran) and a box the caller already knows
 int launch_knn_slab(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n_own,
-                    int64_t n_halo, int k, float *mean_out, double *kth_out)
+                    int64_t n_halo, int k, float *mean_out, double *kth_out, const SlabKnn *sk)
 {
     return knn_grid_level(ctx, 0, x, y, z, stride, n_own + n_halo, 0, n_own, k, mean_out, kth_out, nullptr, 0, 1, false, 0.0f,
-                          n_own);
+                          n_own, 0.0, sk);
 }
 
 }  // namespace gsx

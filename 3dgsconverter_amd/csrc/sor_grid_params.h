@@ -43,6 +43,44 @@ struct GridParams {
     // arrival tickets of the kernels whose last workgroup finishes the job of a former one-workgroup launch
     // (bbox_partial -> grid parameters, bucket_hist -> bucket scan); never touched by grid_params, self-resetting
     unsigned ticket_bbox, ticket_hist;
+    // multi-GPU slab step: the certificate of csrc/dist_slab.hip evaluated where the k-th distance is produced (instead
+    // of an 8-byte array written here and read back by a kernel of its own).  cert_axis < 0: off
+    int cert_axis;
+    float cert_lo, cert_hi;      // planes between which this rank holds EVERY point of the cloud (+-inf at the cloud's ends)
+    unsigned *cert_count;        // number of queries whose k-th neighbour might lie beyond them
+};
+
+#ifdef __HIPCC__
+// every kernel of the grid path hands a finished query's (k+1)-th squared distance (the query itself included) here
+__device__ __forceinline__ void kth_emit(GridParams *gp, double *kth_out, int idx, double kth, float qx, float qy, float qz)
+{
+    if (!kth_out) return;   // the single-GPU path: nothing is loaded, nothing is written
+    const int axis = gp->cert_axis;
+    if (axis >= 0) {
+        const double v = (double)(axis == 0 ? qx : (axis == 1 ? qy : qz));
+        // margin: the halo membership test was made in f32 on the same coordinates -- exact; 1e-6 relative for the
+        // plane arithmetic itself (the rule of slab_certify_kernel, which the tree path still uses)
+        const double d = fmin(v - (double)gp->cert_lo, (double)gp->cert_hi - v) * (1.0 - 1e-6);
+        if (!(kth <= d * d)) atomicAdd(gp->cert_count, 1u);
+    } else {
+        kth_out[idx] = kth;
+    }
+}
+#endif
+
+// launch_knn_slab's optional extras (csrc/dist_slab.hip -> csrc/sor_grid.hip)
+// a bounding box the caller already knows (the all-reduced global box, cut to the slab's bins along the partition
+// axis): the box pass over the rows is skipped
+struct KnownBox {
+    const float *b7;     // device: max over the cloud of (-x,-y,-z,x,y,z), non-finite flag
+    int axis;            // along this axis the rows lie in [lo, hi] instead
+    float lo, hi;
+};
+struct SlabKnn {         // what launch_knn_slab's caller may add (both optional)
+    int cert_axis = -1;
+    float cert_lo = 0.0f, cert_hi = 0.0f;
+    unsigned *cert_count = nullptr;
+    KnownBox box{nullptr, 0, 0.0f, 0.0f};
 };
 
 // Work distribution shared by knn_brick / knn_ring (device): static stride + a small dynamic tail.
