@@ -62,6 +62,13 @@ class SlabStep(C.Structure):
                 ("stats_dev", C.c_void_p), ("uncertain_dev", C.c_void_p)]
 
 
+class DensityInfo(C.Structure):
+    """gsx_density_info (include/gsx_hip.h)"""
+    _fields_ = [("status", C.c_int32), ("n_unique", C.c_int64), ("n_dense", C.c_int64), ("n_kept_voxels", C.c_int64),
+                ("kept_clusters", C.c_int64), ("largest", C.c_int64)]
+
+
+DENSITY_OK, DENSITY_EMPTY, DENSITY_HOST = range(3)
 SLAB_OK, SLAB_EMPTY, SLAB_NONFINITE, SLAB_SMALL_SHARD, SLAB_NO_STRUCTURE = range(5)
 COMM_F32_MAX, COMM_F32_SUM, COMM_I64_SUM, COMM_F64_MAX, COMM_I64_MIN = range(5)
 
@@ -145,6 +152,7 @@ SIGNATURES = {
     "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
+    "gsx_density_filter_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I, _P, _P, C.POINTER(DensityInfo)]),
     "gsx_density_hist_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, C.POINTER(_I64), _P, _P]),
     "gsx_density_merge_dev": (_I, [_P, _P, _P, _I64, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
@@ -805,6 +813,7 @@ class DeviceChain:
         self.empty = False                  # keep_none(): no survivor, whatever self.orig says
         self.mask = self.ctx.alloc(self.n0 + 16)
         self._md = self._st = None          # SOR work buffers (mean distances, statistics), allocated on first use
+        self._box = None                    # box of the uploaded rows (lazily; a superset of every later state of the chain)
 
     def restart(self):
         """back to the state right after the upload (needs keep_pristine): device-to-device copy, identity survivor list"""
@@ -842,6 +851,23 @@ class DeviceChain:
                                                   C.byref(nu), C.byref(nd), keys.ctypes.data, counts.ctypes.data), "gsx_density_voxels_dev")
         m = int(nd.value)
         return {"n_unique": int(nu.value), "dense_keys": keys[:m].copy(), "dense_counts": counts[:m].copy()}
+
+    def density_filter(self, voxel_size: float, min_points: int, keep_multicluster: bool):
+        """the whole density filter on the device (gsx_density_filter_dev) -> dict(status, n_unique, kept_clusters, largest,
+        left: rows after the compaction) ; status DENSITY_HOST: nothing was applied, take the host path"""
+        if self._box is None:     # box of the rows this chain started from: a superset of whatever survives later filters
+            lo, hi = self.bbox()
+            self._box = np.array(list(lo) + list(hi), dtype=np.float32)
+        info = DensityInfo()
+        x, y, z, st = self._xyz()
+        check(self.ctx.lib.gsx_density_filter_dev(self.ctx.handle, x, y, z, st, self.n, float(voxel_size), int(min_points),
+                                                  1 if keep_multicluster else 0, self._box.ctypes.data, self.mask.ptr, C.byref(info)),
+              "gsx_density_filter_dev")
+        out = {"status": int(info.status), "n_unique": int(info.n_unique), "kept_clusters": int(info.kept_clusters),
+               "largest": int(info.largest), "left": None}
+        if info.status == DENSITY_OK:
+            out["left"] = self._compact()
+        return out
 
     def _compact(self) -> int:
         out = self._pool.pop() if self._pool else self.ctx.alloc(4 * self.n0 + 16)

@@ -93,6 +93,8 @@ int density_voxels_dev(gsx_ctx *, const float *, const float *, const float *, i
 int density_hist_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int64_t *, int64_t *,
                      int64_t *);
 int density_merge_dev(gsx_ctx *, const int64_t *, const int64_t *, int64_t, int64_t, int64_t, int64_t *, int64_t *, int64_t *, int64_t *);
+int density_filter_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, int64_t, int, const float *,
+                       uint8_t *, gsx_density_info *);
 int density_mask_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, const int64_t *,
                      int64_t, uint8_t *);
 int kmeans_lloyd_dev(gsx_ctx *, const float *, int64_t, int, int, int, float *, int32_t *);
@@ -495,6 +497,15 @@ int gsx_density_merge_dev(gsx_ctx *c, const int64_t *keys3_dev, const int64_t *c
     GSX_HIP(hipSetDevice(c->device));
     return density_merge_dev(c, keys3_dev, counts_dev, m, min_points, dense_cap, n_unique_out, n_dense_out, dense_keys_out,
                              dense_counts_out);
+}
+
+int gsx_density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                           int64_t min_points, int keep_multicluster, const float *box6, uint8_t *mask_out_dev, gsx_density_info *info)
+{
+    if (!c || !x || !y || !z || !mask_out_dev || !info) GSX_FAIL("gsx_density_filter_dev: null argument");
+    if (n <= 0) GSX_FAIL("gsx_density_filter_dev: empty cloud");
+    GSX_HIP(hipSetDevice(c->device));
+    return density_filter_dev(c, x, y, z, stride, n, voxel_size, min_points, keep_multicluster, box6, mask_out_dev, info);
 }
 
 int gsx_density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,

@@ -639,4 +639,296 @@ int density_mask_dev(gsx_ctx *c, const float *x, const float *y, const float *z,
     return 0;
 }
 
+// ---- the whole filter on the device (gsx_density_filter_dev): count -> dense voxels -> 6-connected clusters -> keep rule ->
+// membership mask, with no host round trip in between (data_processor.py:38-114 start to finish).
+// The cluster step is one workgroup: at most n / min_points voxels are dense (<= 1001 for the reference's thresholds,
+// threshold_percentage >= 0.1), so they fit LDS; more than CL_MAX, or a tie for the largest cluster without
+// keep_multicluster (which the reference resolves by the iteration order of a python set), hands the decision to the host
+// path (gsx_density_voxels_dev + processing/clusters.py): status GSX_DENSITY_HOST.
+constexpr int CL_MAX = 1024;
+
+struct ClusterOut {          // device-side result block (gsx_density_info's device half)
+    unsigned n_unique, n_dense, n_kept_voxels, kept_clusters, largest, status;
+};
+
+template <bool WIDE>
+__device__ __forceinline__ bool key_less(unsigned long long a1, unsigned b1, unsigned long long a2, unsigned b2)
+{
+    return a1 < a2 || (WIDE && a1 == a2 && b1 < b2);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void voxel_cluster_kernel(const unsigned long long *__restrict__ okeys, const unsigned *__restrict__ okb,
+                                                            const unsigned *__restrict__ counters /* [0] unique, [1] dense */,
+                                                            unsigned dense_cap, VoxelFrame f, int keep_multi,
+                                                            unsigned long long *__restrict__ kept_a, unsigned *__restrict__ kept_b,
+                                                            ClusterOut *__restrict__ out)
+{
+    __shared__ unsigned long long ka[CL_MAX];
+    __shared__ unsigned kb[WIDE ? CL_MAX : 1];
+    __shared__ unsigned short nb[CL_MAX][6];
+    __shared__ unsigned lab[CL_MAX];
+    __shared__ unsigned siz[CL_MAX];
+    __shared__ unsigned s_scan[256];
+    __shared__ unsigned s_largest, s_ties, s_nkept, s_ncl;
+    const int tid = threadIdx.x;
+    const unsigned D = counters[1];
+    if (tid == 0) {
+        out->n_unique = counters[0];
+        out->n_dense = D;
+        out->n_kept_voxels = 0;
+        out->kept_clusters = 0;
+        out->largest = 0;
+        out->status = D == 0 ? 1u : ((D > (unsigned)CL_MAX || D > dense_cap) ? 2u : 0u);
+    }
+    if (D == 0 || D > (unsigned)CL_MAX || D > dense_cap) return;
+    // ---- sorted keys (np.unique's row order; the mask kernel's binary search needs it too): bitonic sort, padded with max keys
+    int P = 1;
+    while (P < (int)D) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        ka[i] = i < (int)D ? okeys[i] : ~0ull;
+        if (WIDE) kb[i] = i < (int)D ? okb[i] : ~0u;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k2) == 0;
+                    const unsigned long long a1 = ka[i], a2 = ka[l];
+                    const unsigned b1 = WIDE ? kb[i] : 0u, b2 = WIDE ? kb[l] : 0u;
+                    if (key_less<WIDE>(a2, b2, a1, b1) == up) {
+                        ka[i] = a2;
+                        ka[l] = a1;
+                        if (WIDE) {
+                            kb[i] = b2;
+                            kb[l] = b1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- the six face neighbours of every dense voxel (data_processor.py:67-68), by binary search
+    for (int i = tid; i < (int)D; i += 256) {
+        const unsigned long long k = ka[i] - 1ull;
+        long long c[3];
+        if (WIDE) {
+            c[0] = (long long)(k >> 32);
+            c[1] = (long long)(k & 0xffffffffull);
+            c[2] = (long long)(kb[i] - 1u);
+        } else {
+            c[0] = (long long)(k >> 42);
+            c[1] = (long long)((k >> 21) & 0x1fffff);
+            c[2] = (long long)(k & 0x1fffff);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            long long t[3] = {c[0], c[1], c[2]};
+            t[q >> 1] += (q & 1) ? 1 : -1;
+            unsigned short found = 0xffff;
+            if (t[q >> 1] >= 0 && t[q >> 1] < (long long)f.dim[q >> 1]) {
+                unsigned long long na;
+                unsigned nbb = 0u;
+                if (WIDE) {
+                    na = (((unsigned long long)t[0] << 32) | (unsigned long long)t[1]) + 1ull;
+                    nbb = (unsigned)t[2] + 1u;
+                } else {
+                    na = (((unsigned long long)t[0] << 42) | ((unsigned long long)t[1] << 21) | (unsigned long long)t[2]) + 1ull;
+                }
+                int lo = 0, hi = (int)D;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (key_less<WIDE>(ka[mid], WIDE ? kb[mid] : 0u, na, nbb)) lo = mid + 1; else hi = mid;
+                }
+                if (lo < (int)D && ka[lo] == na && (!WIDE || kb[lo] == nbb)) found = (unsigned short)lo;
+            }
+            nb[i][q] = found;
+        }
+        lab[i] = (unsigned)i;
+        siz[i] = 0u;
+    }
+    __syncthreads();
+    // ---- connected components: minimum-label propagation + pointer jumping until nothing moves
+    for (;;) {
+        int changed = 0;
+        for (int i = tid; i < (int)D; i += 256) {
+            unsigned m = lab[i];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const unsigned short j = nb[i][q];
+                if (j != 0xffff) m = min(m, lab[j]);
+            }
+            m = min(m, lab[m]);
+            if (m < lab[i]) {
+                atomicMin(&lab[i], m);
+                changed = 1;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = tid; i < (int)D; i += 256) {   // full compression, then the cluster sizes (in voxels: data_processor.py:95)
+        unsigned r = lab[i];
+        while (lab[r] != r) r = lab[r];
+        lab[i] = r;
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)D; i += 256) atomicAdd(&siz[lab[i]], 1u);
+    if (tid == 0) {
+        s_largest = 0;
+        s_ties = 0;
+        s_ncl = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)D; i += 256)
+        if (lab[i] == (unsigned)i) atomicMax(&s_largest, siz[i]);
+    __syncthreads();
+    const unsigned largest = s_largest;
+    for (int i = tid; i < (int)D; i += 256)
+        if (lab[i] == (unsigned)i && siz[i] == largest) atomicAdd(&s_ties, 1u);
+    __syncthreads();
+    if (!keep_multi && s_ties > 1) {   // which of the equally large clusters survives is the reference's set-iteration order
+        if (tid == 0) out->status = 2u;
+        return;
+    }
+    // keep rule (data_processor.py:96-106): all clusters of at least 5 % of the largest, or the largest alone
+    const double floor_sz = keep_multi ? (double)largest * 0.05 : (double)largest;
+    for (int i = tid; i < (int)D; i += 256)
+        if (lab[i] == (unsigned)i && (double)siz[i] >= floor_sz) atomicAdd(&s_ncl, 1u);
+    // ---- the kept voxels, still sorted: block scan of the keep flags
+    const int per = (P + 255) / 256;
+    unsigned mine = 0;
+    for (int u = 0; u < per; ++u) {
+        const int i = tid * per + u;
+        if (i < (int)D && (double)siz[lab[i]] >= floor_sz) ++mine;
+    }
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    unsigned at = s_scan[tid] - mine;
+    for (int u = 0; u < per; ++u) {
+        const int i = tid * per + u;
+        if (i < (int)D && (double)siz[lab[i]] >= floor_sz) {
+            kept_a[at] = ka[i];
+            if (WIDE) kept_b[at] = kb[i];
+            ++at;
+        }
+    }
+    if (tid == 255) s_nkept = s_scan[255];
+    __syncthreads();
+    if (tid == 0) {
+        out->n_kept_voxels = s_nkept;
+        out->kept_clusters = s_ncl;
+        out->largest = largest;
+        out->status = s_nkept ? 0u : 1u;
+    }
+}
+
+// membership against the kept list the cluster kernel left on the device (its length included)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void voxel_mask_dev_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, int64_t stride, int64_t n, float voxel,
+                                                             VoxelFrame f, const unsigned long long *__restrict__ kept,
+                                                             const unsigned *__restrict__ kept_b, const ClusterOut *__restrict__ co,
+                                                             uint8_t *__restrict__ mask)
+{
+    __shared__ unsigned long long lk[CL_MAX];
+    __shared__ unsigned lkb[WIDE ? CL_MAX : 1];
+    const int n_kept = co->status == 0u ? (int)co->n_kept_voxels : 0;
+    for (int i = threadIdx.x; i < n_kept; i += 256) {
+        lk[i] = kept[i];
+        if (WIDE) lkb[i] = kept_b[i];
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const VKey key = pack_key<WIDE>(f, voxel_key(x[i * stride], voxel), voxel_key(y[i * stride], voxel), voxel_key(z[i * stride], voxel));
+        int lo = 0, hi = n_kept;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (key_less<WIDE>(lk[mid], WIDE ? lkb[mid] : 0u, key.a, key.b)) lo = mid + 1; else hi = mid;
+        }
+        mask[i] = (lo < n_kept && lk[lo] == key.a && (!WIDE || lkb[lo] == key.b)) ? 1 : 0;
+    }
+}
+
+// box6 (host, nullable): per-axis minima then maxima of a SUPERSET of the rows (e.g. the box of the table the rows were
+// filtered from) -- the key frame then needs no pass over the rows and no synchronisation
+int density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
+                       int64_t min_points, int keep_multi, const float *box6, uint8_t *mask_dev, gsx_density_info *info)
+{
+    const float voxel = (float)voxel_size;
+    if (!(voxel > 0.0f)) GSX_FAIL("density: voxel_size must be > 0");
+    GSX_CHECK(timing_begin(c, GSX_T_DENSITY));
+    GSX_CHECK(c->scratch5.reserve(sizeof(VoxelFrame) + sizeof(ClusterOut) + 64));
+    VoxelFrame *dvf = c->scratch5.as<VoxelFrame>();
+    ClusterOut *dco = reinterpret_cast<ClusterOut *>(c->scratch5.as<char>() + 64);
+    VoxelFrame hvf;
+    bool from_box = box6 != nullptr;
+    if (from_box) {
+        hvf.ok = 1;
+        hvf.pad = 0;
+        for (int a = 0; a < 3; ++a) {   // voxel_frame_kernel's arithmetic (IEEE binary32 divide + floor) on the host
+            float lo = floorf(box6[a] / voxel), hi = floorf(box6[3 + a] / voxel);
+            // a superset box may reach where the rows themselves no longer do (far floaters an earlier filter removed):
+            // out of the key range, or wide for nothing -> the frame of the rows themselves, below
+            if (!(fabsf(lo) < 1.0e9f) || !(fabsf(hi) < 1.0e9f) || !(box6[a] <= box6[3 + a])) {
+                from_box = false;
+                break;
+            }
+            const long long d = (long long)hi - (long long)lo + 1;
+            if (d > (1 << 21) - 1) from_box = false;
+            hvf.kmin[a] = (int)lo;
+            hvf.dim[a] = (int)d;
+        }
+    }
+    if (from_box)
+        GSX_HIP(hipMemcpyAsync(dvf, &hvf, sizeof(hvf), hipMemcpyHostToDevice, c->stream));
+    else
+        GSX_CHECK(compute_frame(c, x, y, z, stride, n, voxel, dvf, &hvf));
+    VoxTable t;
+    const int64_t dense_cap = std::min<int64_t>(n, n / std::max<int64_t>(min_points, 1) + 1);
+    const size_t cap = (size_t)std::max<int64_t>(std::min<int64_t>(dense_cap, CL_MAX + 1), 1);
+    GSX_CHECK(alloc_table(c, hvf, n, 16 * cap + 64 + 12 * (size_t)CL_MAX + 64, &t));
+    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t));
+    unsigned long long *okeys = reinterpret_cast<unsigned long long *>(t.out_base);
+    unsigned *ocnt = reinterpret_cast<unsigned *>(t.out_base + sizeof(unsigned long long) * cap);
+    unsigned *okb = ocnt + cap;
+    unsigned *ctr = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(okb + cap) + 15) & ~(uintptr_t)15);
+    unsigned long long *kept_a = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctr) + 32);
+    unsigned *kept_b = reinterpret_cast<unsigned *>(kept_a + CL_MAX);
+    GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
+    const unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
+    hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)t.tsize, 1024)), dim3(256), 0, c->stream, t.tkeys, t.tkb,
+                       t.tcnt, (unsigned)t.tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
+    if (t.wide) {
+        hipLaunchKernelGGL((voxel_cluster_kernel<true>), dim3(1), dim3(256), 0, c->stream, okeys, okb, ctr, (unsigned)cap, hvf, keep_multi,
+                           kept_a, kept_b, dco);
+        hipLaunchKernelGGL((voxel_mask_dev_kernel<true>), dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
+                           hvf, kept_a, kept_b, dco, mask_dev);
+    } else {
+        hipLaunchKernelGGL((voxel_cluster_kernel<false>), dim3(1), dim3(256), 0, c->stream, okeys, okb, ctr, (unsigned)cap, hvf, keep_multi,
+                           kept_a, kept_b, dco);
+        hipLaunchKernelGGL((voxel_mask_dev_kernel<false>), dim3(blocks_for(c, n, 1024)), dim3(256), 0, c->stream, x, y, z, stride, n, voxel,
+                           hvf, kept_a, kept_b, dco, mask_dev);
+    }
+    GSX_HIP(hipGetLastError());
+    GSX_CHECK(timing_end(c, GSX_T_DENSITY));
+    ClusterOut h;
+    GSX_HIP(hipMemcpyAsync(&h, dco, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));      // the call's one synchronisation
+    info->status = (int32_t)h.status;
+    info->n_unique = h.n_unique;
+    info->n_dense = h.n_dense;
+    info->n_kept_voxels = h.n_kept_voxels;
+    info->kept_clusters = h.kept_clusters;
+    info->largest = h.largest;
+    return 0;
+}
+
 }  // namespace gsx

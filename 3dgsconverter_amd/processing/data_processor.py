@@ -203,6 +203,19 @@ class DataProcessor:
         ch = self._chain_for(self._data)
         n = ch.n
         min_points = int(n * (threshold_percentage / 100.0))  # reference :48
+        # the whole filter in one device call (occupancy, clusters of the dense voxels, keep rule, mask, compaction); only a
+        # tie for the largest cluster -- the reference's set-iteration order decides it -- or > 1024 dense voxels come back
+        # undecided and take the steps below
+        res = ch.density_filter(float(voxel_size), min_points, bool(keep_multicluster))
+        if res["status"] != _lib.DENSITY_HOST:
+            debug_print(f"[DEBUG] Found {res['n_unique']} unique voxels.")
+            if res["status"] == _lib.DENSITY_EMPTY:
+                status_print("Warning: Density filter removed all points.")
+                ch.keep_none()
+                return None
+            status_print(f"Density Filter: Kept {res['kept_clusters']} clusters (largest: {res['largest']} voxels).")
+            status_print(f"After density filter, retained {res['left']} out of {n} vertices.")
+            return None
         occ = ch.density_voxels(float(voxel_size), min_points)
         debug_print(f"[DEBUG] Found {occ['n_unique']} unique voxels.")
         if len(occ["dense_keys"]) == 0:

@@ -273,7 +273,8 @@ def run_host_to_host(L, xyz_host, k, sigma, reps=3):
 def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup, cpu=False):
     """BASELINE.json configs[2]: density filter -> SOR on rows that stay in HBM (what ChainedDataProcessor does between
     `DataProcessor(data)` and `.data`; converter.py:205-236 order).  One step = restore the pristine rows (device copy),
-    voxel occupancy, host cluster selection (<= 181 dense voxels), membership mask + compaction, SOR + compaction."""
+    the density filter as one device call (voxel occupancy, clusters of the <= 181 dense voxels, keep rule, membership mask)
+    + compaction, SOR + compaction.  The box of the uploaded rows is computed once per chain (DeviceChain keeps it)."""
     dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
     clusters = importlib.import_module("3dgsconverter_amd.processing.clusters")
     voxel, thr = dp.density_params_from_sensitivity(sensitivity)
@@ -284,10 +285,13 @@ def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup
     def step():
         ch.restart()
         min_points = int(ch.n * (thr / 100.0))
-        occ = ch.density_voxels(float(voxel), min_points)
-        comps = clusters.connected_clusters(map(tuple, occ["dense_keys"].tolist()))
-        kept, _, _ = clusters.select_clusters(comps, False)
-        last["after_density"] = ch.density_keep(float(voxel), np.array(sorted(kept), dtype=np.int64).reshape(-1, 3))
+        res = ch.density_filter(float(voxel), min_points, False)     # ONE device call: gsx_density_filter_dev + compaction
+        if res["status"] == L.DENSITY_HOST:   # (a tie for the largest cluster: the drop-in's host steps; not this cloud)
+            occ = ch.density_voxels(float(voxel), min_points)
+            comps = clusters.connected_clusters(map(tuple, occ["dense_keys"].tolist()))
+            kept, _, _ = clusters.select_clusters(comps, False)
+            res = {"left": ch.density_keep(float(voxel), np.array(sorted(kept), dtype=np.int64).reshape(-1, 3))}
+        last["after_density"] = res["left"]
         last["sor"] = ch.sor_keep(k, sigma)
 
     try:
@@ -302,11 +306,11 @@ def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup
                "after_density": int(last["after_density"]), "survivors": int(len(survivors)), "sor_threshold": float(last["sor"]["threshold"]),
                "kernel_ms_per_step": g,
                # density kernels: two passes over the rows (12 B each) + 1 B mask = 25 B/splat
-               "roofline": hbm_roofline("voxel_count + voxel_collect + voxel_mask (density.hip)", 25.0 * n, g["density"],
+               "roofline": hbm_roofline("voxel_count + voxel_cluster + voxel_mask (density.hip: gsx_density_filter_dev)", 25.0 * n, g["density"],
                                         "density stage: 25 algorithmic B/splat over the HIP-event time of its kernels; the SOR stage of "
                                         "this chain has the headline's roofline"),
-               "note": "includes one host round trip per filter (dense-voxel list down, kept-voxel list up; statistics down) and "
-                       "two device compactions; the 248-byte host table is compacted once afterwards, outside this step"}
+               "note": "one host synchronisation per filter (the survivor count of its compaction) and two device compactions; the "
+                       "248-byte host table is compacted once afterwards, outside this step"}
         if cpu:
             # cpu_baseline leg: the reference's apply_density_filter (pure numpy/Python, restated in oracle/density.py) on a
             # bounded sample

@@ -343,6 +343,21 @@ int gsx_density_hist_dev(gsx_ctx *ctx, const float *x, const float *y, const flo
 int gsx_density_merge_dev(gsx_ctx *ctx, const int64_t *keys3_dev, const int64_t *counts_dev, int64_t m, int64_t min_points,
                           int64_t dense_cap, int64_t *n_unique_out, int64_t *n_dense_out, int64_t *dense_keys_out,
                           int64_t *dense_counts_out);
+/* The whole filter on device-resident rows in ONE call (data_processor.py:38-114): occupancy, dense voxels, their
+ * 6-connected clusters (one workgroup: at most n / min_points <= ~1000 voxels are dense), the keep rule (:95-106) and the
+ * membership mask -- one synchronisation, at the end.  box6 (host, nullable): minima then maxima of a superset of the rows
+ * (saves the box pass and its synchronisation).  info->status: GSX_DENSITY_OK (mask_out_dev holds the mask),
+ * GSX_DENSITY_EMPTY (no dense voxel: the filter removes everything, :54-57), GSX_DENSITY_HOST (more than 1024 dense voxels,
+ * or two clusters tie for the largest without keep_multicluster -- which one survives is the reference's python-set
+ * iteration order: decide with gsx_density_voxels_dev + processing/clusters.py + gsx_density_mask_dev). */
+enum { GSX_DENSITY_OK = 0, GSX_DENSITY_EMPTY = 1, GSX_DENSITY_HOST = 2 };
+typedef struct gsx_density_info {
+    int32_t status;
+    int64_t n_unique, n_dense, n_kept_voxels, kept_clusters, largest;
+} gsx_density_info;
+int gsx_density_filter_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
+                           double voxel_size, int64_t min_points, int keep_multicluster, const float *box6,
+                           uint8_t *mask_out_dev, gsx_density_info *info);
 int gsx_density_mask_dev(gsx_ctx *ctx, const float *x, const float *y, const float *z, int64_t stride,
                          int64_t n, double voxel_size, const int64_t *kept_keys, int64_t n_kept,
                          uint8_t *mask_out_dev);

@@ -30,6 +30,9 @@ SOR_LARGE = [
     # BASELINE.json configs[3]: 50M uniform splats, L=10, seed 0, k=32, sigma 1 -- the whole cloud
     # through the reference's own remove_flyers CPU branch (cKDTree over 50M points: minutes, ~15 GB)
     ("sor_u50m_L10_k32_s1", {"kind": "uniform", "n": 50_000_000, "extent": 10.0, "seed": 0}, 32, 1.0),
+    # what SOR exists for, at the bench's size (bench.py configs.floaters_10m; the Morton-tree path): a 10^3 scene + 0.5 %
+    # floaters in a 1000^3 box, k=16 (round 4: the tree path's full mask against a reference run, not against the other GPU path)
+    ("sor_floaters10m_k16_s1", {"kind": "scene_with_floaters", "n": 10_000_000, "seed": 0}, 16, 1.0),
 ]
 # BASELINE.json configs[2]: density sensitivity 0.5 on the same cloud, then SOR k=16 on the survivors
 CHAIN_LARGE = [
