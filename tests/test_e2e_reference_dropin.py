@@ -81,6 +81,25 @@ def dropin(gsx, monkeypatch):
             hits.append(("gsx_density_voxels_dev", self.n, float(voxel_size), int(min_points)))
             return density_voxels(self.xyz, voxel_size, min_points)
 
+        def density_filter(self, voxel_size, min_points, keep_multicluster):
+            """gsx_density_filter_dev: the whole filter in one device call (the oracle, pinned to the reference, stands in)"""
+            from oracle import density as oden
+            hits.append(("gsx_density_filter_dev", self.n, float(voxel_size), int(min_points)))
+            keys = oden.voxel_keys(self.xyz, voxel_size)
+            uniq, inv, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+            dense = uniq[counts >= min_points]
+            out = {"status": 0, "n_unique": len(uniq), "kept_clusters": 0, "largest": 0, "left": None}
+            if len(dense) == 0:
+                out["status"] = 1
+                return out
+            import importlib
+            cl = importlib.import_module("3dgsconverter_amd.processing.clusters")
+            comps = cl.connected_clusters(map(tuple, dense.tolist()))
+            kept, out["kept_clusters"], out["largest"] = cl.select_clusters(comps, keep_multicluster)
+            mask = np.fromiter((tuple(k) in kept for k in keys.tolist()), dtype=bool, count=len(keys))
+            out["left"] = self._keep(mask)
+            return out
+
         def _keep(self, mask):
             self.xyz, self.idx = self.xyz[mask], self.idx[mask]
             self.n = len(self.idx)
@@ -230,8 +249,7 @@ def test_converter_run_density_flag_goes_through_the_dropin(tmp_path, gsx, dropi
     assert issubclass(conv.DataProcessor, gsx.DataProcessor)
     got = _run(tmp_path, inp, "dropin", density_sensitivity=0.3)
     # install() binds the chained class: one upload, the filters' device entry points, one compaction at `.data`
-    assert [h[0] for h in dropin if h[0] not in ("gsx_density_voxels", "gsx_density_mask")] == \
-        ["DeviceChain", "gsx_density_voxels_dev", "gsx_density_mask_dev"]   # (the fake chain reuses the fake host entries)
+    assert [h[0] for h in dropin] == ["DeviceChain", "gsx_density_filter_dev"]   # the whole filter: ONE device call
     gsx.uninstall()
     assert not issubclass(conv.DataProcessor, gsx.DataProcessor)
     want = _run(tmp_path, inp, "reference", density_sensitivity=0.3)
@@ -300,9 +318,8 @@ def test_converter_run_all_four_filters_are_one_chain(tmp_path, gsx, dropin):
     inp, _ = _write_input(tmp_path)
     box = (-2.5, -3.0, -2.0, 3.0, 2.75, 2.2)
     got = _run(tmp_path, inp, "dropin", bbox=box, min_opacity=40, density_sensitivity=0.3, sor_k=10.0, sor_sigma=1.0)
-    names = [h[0] for h in dropin if h[0] not in ("gsx_density_voxels", "gsx_density_mask")]
-    assert names == ["DeviceChain", "gsx_mask_bbox_dev", "gsx_mask_ge_dev", "gsx_density_voxels_dev", "gsx_density_mask_dev",
-                     "gsx_sor_knn_dev"]
+    names = [h[0] for h in dropin]
+    assert names == ["DeviceChain", "gsx_mask_bbox_dev", "gsx_mask_ge_dev", "gsx_density_filter_dev", "gsx_sor_knn_dev"]
     gsx.uninstall()
     pre = _run(tmp_path, inp, "reference_pre", bbox=box, min_opacity=40, density_sensitivity=0.3)
     assert 0 < len(pre) < 6000 and len(pre) == dropin[-1][1]
@@ -324,7 +341,7 @@ def test_converter_run_sh_cap_and_rgb_are_the_dropins_own(tmp_path, gsx, dropin)
     del dropin[:]
     got_f = _run(tmp_path, inp, "dropin_f", sh_level=0, rgb=True, density_sensitivity=0.3, auto_bbox=True)
     assert [h[0] for h in dropin if h[0].endswith("_dev") or "rgb" in h[0]] == \
-        ["gsx_density_voxels_dev", "gsx_density_mask_dev", "gsx_slab_bbox_dev"] + ["gsx_rgb_from_sh"] * 3
+        ["gsx_density_filter_dev", "gsx_slab_bbox_dev"] + ["gsx_rgb_from_sh"] * 3
     gsx.uninstall()
     want = _run(tmp_path, inp, "reference", sh_level=1, rgb=True, auto_bbox=True)
     zero_cols = int((want.filter(regex="_sh").abs().sum() == 0).sum())     # the parquet codec's r/g/b_sh* columns
