@@ -255,6 +255,76 @@ __global__ __launch_bounds__(64) void kmeans_centroid_operands_kernel(const floa
     opnd[((size_t)(t * NS + j) * 2 + 1) * 64 + lane] = lo;
 }
 
+// Round 4: the END of one iteration and the START of the next in one launch (formerly finalize_reset, a 64-byte memset and
+// centroid_operands: three of the ~9 launches of a SOG chunk iteration, each a few latency-bound microseconds).  Block
+// (tile t, slice j), lane l owns the 8 dimensions k0 .. k0+7 of centroid 32 t + (l & 31) -- every (centroid, dimension) has
+// exactly one owner, which divides the float64 sum (gpu_ops.py:91-96), writes the centroid and turns it into operand words
+// with kmeans_centroid_operands_kernel's arithmetic; |c|^2 is recomputed by every lane from all D sums of its centroid
+// (the same expression, so the same bits).  The accumulators are NOT re-zeroed here (other blocks still read them): the
+// label scatter zeroes the sums and the exact-list kernel the counts of the NEXT iteration.  meta_next[0] receives
+// max |c|^2 (zeroed two iterations ago), meta_done (this iteration's list length, ticket, ...) is zeroed for the one after.
+template <int D>
+__global__ __launch_bounds__(64) void kmeans_finalize_operands_kernel(const double *__restrict__ sums, const unsigned *__restrict__ counts,
+                                                                      int k, float *__restrict__ cent, ku32x4 *__restrict__ opnd,
+                                                                      unsigned *__restrict__ meta_next, unsigned *__restrict__ meta_done)
+{
+    constexpr int DP = km_dp(D), NS = DP / 16;
+    const int t = blockIdx.x / NS, j = blockIdx.x % NS;
+    const int lane = threadIdx.x;
+    const int c = 32 * t + (lane & 31), k0 = 16 * j + 8 * (lane >> 5);
+    if (blockIdx.x == 0 && lane < 16) meta_done[lane] = 0u;
+    float v[8];
+    float n2 = 0.0f;
+    float inv = 0.0f;
+    bool live = false;
+    if (c < k) {
+        const unsigned cnt = counts[c];
+        live = cnt > 0;
+        inv = live ? 1.0f / (float)cnt : 0.0f;
+        double sv[D];   // all D loads in flight (a rolled loop made this one-wave-per-block kernel 15 us: latency)
+#pragma unroll
+        for (int d = 0; d < D; ++d) sv[d] = sums[(int64_t)c * D + d];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float cv = live ? (float)sv[d] * inv : 0.0f;   // empty cluster -> 0 (gpu_ops.py:78-96)
+            n2 = __builtin_fmaf(cv, cv, n2);
+        }
+        if (j == 0 && lane < 32) atomicMax(reinterpret_cast<int *>(meta_next), __float_as_int(n2));  // n2 >= 0: int order = float order
+    } else {
+        n2 = 1.0e30f;  // padding rows never win
+    }
+    const unsigned p1 = km_cvt_pk_bf16(n2, n2);
+    const float r1 = n2 - km_bf_lo(p1);
+    const unsigned p2 = km_cvt_pk_bf16(r1, r1);
+    const float r2 = r1 - km_bf_lo(p2);
+    bool norm_slot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int d = k0 + i;
+        norm_slot[i] = d >= D && d < D + 3;
+        float cv = 0.0f;
+        if (c < k && d < D) {
+            cv = live ? (float)sums[(int64_t)c * D + d] * inv : 0.0f;
+            cent[(int64_t)c * D + d] = cv;
+        }
+        v[i] = -2.0f * cv;
+    }
+    ku32x4 hi, lo;
+    km_split8(v, hi, lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (norm_slot[i]) {
+            const int piece = k0 + i - D;
+            const float val = piece == 0 ? km_bf_lo(p1) : (piece == 1 ? km_bf_lo(p2) : r2);
+            const unsigned bits = km_cvt_pk_bf16(val, val) & 0xffffu;
+            const int w = i >> 1, sh = (i & 1) * 16;
+            hi[w] = (hi[w] & ~(0xffffu << sh)) | (bits << sh);
+            lo[w] = lo[w] & ~(0xffffu << sh);
+        }
+    opnd[((size_t)(t * NS + j) * 2 + 0) * 64 + lane] = hi;
+    opnd[((size_t)(t * NS + j) * 2 + 1) * 64 + lane] = lo;
+}
+
 constexpr int KM_MF_WAVES = 4;
 constexpr int KM_MF_PT = 1;                          // 32-point tiles per wave (SOG chunk: 53 us with 1, 59 with 2, 61 with 3)
 constexpr int KM_MF_TILE = KM_MF_WAVES * KM_MF_PT * 32;  // points per workgroup
@@ -425,19 +495,26 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
                                                                        const float *__restrict__ cent, int k,
                                                                        const unsigned *__restrict__ list,
                                                                        const unsigned *__restrict__ list_count,
-                                                                       int32_t *__restrict__ labels)
+                                                                       int32_t *__restrict__ labels,
+                                                                       unsigned *__restrict__ zero_counts /* nullable: k words to clear */)
 {
-    const int lane = threadIdx.x & 63;
-    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    if (zero_counts)   // the label histogram that follows accumulates into these (round 4: nobody else re-zeroes them)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < k; i += gridDim.x * 256) zero_counts[i] = 0u;
+    // round 4: one WORKGROUP per point, its four waves take every fourth 64-centroid stripe (a point is a latency chain of
+    // K / 64 row fetches per lane -- 16 at K = 1024 -- and the list holds fewer points than the chip has workgroups:
+    // 15 -> ~5 us per SOG chunk iteration); the four partial winners meet in LDS, lowest index on ties
+    __shared__ float s_best[4];
+    __shared__ int s_bi[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned cnt = *list_count;
-    for (unsigned it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < cnt; it += nwaves) {
+    for (unsigned it = blockIdx.x; it < cnt; it += gridDim.x) {
         const int64_t i = list[it];
         float x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = data[i * D + d];
         float best = 1e20f;  // gpu_ops.py:60
         int bi = -1;
-        for (int c = lane; c < k; c += 64) {
+        for (int c = wv * 64 + lane; c < k; c += 256) {
             const float *__restrict__ cc = cent + (int64_t)c * D;
             float cv[D];
 #pragma unroll
@@ -462,7 +539,23 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
             best = take ? ob : best;
             bi = take ? oi : bi;
         }
-        if (lane == 0) labels[i] = bi;
+        if (lane == 0) {
+            s_best[wv] = best;
+            s_bi[wv] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float ob = s_best[w];
+                const int oi = s_bi[w];
+                const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+                best = take ? ob : best;
+                bi = take ? oi : bi;
+            }
+            labels[i] = bi;
+        }
+        __syncthreads();
     }
 }
 
@@ -470,8 +563,43 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
 // labels -> counts[K] (LDS-aggregated histogram) -> exclusive scan -> point indices grouped by label -> one wave per
 // centroid sums its rows (lanes = dimensions, rows read coalesced) in float64 and divides: no per-element atomics, no
 // sums buffer, no separate finalize.  Points with label -1 (unassignable) belong to no cluster.
+// starts[c] = exclusive scan of counts; cursor[c] = starts[c] -- by ONE workgroup of 256 threads (every thread must call)
+__device__ __forceinline__ void kmeans_label_scan_body(const unsigned *__restrict__ counts, int k, unsigned *__restrict__ starts,
+                                                       unsigned *__restrict__ cursor)
+{
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b = 0; b < k; b += 256) {
+        const int i = b + threadIdx.x;
+        // (written by other workgroups' atomics: device-scope loads)
+        const unsigned v = i < k ? __hip_atomic_load(&counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off);
+            if ((int)(threadIdx.x & 63) >= off) inc += o;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned pre = s_carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s_w[w];
+        if (i < k) {
+            starts[i] = pre + inc - v;
+            cursor[i] = pre + inc - v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = pre + inc;
+        __syncthreads();
+    }
+}
+
+// histogram of the labels; the LAST workgroup to arrive (ticket, self-resetting) scans it -- formerly a one-workgroup
+// launch of its own, 4.6 of the ~120 us of a SOG chunk iteration
 __global__ __launch_bounds__(256) void kmeans_label_hist_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
-                                                                unsigned *__restrict__ counts)
+                                                                unsigned *__restrict__ counts, unsigned *__restrict__ ticket,
+                                                                unsigned *__restrict__ starts, unsigned *__restrict__ cursor)
 {
     extern __shared__ unsigned s_h[];
     const bool use_lds = k <= 8192;
@@ -488,44 +616,24 @@ __global__ __launch_bounds__(256) void kmeans_label_hist_kernel(const int32_t *_
         for (int i = threadIdx.x; i < k; i += 256)
             if (s_h[i]) atomicAdd(&counts[i], s_h[i]);
     }
-}
-
-// starts[c] = exclusive scan of counts; cursor[c] = starts[c] (one workgroup)
-__global__ __launch_bounds__(1024) void kmeans_label_scan_kernel(const unsigned *__restrict__ counts, int k,
-                                                                 unsigned *__restrict__ starts, unsigned *__restrict__ cursor)
-{
-    __shared__ unsigned s_w[16];
-    __shared__ unsigned s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_s_waitcnt(0);   // this workgroup's device-scope atomics have completed before the ticket
     __syncthreads();
-    for (int b = 0; b < k; b += 1024) {
-        const int i = b + threadIdx.x;
-        const unsigned v = i < k ? counts[i] : 0u;
-        unsigned inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned o = __shfl_up(inc, off);
-            if ((int)(threadIdx.x & 63) >= off) inc += o;
-        }
-        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        unsigned pre = s_carry;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s_w[w];
-        if (i < k) {
-            starts[i] = pre + inc - v;
-            cursor[i] = pre + inc - v;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = pre + inc;
-        __syncthreads();
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *ticket = 0;
+    kmeans_label_scan_body(counts, k, starts, cursor);
 }
 
 // point indices grouped by label.  Per 2048-point tile: LDS ranks (returning atomics), ONE global atomic per (tile, label)
 // reserves the run -- a global atomic per point serialises on the K cursors (35 us per SOG chunk)
 __global__ __launch_bounds__(256) void kmeans_label_scatter_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
-                                                                   unsigned *__restrict__ cursor, unsigned *__restrict__ perm)
+                                                                   unsigned *__restrict__ cursor, unsigned *__restrict__ perm,
+                                                                   double *__restrict__ zero_sums, int64_t n_sums)
 {
+    if (zero_sums)     // the segmented sums that follow accumulate into these (round 4: finalize no longer re-zeroes them)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_sums; i += (int64_t)gridDim.x * 256) zero_sums[i] = 0.0;
     extern __shared__ unsigned s_h[];   // [k] counts, then [k] run bases (k <= 8192)
     unsigned *s_b = s_h + k;
     const bool use_lds = k <= 8192;
@@ -604,6 +712,7 @@ __global__ __launch_bounds__(256) void kmeans_centroid_reduce_kernel(const float
 // to the cluster's accumulators when the label changes: perfectly balanced whatever the cluster sizes are (one workgroup
 // per centroid, above, runs as long as its largest cluster and reads through one CU), ~2 x 45 float64 atomics per wave.
 // kmeans_finalize_reset_kernel divides and re-zeroes.
+template <int ROWS>   // consecutive entries of the permutation per wave: 64, 32 or 16 (fewer rows = more waves to hide the gathers behind)
 __global__ __launch_bounds__(256) void kmeans_segment_sum_kernel(const float *__restrict__ data, int D,
                                                                  const unsigned *__restrict__ perm,
                                                                  const unsigned *__restrict__ starts,
@@ -613,22 +722,23 @@ __global__ __launch_bounds__(256) void kmeans_segment_sum_kernel(const float *__
     const int64_t n = (int64_t)starts[k - 1] + counts[k - 1];   // rows with a label (unassignable rows are not in the permutation)
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w * 64 < n; w += nw) {
-        const int64_t j0 = w * 64;
-        const int m = (int)((n - j0) < 64 ? (n - j0) : 64);
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w * ROWS < n; w += nw) {
+        const int64_t j0 = w * ROWS;
+        const int m = (int)((n - j0) < ROWS ? (n - j0) : ROWS);
         const unsigned my_row = lane < m ? perm[j0 + lane] : 0u;
         const int my_lab = lane < m ? labels[my_row] : -1;
         int cur = __builtin_amdgcn_readfirstlane(my_lab);
         double acc = 0.0;
-        for (int i0 = 0; i0 < m; i0 += 16) {
-            float v[16];
+        constexpr int HB = ROWS < 16 ? ROWS : 16;   // row loads in flight per lane (32: no faster)
+        for (int i0 = 0; i0 < m; i0 += HB) {
+            float v[HB];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const unsigned row = (unsigned)__shfl((int)my_row, (i0 + u) & 63);
                 v[u] = (i0 + u < m && lane < D) ? data[(int64_t)row * D + lane] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 if (i0 + u < m) {   // wave-uniform
                     const int lab = __shfl(my_lab, (i0 + u) & 63);
                     if (lab != cur) {
@@ -751,19 +861,26 @@ static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const floa
 
 template <int D>
 static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float *cent, int k, int32_t *labels, double *sums,
-                                unsigned *counts)
+                                unsigned *counts, int it)
 {
     constexpr int NS = km_dp(D) / 16;
     const int ktiles = (k + 31) / 32;
     const size_t opnd_bytes = sizeof(ku32x4) * (size_t)ktiles * NS * 2 * 64;
-    // operand words | meta (16 words) | uncertain list / permutation (n words) | starts (k) | cursor (k)
-    GSX_CHECK(c->scratch5.reserve(opnd_bytes + sizeof(unsigned) * (size_t)(16 + n + 2 * (size_t)k + 16)));
+    // operand words | meta (2 x 16 words, alternating by iteration) | uncertain list / permutation (n words) | starts (k) | cursor (k)
+    GSX_CHECK(c->scratch5.reserve(opnd_bytes + sizeof(unsigned) * (size_t)(32 + n + 2 * (size_t)k + 16)));
     ku32x4 *opnd = c->scratch5.as<ku32x4>();
-    unsigned *meta = reinterpret_cast<unsigned *>(c->scratch5.as<char>() + opnd_bytes);  // [0] = max |c|^2 (float bits), [1] = list length
-    unsigned *list = meta + 16, *starts = list + n, *cursor = starts + k;
-    GSX_HIP(hipMemsetAsync(meta, 0, sizeof(unsigned) * 16, c->stream));
-    hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
-                       reinterpret_cast<float *>(meta));
+    unsigned *meta2 = reinterpret_cast<unsigned *>(c->scratch5.as<char>() + opnd_bytes);
+    unsigned *meta = meta2 + 16 * (it & 1);            // [0] = max |c|^2 (float bits), [1] = list length, [2] = histogram ticket
+    unsigned *meta_next = meta2 + 16 * ((it + 1) & 1);
+    unsigned *list = meta2 + 32, *starts = list + n, *cursor = starts + k;
+    const bool fused_update = D <= 64;                 // (always: D is 9, 24 or 45)
+    if (it == 0 || !fused_update) {
+        // the first iteration's operands come from the caller's centroids; every later one's were written by the
+        // finalize + operands kernel at the end of the iteration before
+        GSX_HIP(hipMemsetAsync(meta2, 0, sizeof(unsigned) * 32, c->stream));
+        hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
+                           reinterpret_cast<float *>(meta));
+    }
     if (c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
         // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h)
         const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)c->num_cu);
@@ -775,22 +892,29 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
         hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
                            reinterpret_cast<const float *>(meta), labels, list, meta + 1);
     }
-    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * 2), dim3(256), 0, c->stream, data, cent, k, list,
-                       meta + 1, labels);
+    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * c->km_exact_blocks), dim3(256), 0, c->stream, data, cent, k, list,
+                       meta + 1, labels, fused_update && it > 0 ? counts : nullptr);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
     GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
     // update (the list is dead now: its storage becomes the permutation)
     const int hb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 4));
     hipLaunchKernelGGL(kmeans_label_hist_kernel, dim3(hb), dim3(256), k <= 8192 ? sizeof(unsigned) * (size_t)k : 0, c->stream, labels, n,
-                       k, counts);
-    hipLaunchKernelGGL(kmeans_label_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, k, starts, cursor);
+                       k, counts, meta + 2, starts, cursor);   // (+ the scan of the counts, in its last workgroup)
     hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
-                       labels, n, k, cursor, list);
-    if (D <= 64) {
-        const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 256), (int64_t)c->num_cu * 8));
-        hipLaunchKernelGGL(kmeans_segment_sum_kernel, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
-        hipLaunchKernelGGL(kmeans_finalize_reset_kernel, dim3(k), dim3(64), 0, c->stream, sums, counts, D, cent);
+                       labels, n, k, cursor, list, fused_update && it > 0 ? sums : nullptr, (int64_t)k * D);
+    if (fused_update) {
+        const int rows = c->km_seg_rows;
+        const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4 * rows), (int64_t)c->num_cu * 8));
+        if (rows == 64)
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<64>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+        else if (rows == 32)
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<32>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+        else
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<16>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+        // finalize + the NEXT iteration's operands + the meta block of the one after, in one launch
+        hipLaunchKernelGGL((kmeans_finalize_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, sums, counts, k, cent, opnd,
+                           meta_next, meta);
     } else {
         hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
     }
@@ -801,16 +925,16 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
 
 // returns 0 and sets *fused when the templated kernel (assign + accumulate in one launch) ran
 static int launch_assign(gsx_ctx *c, const float *data, int64_t n, int d, float *cent, int k, int32_t *labels,
-                         double *sums, unsigned *counts, bool *fused, bool *updated)
+                         double *sums, unsigned *counts, bool *fused, bool *updated, int it)
 {
     *fused = true;
     *updated = false;
     if (c->kmeans_mfma && k >= 64 && (d == 9 || d == 24 || d == 45)) {
         // matrix-core filter + exact certificate (identical labels), update by segmented reduction: the whole iteration
         *updated = true;
-        if (d == 9) return launch_assign_mfma_t<9>(c, data, n, cent, k, labels, sums, counts);
-        if (d == 24) return launch_assign_mfma_t<24>(c, data, n, cent, k, labels, sums, counts);
-        return launch_assign_mfma_t<45>(c, data, n, cent, k, labels, sums, counts);
+        if (d == 9) return launch_assign_mfma_t<9>(c, data, n, cent, k, labels, sums, counts, it);
+        if (d == 24) return launch_assign_mfma_t<24>(c, data, n, cent, k, labels, sums, counts, it);
+        return launch_assign_mfma_t<45>(c, data, n, cent, k, labels, sums, counts, it);
     }
     switch (d) {
         case 1: launch_assign_t<1>(c, data, n, cent, k, labels, sums, counts); break;
@@ -843,7 +967,7 @@ int kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k,
     for (int it = 0; it < max_iter; ++it) {
         bool fused = false, updated = false;
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_ASSIGN));
-        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused, &updated));
+        GSX_CHECK(launch_assign(c, data_dev, n, d, cent_dev, k, labels_dev, sums, counts, &fused, &updated, it));
         if (updated) continue;   // the matrix-core path ran assign AND update (sort-by-label reduction) and closed both timing slots
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
         GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));

@@ -83,14 +83,24 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     float bad = 0.0f;  // fminf/fmaxf drop NaNs silently, so non-finite input is tracked separately
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float v[3] = {x[(int64_t)i * stride], y[(int64_t)i * stride], z[(int64_t)i * stride]};
+    const int step = gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * (int64_t)step) {   // 12 loads in flight per lane
+        float v[4][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = fminf(mn[a], v[a]);
-            mx[a] = fmaxf(mx[a], v[a]);
-            bad = (fabsf(v[a]) < __builtin_inff()) ? bad : 1.0f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = (int64_t)(i0 + u * step < n ? i0 + u * step : i0) * stride;   // (a repeated point changes no extremum)
+            v[u][0] = x[i];
+            v[u][1] = y[i];
+            v[u][2] = z[i];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = fminf(mn[a], v[u][a]);
+                mx[a] = fmaxf(mx[a], v[u][a]);
+                bad = (fabsf(v[u][a]) < __builtin_inff()) ? bad : 1.0f;
+            }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -344,17 +354,17 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const float *__restric
         for (int i = threadIdx.x; i < g.bk_count; i += 256) hist[i] = 0;
         __syncthreads();
         const int lo = t * BIN_TILE, hi = min(n, lo + BIN_TILE);
-        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {   // 4 independent loads in flight per lane
-            float py[4], pz[4];
+        for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 2048) {   // 16 independent loads in flight per lane
+            float py[8], pz[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + 256 * u, hi - 1);
                 const int64_t s = (int64_t)(first + i) * stride;
                 py[u] = y[s];
                 pz[u] = z[s];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
                 if (i0 + 256 * u < hi)
                     atomicAdd(&hist[bucket_of(g, cell_coord(py[u], g.oy, g.inv_h, g.ny), cell_coord(pz[u], g.oz, g.inv_h, g.nz))], 1u);
         }

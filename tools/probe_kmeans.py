@@ -1,5 +1,6 @@
-"""GPU box: BASELINE.json configs[4] (bench.py:run_kmeans) alone on ONE lane, for `rocprofv3 --kernel-trace --stats`
-(the per-kernel averages of a Lloyd iteration; concurrent lanes only change how the kernels overlap)."""
+"""GPU box: BASELINE.json configs[4] (bench.py:run_kmeans) alone, for `rocprofv3 --kernel-trace --stats` (the per-kernel
+averages of a Lloyd iteration on ONE lane; concurrent lanes only change how the kernels overlap) and for A/B runs of library
+knobs:   python tools/probe_kmeans.py [lanes] [name=value ...]"""
 import importlib
 import os
 import sys
@@ -10,5 +11,7 @@ import bench  # noqa: E402
 
 gsx = importlib.import_module("3dgsconverter_amd")
 L = gsx._lib
-r = bench.run_kmeans(L, L.Context(0), gsx, 10_000_000, 2, 1, cpu=False, lanes=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-print(r["ms_per_step"], r["kernel_ms_per_step"])
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+params = [(kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[2:]]
+r = bench.run_kmeans(L, L.Context(0), gsx, 10_000_000, 2, 1, cpu=False, lanes=lanes, params=params)
+print(lanes, params, r["ms_per_step"], r["kernel_ms_per_step"])
