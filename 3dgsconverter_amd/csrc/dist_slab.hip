@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
 
 // returned mean distances arrive in the order the points were sent: out[send_src[p]] = recv[p]
 __global__ __launch_bounds__(256) void slab_unpermute_kernel(const float *__restrict__ recv, const unsigned *__restrict__ send_src,
-                                                             int64_t n, float *__restrict__ out)
+                                                             int64_t n, float *__restrict__ out,
+                                                             const unsigned *__restrict__ cnt_src = nullptr, unsigned *__restrict__ cnt_dst = nullptr)
 {
+    // (fused step: this rank's certificate count rides behind its piece sums in the all-gather that follows)
+    if (cnt_dst && blockIdx.x == 0 && threadIdx.x < 2) cnt_dst[threadIdx.x] = cnt_src[threadIdx.x];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
         out[send_src[p]] = recv[p];
 }
@@ -246,8 +249,14 @@ struct PackPlan {
     int stride;
     int count[SLAB_MAX_RANKS];
 };
-__global__ __launch_bounds__(256) void slab_pack_pieces_kernel(const float *__restrict__ all, PackPlan p, float *__restrict__ out)
+__global__ __launch_bounds__(256) void slab_pack_pieces_kernel(const float *__restrict__ all, PackPlan p, float *__restrict__ out,
+                                                               unsigned long long *__restrict__ cert_total /* nullable */)
 {
+    if (cert_total && blockIdx.x == 0 && threadIdx.x == 0) {   // the ranks' certificate counts sit behind their piece sums
+        unsigned long long t = 0;
+        for (int q = 0; q < p.world; ++q) t += *reinterpret_cast<const unsigned long long *>(all + (size_t)q * p.stride + (p.stride - 2));
+        *cert_total = t;
+    }
     int o = 0;
     for (int q = 0; q < p.world; ++q) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i < p.count[q]; i += gridDim.x * 256) out[o + i] = all[(size_t)q * p.stride + i];
@@ -642,7 +651,8 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
             GSX_HIP(hipGetLastError());
         }
     }
-    if (G > 1) GSX_CHECK(gsx_comm_all_reduce(c, unc, 1, GSX_COMM_I64_SUM));
+    // (G > 1: the count is not all-reduced on its own -- it travels behind this rank's piece sums in the first all-gather of
+    //  the statistics and is summed by the pack kernel: one small collective less per step)
     // ---- 6. mean distances back to the index owners, original order
     GSX_CHECK(w.md.reserve(4 * (size_t)(n_local + 8192 + 4)));
     const float *ret = w.md_slab.as<float>();
@@ -652,11 +662,6 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
         ret = w.ret.as<float>();
     }
     float *md = w.md.as<float>();
-    if (n_local > 0) {
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 1024), (int64_t)c->num_cu * 8));
-        hipLaunchKernelGGL(slab_unpermute_kernel, dim3(blocks), dim3(256), 0, c->stream, ret, w.send_src.as<unsigned>(), n_local, md);
-        GSX_HIP(hipGetLastError());
-    }
     // ---- 7. numpy-exact statistics from 8192-element piece sums (pieces are cut at the true GLOBAL offsets: the
     // < 8192 leading elements of a shard belong to the left neighbour's last piece and are handed over)
     int64_t starts[SLAB_MAX_RANKS + 1], heads[SLAB_MAX_RANKS + 1];
@@ -665,31 +670,6 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     for (int q = 0; q < G; ++q) heads[q] = (8192 - starts[q] % 8192) % 8192;
     heads[G] = 0;
     const int64_t head = heads[r], nxt_head = heads[r + 1];
-    const float *st_in;
-    float *st_tail;
-    if (head % 4 == 0) {
-        st_in = md + head;
-        st_tail = md + n_local;
-    } else {   // piece sums read 16 bytes at a time: an aligned copy (4 B/point, device copy)
-        GSX_CHECK(w.md_stats.reserve(4 * (size_t)(n_local + 8192 + 4)));
-        GSX_HIP(hipMemcpyAsync(w.md_stats.p, md + head, 4 * (size_t)(n_local - head), hipMemcpyDeviceToDevice, c->stream));
-        st_in = w.md_stats.as<float>();
-        st_tail = w.md_stats.as<float>() + (n_local - head);
-    }
-    if (G > 1) {
-        int64_t so[SLAB_MAX_RANKS] = {0}, sc[SLAB_MAX_RANKS] = {0}, ro[SLAB_MAX_RANKS] = {0}, rc[SLAB_MAX_RANKS] = {0};
-        if (r > 0) sc[r - 1] = head;
-        if (r + 1 < G) rc[r + 1] = nxt_head;
-        // (send from md[0..head), receive behind the own elements: st_tail is addressed relative to md / md_stats)
-        if (head % 4 == 0) {
-            for (int q = 0; q < G; ++q) ro[q] = n_local;
-            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, md, 1, so, sc, ro, rc, 4));
-        } else {
-            for (int q = 0; q < G; ++q) ro[q] = n_local - head;
-            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, w.md_stats.p, 1, so, sc, ro, rc, 4));
-        }
-    }
-    (void)st_tail;
     const int64_t n_mine = n_local - head + nxt_head;
     PackPlan pk;
     pk.world = G;
@@ -700,16 +680,47 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
         max_pieces = std::max(max_pieces, pk.count[q]);
         total_pieces += pk.count[q];
     }
-    pk.stride = max_pieces;
-    GSX_CHECK(w.pieces.reserve(4 * (size_t)std::max(max_pieces, 1)));
-    GSX_CHECK(w.allpieces.reserve(4 * (size_t)std::max(max_pieces, 1) * G));
+    // piece buffer: the sums, then 2 words = this rank's certificate count (even offset: 8-byte aligned)
+    const int stride = ((max_pieces + 1) & ~1) + 2;
+    pk.stride = stride;
+    GSX_CHECK(w.pieces.reserve(4 * (size_t)stride));
+    GSX_CHECK(w.allpieces.reserve(4 * (size_t)stride * G));
     GSX_CHECK(w.packed.reserve(4 * (size_t)std::max(total_pieces, 1)));
+    unsigned *unc_total = cursor + 34;
+    if (n_local > 0) {   // (also hands this rank's certificate count to the tail of the piece buffer)
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 1024), (int64_t)c->num_cu * 8));
+        hipLaunchKernelGGL(slab_unpermute_kernel, dim3(blocks), dim3(256), 0, c->stream, ret, w.send_src.as<unsigned>(), n_local, md,
+                           unc, w.pieces.as<unsigned>() + (stride - 2));
+        GSX_HIP(hipGetLastError());
+    }
+    const float *st_in;
+    if (head % 4 == 0) {
+        st_in = md + head;
+    } else {   // piece sums read 16 bytes at a time: an aligned copy (4 B/point, device copy)
+        GSX_CHECK(w.md_stats.reserve(4 * (size_t)(n_local + 8192 + 4)));
+        GSX_HIP(hipMemcpyAsync(w.md_stats.p, md + head, 4 * (size_t)(n_local - head), hipMemcpyDeviceToDevice, c->stream));
+        st_in = w.md_stats.as<float>();
+    }
+    if (G > 1) {
+        int64_t so[SLAB_MAX_RANKS] = {0}, sc[SLAB_MAX_RANKS] = {0}, ro[SLAB_MAX_RANKS] = {0}, rc[SLAB_MAX_RANKS] = {0};
+        if (r > 0) sc[r - 1] = head;
+        if (r + 1 < G) rc[r + 1] = nxt_head;
+        // (send from md[0..head), receive behind the own elements of md / of the aligned copy)
+        if (head % 4 == 0) {
+            for (int q = 0; q < G; ++q) ro[q] = n_local;
+            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, md, 1, so, sc, ro, rc, 4));
+        } else {
+            for (int q = 0; q < G; ++q) ro[q] = n_local - head;
+            GSX_CHECK(gsx_comm_all_to_all_segs(c, md, w.md_stats.p, 1, so, sc, ro, rc, 4));
+        }
+    }
     for (int mode = 0; mode < 2; ++mode) {
         if (n_mine > 0) GSX_CHECK(launch_sor_piece_sums(c, st_in, n_mine, mode ? stats : nullptr, w.pieces.as<float>()));
         const float *pieces = w.pieces.as<float>();
         if (G > 1) {
-            GSX_CHECK(gsx_comm_all_gather(c, w.pieces.p, w.allpieces.p, 4 * (int64_t)max_pieces));
-            hipLaunchKernelGGL(slab_pack_pieces_kernel, dim3(4), dim3(256), 0, c->stream, w.allpieces.as<float>(), pk, w.packed.as<float>());
+            GSX_CHECK(gsx_comm_all_gather(c, w.pieces.p, w.allpieces.p, 4 * (int64_t)stride));
+            hipLaunchKernelGGL(slab_pack_pieces_kernel, dim3(4), dim3(256), 0, c->stream, w.allpieces.as<float>(), pk, w.packed.as<float>(),
+                               mode == 0 ? reinterpret_cast<unsigned long long *>(unc_total) : nullptr);
             GSX_HIP(hipGetLastError());
             pieces = w.packed.as<float>();
         }
@@ -725,7 +736,7 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     out->mask_dev = mask;
     out->mean_dists_dev = md;
     out->stats_dev = stats;
-    out->uncertain_dev = reinterpret_cast<const int64_t *>(unc);
+    out->uncertain_dev = reinterpret_cast<const int64_t *>(G > 1 ? unc_total : unc);
     return 0;
 }
 
