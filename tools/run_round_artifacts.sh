@@ -3,7 +3,7 @@
 # commands, PMC passes (separate passes: TCC FETCH / WRITE, SQ issue counters).  usage: run_round_artifacts.sh r02
 set -u
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -11,6 +11,8 @@ cd $ROOT
 timeout 900 python bench.py > $OUT/bench_${R}_10m.json 2> $OUT/bench_${R}.err
 timeout 600 python bench.py --exchange slab --steps 20 --no-cpu-baseline > $OUT/bench_${R}_slab_1rank.json 2>> $OUT/bench_${R}.err
 timeout 600 python bench.py --n 50000000 --extent 10 --k 32 --steps 10 --no-cpu-baseline --no-secondary > $OUT/bench_${R}_50m_k32.json 2>> $OUT/bench_${R}.err
+# the N-rank code path on this one-GPU box: bench.py starts its own ranks, which share the GPU over the hostwire transport
+timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --n 2000000 --n3 4000000 > $OUT/bench_${R}_gpus2_hostwire.json 2>> $OUT/bench_${R}.err
 cd /tmp
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R} -o trace -- python $ROOT/bench.py $B > $OUT/prof_${R}.log 2>&1
