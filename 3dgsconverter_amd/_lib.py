@@ -78,6 +78,7 @@ SIGNATURES = {
     "gsx_version": (C.c_char_p, []),
     "gsx_last_error": (C.c_char_p, []),
     "gsx_device_count": (_I, []),
+    "gsx_device_uid": (_I, [_I, C.c_char_p, _I]),
     "gsx_ctx_create": (_I, [_I, C.POINTER(_P)]),
     "gsx_ctx_destroy": (None, [_P]),
     "gsx_ctx_set_stream": (_I, [_P, _P]),
@@ -199,6 +200,13 @@ def device_count() -> int:
         return int(load().gsx_device_count())
     except GsxError:
         return 0
+
+
+def device_uid(device: int) -> str:
+    """PCI bus id of a visible device: equal strings <=> the same physical GPU"""
+    buf = C.create_string_buffer(64)
+    check(load().gsx_device_uid(device, buf, 64), "gsx_device_uid")
+    return buf.value.decode()
 
 
 def has_hip() -> bool:

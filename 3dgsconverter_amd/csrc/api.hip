@@ -119,6 +119,16 @@ int gsx_device_count(void)
     return n;
 }
 
+int gsx_device_uid(int device, char *out, int cap)
+{
+    if (!out || cap < 16) GSX_FAIL("gsx_device_uid: need a buffer of at least 16 bytes");
+    if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess) {
+        (void)hipGetLastError();
+        GSX_FAIL("gsx_device_uid: no such device");
+    }
+    return 0;
+}
+
 int gsx_ctx_create(int device, gsx_ctx **out)
 {
     if (!out) GSX_FAIL("gsx_ctx_create: null out");

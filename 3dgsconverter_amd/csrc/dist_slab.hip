@@ -144,8 +144,12 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
                                                              const float *__restrict__ z, int64_t stride, int64_t n,
                                                              SlabPlan plan, unsigned *__restrict__ cursor /* [2*world], zeroed: rows handed out per slot */,
                                                              float *__restrict__ send /* rows of 3 floats */,
-                                                             unsigned *__restrict__ send_src /* local index of each OWN row */)
+                                                             unsigned *__restrict__ send_src /* local index of each OWN row */,
+                                                             int self_slot = -1, float *__restrict__ self_rows = nullptr,
+                                                             int64_t self_shift = 0)
 {
+    // self_slot >= 0 (fused step): the rows this rank owns itself skip the send buffer and the wire and land where the
+    // exchange would have put them: self_rows[3 * (send position + self_shift)]
     __shared__ unsigned s_cnt[2 * SLAB_MAX_RANKS];
     __shared__ unsigned s_base[2 * SLAB_MAX_RANKS];
     const int nslot = 2 * plan.world;
@@ -187,9 +191,10 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
         const int64_t i = tile0 + u * 256 + threadIdx.x;
         {
             const size_t at = (size_t)s_base[2 * owner[u]] + atomicAdd(&s_cnt[2 * owner[u]], 1u);
-            send[3 * at + 0] = px[u];
-            send[3 * at + 1] = py[u];
-            send[3 * at + 2] = pz[u];
+            float *dst = 2 * owner[u] == self_slot ? self_rows + 3 * ((int64_t)at + self_shift) : send + 3 * at;
+            dst[0] = px[u];
+            dst[1] = py[u];
+            dst[2] = pz[u];
             send_src[at] = (unsigned)i;
         }
         for (int t = 0; t < plan.world; ++t)
@@ -205,12 +210,14 @@ __global__ __launch_bounds__(256) void slab_partition_kernel(const float *__rest
 // returned mean distances arrive in the order the points were sent: out[send_src[p]] = recv[p]
 __global__ __launch_bounds__(256) void slab_unpermute_kernel(const float *__restrict__ recv, const unsigned *__restrict__ send_src,
                                                              int64_t n, float *__restrict__ out,
-                                                             const unsigned *__restrict__ cnt_src = nullptr, unsigned *__restrict__ cnt_dst = nullptr)
+                                                             const unsigned *__restrict__ cnt_src = nullptr, unsigned *__restrict__ cnt_dst = nullptr,
+                                                             int64_t self_lo = 0, int64_t self_hi = 0,
+                                                             const float *__restrict__ self_src = nullptr /* indexed by p too */)
 {
     // (fused step: this rank's certificate count rides behind its piece sums in the all-gather that follows)
     if (cnt_dst && blockIdx.x == 0 && threadIdx.x < 2) cnt_dst[threadIdx.x] = cnt_src[threadIdx.x];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
-        out[send_src[p]] = recv[p];
+        out[send_src[p]] = (p >= self_lo && p < self_hi) ? self_src[p] : recv[p];   // (own queries: straight from the KNN's output)
 }
 
 // number of queries whose (k+1)-th neighbour might lie beyond what this rank holds: kth_d2 > (distance to the nearest
@@ -610,8 +617,10 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
         sp.off[2 * s + 1] = (unsigned)p.halo_off[s];
     }
     if (n_local > 0) {
+        // (over a wire the rows this rank owns itself go straight into its slab: no self-copy of 1/G of the cloud)
         hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n_local, 2048)), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, sp,
-                           cursor, w.send.as<float>(), w.send_src.as<unsigned>());
+                           cursor, w.send.as<float>(), w.send_src.as<unsigned>(), wire ? 2 * r : -1, w.slab.as<float>(),
+                           p.r_own_off[r] - p.own_off[r]);
         GSX_HIP(hipGetLastError());
     }
     const float *slab_rows = w.slab.as<float>();
@@ -621,6 +630,7 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
             so[q] = p.own_off[q]; sc[q] = p.own_cnt[q]; ro[q] = p.r_own_off[q]; rc[q] = p.in_own[q];
             so[G + q] = p.halo_off[q]; sc[G + q] = p.halo_cnt[q]; ro[G + q] = p.r_halo_off[q]; rc[G + q] = p.in_halo[q];
         }
+        sc[r] = rc[r] = 0;   // already in place
         GSX_CHECK(gsx_comm_all_to_all_segs(c, w.send.p, w.slab.p, 2, so, sc, ro, rc, 12));
     } else {
         slab_rows = w.send.as<float>();   // no communicator: the (permuted) send buffer IS the slab
@@ -658,7 +668,12 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     const float *ret = w.md_slab.as<float>();
     if (wire) {
         GSX_CHECK(w.ret.reserve(4 * (size_t)std::max<int64_t>(n_local, 1)));
-        GSX_CHECK(gsx_comm_all_to_all_segs(c, w.md_slab.p, w.ret.p, 1, p.r_own_off, p.in_own, p.own_off, p.own_cnt, 4));
+        int64_t sc[SLAB_MAX_RANKS], rc[SLAB_MAX_RANKS];
+        for (int q = 0; q < G; ++q) {
+            sc[q] = q == r ? 0 : p.in_own[q];    // the own queries' means are read where the KNN left them
+            rc[q] = q == r ? 0 : p.own_cnt[q];
+        }
+        GSX_CHECK(gsx_comm_all_to_all_segs(c, w.md_slab.p, w.ret.p, 1, p.r_own_off, sc, p.own_off, rc, 4));
         ret = w.ret.as<float>();
     }
     float *md = w.md.as<float>();
@@ -689,8 +704,10 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     unsigned *unc_total = cursor + 34;
     if (n_local > 0) {   // (also hands this rank's certificate count to the tail of the piece buffer)
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 1024), (int64_t)c->num_cu * 8));
+        const int64_t self_lo = wire ? p.own_off[r] : 0, self_hi = wire ? p.own_off[r] + p.own_cnt[r] : 0;
         hipLaunchKernelGGL(slab_unpermute_kernel, dim3(blocks), dim3(256), 0, c->stream, ret, w.send_src.as<unsigned>(), n_local, md,
-                           unc, w.pieces.as<unsigned>() + (stride - 2));
+                           unc, w.pieces.as<unsigned>() + (stride - 2), self_lo, self_hi,
+                           w.md_slab.as<float>() + (p.r_own_off[r] - p.own_off[r]));
         GSX_HIP(hipGetLastError());
     }
     const float *st_in;

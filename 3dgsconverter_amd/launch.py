@@ -12,7 +12,9 @@ The reference is a single process; this is launcher plumbing of its MI355X scale
 Device per rank: ``LOCAL_RANK`` when the node shows at least WORLD_SIZE GPUs (every rank sees every GPU, as under torchrun:
 RCCL needs the peers visible), otherwise ``LOCAL_RANK % device_count`` -- ranks then SHARE GPUs, which RCCL refuses, and the
 communicator uses the shared-memory "hostwire" transport (csrc/comm.hip): a functional run of the same code, not a scaling
-measurement.  ``GSX_COMM_TRANSPORT=hostwire|rccl`` overrides the choice.
+measurement.  The ranks then settle the transport among themselves from the GPUs they actually opened
+(``agree_transport``: PCI bus ids, all distinct -> RCCL), which also covers launchers that show each rank one GPU.
+``GSX_COMM_TRANSPORT=hostwire|rccl`` overrides the choice.
 """
 from __future__ import annotations
 
@@ -82,18 +84,54 @@ def exchange_unique_id(rank: int, make_id, path: str | None = None, timeout_s: f
 def retire_unique_id(rank: int, path: str | None = None):
     """after every rank has initialised its communicator (a barrier later): the file has done its job"""
     if rank == 0:
-        try:
-            os.unlink(path or rendezvous_path())
-        except OSError:
-            pass
+        path = path or rendezvous_path()
+        for name in [path] + ["%s.dev%d" % (path, r) for r in range(int(os.environ.get("WORLD_SIZE", "1")))]:
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
 
 
 def pick_device_and_transport(local_rank: int, world: int, device_count: int):
-    """-> (device index, transport name)"""
+    """-> (device index, transport name).  The transport is a first guess from the device count alone; agree_transport()
+    settles it from the devices the ranks actually opened."""
     forced = os.environ.get("GSX_COMM_TRANSPORT")
     if device_count >= world:
         return local_rank, forced or "rccl"
     return local_rank % max(device_count, 1), forced or "hostwire"
+
+
+def agree_transport(rank: int, world: int, device_uid: str, path: str | None = None, timeout_s: float = 300.0) -> str:
+    """every rank publishes the identity of the GPU it opened (``_lib.device_uid``: the PCI bus id) next to the rendezvous
+    file and reads the others': all different -> "rccl", any two equal -> "hostwire".  This also covers launchers that
+    give each rank ONE visible GPU (HIP_VISIBLE_DEVICES per rank: device_count() is 1 on eight different GPUs).
+    ``GSX_COMM_TRANSPORT`` still overrides."""
+    forced = os.environ.get("GSX_COMM_TRANSPORT")
+    if forced:
+        return forced
+    path = path or rendezvous_path()
+    mine = "%s.dev%d" % (path, rank)
+    tmp = "%s.tmp%d" % (mine, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(device_uid + "\n")
+    os.replace(tmp, mine)
+    seen, t0 = {}, time.time()
+    while len(seen) < world:
+        for r in range(world):
+            if r in seen:
+                continue
+            try:
+                with open("%s.dev%d" % (path, r)) as f:
+                    txt = f.read()
+                if txt.endswith("\n"):
+                    seen[r] = txt.strip()
+            except FileNotFoundError:
+                pass
+        if len(seen) < world:
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("rank %d: %d of %d ranks announced their device at %s.dev*" % (rank, len(seen), world, path))
+            time.sleep(0.01)
+    return "rccl" if len(set(seen.values())) == world else "hostwire"
 
 
 def spawn_ranks(world: int, argv=None, env_extra=None, timeout_s: float | None = None) -> int:

@@ -612,6 +612,7 @@ def main_multi(args):
         name, val = kv.split("=")
         ctx.set_param(name, float(val))
     be = gslab.HipSlabBackend(ctx=ctx)
+    transport = launch.agree_transport(rank, world, L.device_uid(device))   # distinct GPUs -> RCCL, shared -> hostwire
     uid = launch.exchange_unique_id(rank, lambda: gslab.RcclComm.unique_id(transport))
     comm = gslab.RcclComm(ctx, rank, world, uid)
     comm.barrier()                      # every rank holds its communicator: the id file has done its job

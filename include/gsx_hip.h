@@ -72,6 +72,10 @@ const char *gsx_version(void);
 const char *gsx_last_error(void);
 /* replaces the capability probe gpu_ops.py:8-23 (HAS_TAICHI) */
 int gsx_device_count(void);
+/* the PCI bus id of visible device `device` as text ("0000:c1:00.0"): two processes name the same physical GPU exactly
+ * when the strings match, whatever HIP_VISIBLE_DEVICES each of them runs under.  launch.py picks the communicator's
+ * transport with it (distinct GPUs -> RCCL, shared ones -> hostwire).  Launcher plumbing, no reference counterpart. */
+int gsx_device_uid(int device, char *out, int cap);
 
 /* ---- context ------------------------------------------------------------ */
 int  gsx_ctx_create(int device, gsx_ctx **out);

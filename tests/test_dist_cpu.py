@@ -441,6 +441,38 @@ def _rdzv_rank(rank, path, out):
         f.write(uid)
 
 
+def _agree_rank(rank, world, uid, path, out):
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ.pop("GSX_COMM_TRANSPORT", None)
+    launch = importlib.import_module("3dgsconverter_amd.launch")
+    with open(out + ".%d" % rank, "w") as f:
+        f.write(launch.agree_transport(rank, world, uid, path, timeout_s=30))
+
+
+@pytest.mark.parametrize("uids,expect", [(["0000:05:00.0", "0000:15:00.0", "0000:25:00.0"], "rccl"),
+                                         (["0000:05:00.0", "0000:15:00.0", "0000:05:00.0"], "hostwire")])
+def test_transport_follows_the_devices_the_ranks_opened(tmp_path, uids, expect):
+    """ranks on distinct GPUs (whatever each one's HIP_VISIBLE_DEVICES shows) -> RCCL; any two on one GPU -> hostwire"""
+    import importlib
+    import multiprocessing as mp
+    path, out = str(tmp_path / "uid"), str(tmp_path / "got")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_agree_rank, args=(r, 3, uids[r], path, out)) for r in (2, 0, 1)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert [p.exitcode for p in procs] == [0, 0, 0]
+    assert [open(out + ".%d" % r).read() for r in range(3)] == [expect] * 3
+    os.environ["WORLD_SIZE"] = "3"
+    try:
+        importlib.import_module("3dgsconverter_amd.launch").retire_unique_id(0, path)
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("uid")]
+
+
 def test_unique_id_rendezvous_through_a_file(tmp_path):
     import importlib
     import multiprocessing as mp

@@ -43,6 +43,7 @@ def main(args):
     ctx = L.Context(device)
     comm = None
     if world > 1:
+        transport = launch.agree_transport(rank, world, L.device_uid(device))
         comm = gslab.RcclComm(ctx, rank, world, launch.exchange_unique_id(rank, lambda: gslab.RcclComm.unique_id(transport)))
         comm.barrier()
         launch.retire_unique_id(rank)
