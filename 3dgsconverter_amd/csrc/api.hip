@@ -275,6 +275,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->adaptive = (int)value;
     } else if (!strcmp(name, "tree")) {
         c->tree = (int)value;
+    } else if (!strcmp(name, "tree_scale")) {
+        c->tree_scale = value;
     } else if (!strcmp(name, "defer_words")) {
         c->defer_words = (int)value;
     } else if (!strcmp(name, "filter_mfma")) {

@@ -95,6 +95,8 @@ struct TreeParams {
     unsigned max_leaf;     // points of the fullest leaf (> 64: more than 64 points in ONE fine cell -- the key resolution is exhausted)
     unsigned defer_why[8];   // knn_tree_near's reasons for handing a query on (trace output only): 0 too many cells, 1 dense cell,
                              // 2 buffer full, 3 / 4 fewer than k points inside the last radius tried / inside a known bound, 5-7 attempt
+    unsigned probe_ticket;     // self-resetting: the last wave of tree_probe_kernel picks the scale
+    unsigned probe_hist[32];   // density probe: samples by the fractional octave of their ideal leaf edge (tree_probe_kernel)
     unsigned leaf_ctr[8 * 32];
     unsigned fail_ctr[8 * 32];
     unsigned fail2_ctr[8 * 32];
@@ -135,7 +137,7 @@ __device__ __forceinline__ unsigned fine_cell(float v, double o, double inv_s)
 // ---------------------------------------------------------------- bounding box -> TreeParams
 __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                         const float *__restrict__ z, int64_t stride, int n, float *__restrict__ part,
-                                                        TreeParams *__restrict__ tp, unsigned *__restrict__ devflags)
+                                                        TreeParams *__restrict__ tp, unsigned *__restrict__ devflags, double scale)
 {
     __shared__ float red[7][4];
     __shared__ unsigned s_last;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
         tp->fail_ctr[i] = 0;
         tp->fail2_ctr[i] = 0;
     }
+    if (lane < 32) tp->probe_hist[lane] = 0;
     if (lane != 0) return;
     tp->ticket_bbox = 0;
     const bool isbad = v[6] != 0.0f || n <= 0;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
         mag = fmax(mag, fmax(fabs((double)v[a]), fabs((double)v[3 + a])));
     }
     // 2^21 fine cells along the longest axis; the 2^-18 head room keeps the maximum inside the last cell
-    const double s = (emax > 0.0 && emax < 1e300) ? emax * (1.0 + 0x1p-18) * 0x1p-21 : 1.0;
+    const double s = (emax > 0.0 && emax < 1e300) ? emax * (1.0 + 0x1p-18) * 0x1p-21 * scale : 1.0;
     tp->ox = isbad ? 0.0 : (double)v[0];
     tp->oy = isbad ? 0.0 : (double)v[1];
     tp->oz = isbad ? 0.0 : (double)v[2];
@@ -228,6 +231,158 @@ __global__ __launch_bounds__(256) void tree_bbox_kernel(const float *__restrict_
     tp->max_leaf = 0;
     for (int i = 0; i < 8; ++i) tp->defer_why[i] = 0;
     if (v[6] != 0.0f) atomicOr(devflags, 1u);
+}
+
+// ---------------------------------------------------------------- density probe: the scale of the key grid
+// The leaves are nodes of a BINARY radix tree, so their boxes come in three shapes -- 1:1:1, 2:1:1, 2:2:1 -- and a cloud
+// whose points mostly share one density gets ONE of them everywhere: which, is an accident of extent / 2^21.  Measured
+// on the 10M scene + floaters (profiles/r04_tree_scale.txt; knn_leaf + fallback, ms): cubes of ~50 points 3.60, 2:2:1
+// boxes of ~41 3.70, 2:1:1 boxes of ~36 (what extent / 2^21 happened to give) 4.38, 2:1:1 boxes of ~55 6.41 (18x their
+// points as candidates: two drains per leaf).  The fine cell edge is free up to a factor of two (the keys keep 20 of
+// their 21 bits per axis), so: estimate the local density at 4096 sample points (8th neighbour WITHIN the sample), express
+// each as the fractional octave t of the cube edge that would hold 64 points, and stretch the grid by the 2^delta that
+// puts the most samples where leaves are cheap.  A heuristic on the partition only: every result stays certified.
+constexpr int PROBE_S = 4096, PROBE_M = 8, PROBE_BINS = 32;
+constexpr int PROBE_MIN_N = 1 << 18;   // smaller clouds: the probe's three launches cost more than a better shape gains
+
+__global__ __launch_bounds__(256) void tree_probe_gather_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                const float *__restrict__ z, int64_t stride, int n,
+                                                                float4 *__restrict__ smp)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= PROBE_S) return;
+    const int64_t i = ((int64_t)j * n / PROBE_S) * stride;
+    smp[j] = make_float4(x[i], y[i], z[i], 0.0f);
+}
+
+// Where the samples' t concentrates (the mode of the histogram, +-1/8 octave holding >= 40 % of them: a cloud with one
+// dominant density), the grid is stretched so that the mode lands on t = 0.12: cubes of ~50 points.  The estimate reads
+// ~0.065 octave high on the 10M scene (samples near the rim of the dense part see half-empty balls; E[log V_8] != log E):
+// calibrated out.  No concentration (blobs whose density varies continuously: every t equally likely) -> nothing to choose.
+constexpr float PROBE_TARGET_T = 0.12f, PROBE_BIAS_T = 0.065f;
+
+__device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int lane, const unsigned *hist)   // one whole wave
+{
+    const int l = lane & (PROBE_BINS - 1);
+    const float h_mine = (float)hist[l];
+    tp->probe_hist[l] = hist[l];   // (kept for the trace output)
+    float win = 0.0f, mom = 0.0f, total = h_mine;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) total += __shfl_xor(total, off);
+#pragma unroll
+    for (int j = -4; j <= 4; ++j) {
+        const float h = __shfl(h_mine, (l + j) & (PROBE_BINS - 1));
+        win += h;
+        mom += h * (float)j;
+    }
+    float best = win;
+    int arg = l;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oa = __shfl_xor(arg, off);
+        if (ob > best || (ob == best && oa < arg)) {
+            best = ob;
+            arg = oa;
+        }
+    }
+    if (lane != arg) return;
+    tp->probe_ticket = 0;
+    if (total < PROBE_S / 8 || win < 0.40f * total) return;   // too few usable samples / no dominant density
+    float delta = ((float)l + 0.5f + mom / win) / PROBE_BINS - PROBE_BIAS_T - PROBE_TARGET_T;
+    delta -= floorf(delta);
+    const double s = tp->s * exp2((double)delta);
+    tp->s = s;
+    tp->inv_s = 1.0 / s;
+}
+
+// A workgroup stages all samples in LDS (64 KiB); each of its waves takes PROBE_PER_WAVE of them at once: every lane keeps the 4 nearest
+// of its 64 candidates per sample, the wave pops the 8 nearest of those.  The last wave to finish turns the histogram into
+// the scale.  (One sample per wave straight from L2 was a chain of 64 dependent loads: 90 us.)
+constexpr int PROBE_PER_WAVE = 2;   // samples a wave takes at once (1: 37 us, 2: 28 us, 4: 31 us per launch)
+__global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restrict__ smp, int n, TreeParams *__restrict__ tp,
+                                                         unsigned char *__restrict__ bins /* [PROBE_S]: histogram bin of every sample, 0xff = none */)
+{
+    __shared__ unsigned s_hist[PROBE_BINS];
+    __shared__ unsigned s_last;
+    __shared__ float4 s_smp[PROBE_S];
+    {   // (all 16 loads of a thread in flight: rolled, the loop waited for each in turn -- 16 L2 round trips, 45 us)
+        float4 t[PROBE_S / 256];
+#pragma unroll
+        for (int i = 0; i < PROBE_S / 256; ++i) t[i] = smp[i * 256 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < PROBE_S / 256; ++i) s_smp[i * 256 + threadIdx.x] = t[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PROBE_PER_WAVE;
+    const float inf = __builtin_inff();
+    float4 me[PROBE_PER_WAVE];
+    float a[PROBE_PER_WAVE][4];
+#pragma unroll
+    for (int v = 0; v < PROBE_PER_WAVE; ++v) {
+        me[v] = s_smp[q0 + v];
+        a[v][0] = a[v][1] = a[v][2] = a[v][3] = inf;
+    }
+#pragma unroll 4
+    for (int c = lane; c < PROBE_S; c += 64) {
+        const float4 p = s_smp[c];
+#pragma unroll
+        for (int v = 0; v < PROBE_PER_WAVE; ++v) {
+            const float dx = p.x - me[v].x, dy = p.y - me[v].y, dz = p.z - me[v].z;
+            float d = dx * dx + dy * dy + dz * dz;
+            d = (c == q0 + v || !(d >= 0.0f)) ? inf : d;
+            a[v][3] = fminf(a[v][3], fmaxf(a[v][2], d));
+            a[v][2] = fminf(a[v][2], fmaxf(a[v][1], d));
+            a[v][1] = fminf(a[v][1], fmaxf(a[v][0], d));
+            a[v][0] = fminf(a[v][0], d);
+        }
+    }
+    const float lg_s = __log2f((float)tp->s);
+    const float lg_c = __log2f((float)(PROBE_M - 1) / 4.18879f * ((float)n / PROBE_S));
+    const bool bad = tp->bad_input != 0;
+#pragma unroll
+    for (int v = 0; v < PROBE_PER_WAVE; ++v) {
+        float r2 = 0.0f;
+        for (int round = 0; round < PROBE_M; ++round) {
+            float m = a[v][0];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            r2 = m;
+            if (a[v][0] == m) {
+                a[v][0] = a[v][1];
+                a[v][1] = a[v][2];
+                a[v][2] = a[v][3];
+                a[v][3] = inf;
+            }
+        }
+        if (lane == 0) {
+            unsigned char bin = 0xff;
+            if (!bad && r2 > 0.0f && r2 < inf) {   // (duplicates: no finite density)
+                // rho = (m - 1) / (4/3 pi r^3) * n / S   (E[1/V_m] = rho / (m - 1));   the cube of edge s * 2^u holds 64 points:
+                // u = log2(cbrt(64 / rho) / s) = (6 - log2 rho) / 3 - log2 s      (f32 logarithms: +-1e-6 octave)
+                const float u = (6.0f - lg_c + 1.5f * __log2f(r2)) * (1.0f / 3.0f) - lg_s;
+                if (u > -64.0f && u < 64.0f) bin = (unsigned char)min(PROBE_BINS - 1, (int)((u - floorf(u)) * PROBE_BINS));
+            }
+            // (a byte per sample, counted by the last workgroup: 4096 atomics on one cache line took 45 us -- the chip
+            //  serialises them at ~90 per us, see WorkQueue in sor_grid_params.h)
+            __hip_atomic_store(&bins[q0 + v], bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&tp->probe_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    if (threadIdx.x < PROBE_BINS) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < PROBE_S; i += 256) {
+        const unsigned char b = __hip_atomic_load(&bins[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b < PROBE_BINS) atomicAdd(&s_hist[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) tree_pick_scale(tp, lane, s_hist);
 }
 
 __global__ __launch_bounds__(256) void tree_keys_kernel(const float *__restrict__ x, const float *__restrict__ y,
@@ -1404,7 +1559,13 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_BIN));
     hipLaunchKernelGGL(tree_bbox_kernel, dim3(bbox_blocks), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref,
-                       w.bboxpart.as<float>(), tp, ctx->devflags.as<unsigned>());
+                       w.bboxpart.as<float>(), tp, ctx->devflags.as<unsigned>(), ctx->tree_scale > 0.0 ? ctx->tree_scale : 1.0);
+    if (ctx->tree_scale == 0.0 && n_ref >= PROBE_MIN_N) {   // the shape of the leaves: see "density probe" above
+        float4 *smp = w.keys[1].as<float4>();              // (free until the sort)
+        hipLaunchKernelGGL(tree_probe_gather_kernel, dim3(PROBE_S / 256), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, smp);
+        hipLaunchKernelGGL(tree_probe_kernel, dim3(PROBE_S / (4 * PROBE_PER_WAVE)), dim3(256), 0, ctx->stream, smp, (int)n_ref, tp,
+                           reinterpret_cast<unsigned char *>(smp + PROBE_S));
+    }
     hipLaunchKernelGGL(tree_keys_kernel, dim3(tree_blocks(ctx, n_ref, 4)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, tp,
                        k0, v0);
     GSX_HIP(hipGetLastError());
@@ -1460,6 +1621,11 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
         if (getenv("GSX_TRACE_LEVELS"))
             fprintf(stderr, "[gsx] tree: n=%d fine cell %g leaves=%u (%.1f points each) fallback queries=%u, of which descents=%u\n", h.n,
                     h.s, h.nleaves, h.nleaves ? (double)h.n / h.nleaves : 0.0, h.fail_count, h.fail2_count);
+        if (getenv("GSX_TRACE_LEVELS")) {
+            fprintf(stderr, "[gsx] probe:");
+            for (int b = 0; b < 32; ++b) fprintf(stderr, " %u", h.probe_hist[b]);
+            fprintf(stderr, "\n");
+        }
         if (getenv("GSX_TRACE_LEVELS"))
             fprintf(stderr, "[gsx] near: cells>512 %u, dense cell %u (attempt 0/1/2: %u %u %u), M>cap %u, M<k %u, bound M<k %u\n", h.defer_why[0], h.defer_why[1],
                     h.defer_why[5], h.defer_why[6], h.defer_why[7], h.defer_why[2], h.defer_why[3], h.defer_why[4]);

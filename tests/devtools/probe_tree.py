@@ -58,6 +58,8 @@ def timeit(L, kind, n, tree, reps=3):
     xyz = bench.synth_clustered(n, 0) if kind == "clustered" else (bench.synth_scene_with_floaters(n, 0) if kind == "floaters" else bench.synth_uniform(n, 10.0, 0))
     ctx.set_param("adaptive", 1)
     ctx.set_param("tree", tree)
+    for kv in sys.argv[5:]:
+        ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     b = bench.SorBench(L, ctx, xyz, 16, 1.0)
     b.step(); ctx.synchronize()
     os.environ["GSX_TRACE_LEVELS"] = "1"
