@@ -206,6 +206,13 @@ __device__ __forceinline__ float km_min3(float a, float b, float c)
     return r;
 }
 
+__device__ __forceinline__ float km_med3(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 constexpr int km_dp(int d) { return (d + 3 + 15) / 16 * 16; }  // K-dimension incl. the three |c|^2 slots: 16, 32, 48
 
 // Centroid operands for the whole iteration: for tile t (32 centroids), 16-dimension slice j, variant v (0 = high pieces

@@ -124,26 +124,18 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                 }
-                float lo[8], hi[8];   // tournament for the two smallest of the 16 values, as in kmeans_assign_mfma_kernel
+                // the two smallest of the running pair and the 16 tagged values, one value at a time: with best <= second,
+                // the new second is the MEDIAN of (best, second, v) and the new best min(best, v) -- 2 ops per value against
+                // 2.6 for a tournament of pairs (which it replaced: 64.75 against 65.06 ms per scene on one lane); the same two values
+                // come out
+                const float best_in = best;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float a0 = __uint_as_float((__float_as_uint(acc[2 * q]) & ~0xfu) | (unsigned)(2 * q));
-                    const float a1 = __uint_as_float((__float_as_uint(acc[2 * q + 1]) & ~0xfu) | (unsigned)(2 * q + 1));
-                    lo[q] = km_min(a0, a1);
-                    hi[q] = km_max(a0, a1);
+                for (int q = 0; q < 16; ++q) {
+                    const float v = __uint_as_float((__float_as_uint(acc[q]) & ~0xfu) | (unsigned)q);
+                    second = km_med3(best, second, v);
+                    best = km_min(best, v);
                 }
-#pragma unroll
-                for (int w = 4; w >= 1; w >>= 1)
-#pragma unroll
-                    for (int q = 0; q < w; ++q) {
-                        const float m = km_max(lo[q], lo[q + w]);
-                        lo[q] = km_min(lo[q], lo[q + w]);
-                        hi[q] = km_min3(m, hi[q], hi[q + w]);
-                    }
-                const float m = km_max(best, lo[0]);
-                btile = lo[0] < best ? t : btile;
-                best = km_min(best, lo[0]);
-                second = km_min3(m, second, hi[0]);
+                btile = best < best_in ? t : btile;
             }
             // the two half-waves hold the same points (different centroid rows): merge, publish this wave's view
             const int rb = (int)(__float_as_uint(best) & 0xfu);
