@@ -103,7 +103,9 @@ int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *tota
  * inside gsx_sor_knn_dev, so it is ON for the host entry point gsx_sor_filter and OFF by default for
  * contexts driven through the asynchronous _dev calls), "tree" (default 1; 0: adaptive mode refines the
  * grid level by level instead, DESIGN.md 5.5 -- kept for A/B and used by the replicated multi-GPU shares),
- * "filter_mfma" (1 = matrix-core phase-1 filter, default), "timing_mask" (bit s set = slot
+ * "tree_scale" (0, default: the tree path's density probe stretches the key grid by up to 2x so that the leaves of
+ * a cloud with one dominant density are cubes of ~50 points; f > 0: that factor, no probe -- A/B; results are
+ * bit-identical for every value), "filter_mfma" (1 = matrix-core phase-1 filter, default), "timing_mask" (bit s set = slot
  * GSX_T_s records events while timing is enabled; default all -- every event pair costs stream time),
  * "debug_skip" (profiling only) */
 int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
