@@ -208,6 +208,9 @@ struct gsx_comm {
     int rank = 0, world = 1;
     rcclComm_t comm = nullptr;   // transport "rccl"
     HostWire *hw = nullptr;      // transport "hostwire"
+    bool self_wire = false;      // GSX_COMM_SELF_WIRE=1 (test knob): a rank's block for ITSELF also travels as ncclSend + ncclRecv in
+                                 // the group instead of a device copy -- the grouped point-to-point calls (data type, counts, offsets,
+                                 // stream) run through the real library on a box with one GPU
 };
 
 static int hw_destroy(gsx_comm *m)
@@ -400,6 +403,7 @@ int gsx_comm_init(gsx_ctx *c, int rank, int world, const void *id128)
     if (c->comm) GSX_FAIL("gsx_comm_init: the context already has a communicator");
     GSX_HIP(hipSetDevice(c->device));
     gsx_comm *m = new gsx_comm();
+    if (const char *t = getenv("GSX_COMM_SELF_WIRE")) m->self_wire = atoi(t) != 0;
     m->rank = rank;
     m->world = world;
     if (memcmp(id128, HW_MAGIC, 8) == 0) {
@@ -515,13 +519,14 @@ int gsx_comm_all_to_all_segs(gsx_ctx *c, const void *send_dev, void *recv_dev, i
     for (int s = 0; s < nseg; ++s)
         if (send_cnt[s * G + me] != recv_cnt[s * G + me]) GSX_FAIL("gsx_comm_all_to_all: local block sizes differ");
     if (m->hw) return hw_all_to_all(c, m, send_dev, recv_dev, nseg, send_off, send_cnt, recv_off, recv_cnt, eb);
+    const bool self_wire = m->self_wire;
     bool remote = false;
-    for (int i = 0; i < nseg * G; ++i) remote |= (i % G) != me && (send_cnt[i] > 0 || recv_cnt[i] > 0);
+    for (int i = 0; i < nseg * G; ++i) remote |= ((i % G) != me || self_wire) && (send_cnt[i] > 0 || recv_cnt[i] > 0);
     if (remote) {   // (an empty group still costs RCCL bookkeeping)
         GSX_RCCL(g_rccl.GroupStart());
         for (int s = 0; s < nseg; ++s)
             for (int p = 0; p < G; ++p) {
-                if (p == me) continue;
+                if (p == me && !self_wire) continue;
                 const int i = s * G + p;
                 if (send_cnt[i] > 0)
                     GSX_RCCL(g_rccl.Send(static_cast<const char *>(send_dev) + eb * (size_t)send_off[i], (size_t)send_cnt[i] * mul, dt, p,
@@ -532,7 +537,7 @@ int gsx_comm_all_to_all_segs(gsx_ctx *c, const void *send_dev, void *recv_dev, i
             }
         GSX_RCCL(g_rccl.GroupEnd());
     }
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = 0; s < nseg && !self_wire; ++s) {
         const int i = s * G + me;
         if (send_cnt[i] > 0)
             GSX_HIP(hipMemcpyAsync(static_cast<char *>(recv_dev) + eb * (size_t)recv_off[i],

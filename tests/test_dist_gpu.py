@@ -72,6 +72,38 @@ def test_slab_path_world1_through_rccl_matches_the_golden_1m(gsx, golden_cases):
     comm.close()
 
 
+def test_grouped_send_recv_through_the_real_rccl_on_one_gpu(gsx, golden_cases, monkeypatch):
+    """GSX_COMM_SELF_WIRE=1: the block a rank keeps for itself travels as ncclSend + ncclRecv inside the group instead of a
+    device copy, so the point-to-point half of csrc/comm.hip (row data type and counts, byte offsets, two segments in one
+    group, the stream) runs through librccl on this one-GPU box; the step-by-step slab pipeline on top of it still matches
+    the reference run"""
+    slab = importlib.import_module("3dgsconverter_amd.dist_slab")
+    monkeypatch.setenv("GSX_COMM_SELF_WIRE", "1")
+    case = golden_cases["sor"]["sor_u1m_k16_s1"]
+    xyz = datasets.make(case["dataset"])
+    be = slab.HipSlabBackend(0)
+    comm = slab.RcclComm(be.ctx, 0, 1, slab.RcclComm.unique_id())
+    assert comm.transport == "rccl"
+    a, b = be.buf("t_a", 4096), be.buf("t_b", 4096)
+    be.from_host(a, np.arange(1024, dtype=np.float32))
+    be.from_host(b, np.zeros(1024, dtype=np.float32))
+    comm.all_to_all_v(a, [2], [3], b, [5], [3], 4)                       # 3 floats from a[2:] to b[5:]
+    np.testing.assert_array_equal(be.to_host(b, np.float32, 10), [0, 0, 0, 0, 0, 2, 3, 4, 0, 0])
+    comm.all_to_all_v(a, [3], [5], b, [20], [5], 12)                     # 5 ROWS of three floats: a[9:24] -> b[60:75]
+    np.testing.assert_array_equal(be.to_host(b, np.float32, 80)[58:77], [0, 0] + list(range(9, 24)) + [0, 0])
+    comm.all_to_all_segs(a, b, [([100], [4], [300], [4]), ([200], [6], [400], [6])], 4)   # two segments in ONE group
+    got = be.to_host(b, np.float32, 1024)
+    np.testing.assert_array_equal(got[300:304], np.arange(100, 104))
+    np.testing.assert_array_equal(got[400:406], np.arange(200, 206))
+    rows = be.buf("rows", xyz.nbytes)
+    be.from_host(rows, xyz)
+    res = slab.slab_sor(be, comm, rows, len(xyz), case["k_used"], case["sigma_used"], want_host=True, fused=False)
+    assert sha16(res["mean_dists_host"].tobytes()) == case["mean_dists_sha"]
+    assert sha16(np.packbits(res["mask_host"]).tobytes()) == case["mask_sha"]
+    be.check()
+    comm.close()
+
+
 def _spawn(target, world, args):
     """world processes through the standard library's spawn context (no torch anywhere: numpy + ctypes)"""
     import multiprocessing as mp
