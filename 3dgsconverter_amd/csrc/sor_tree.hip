@@ -256,12 +256,21 @@ __global__ __launch_bounds__(256) void tree_probe_gather_kernel(const float *__r
 }
 
 // Where the samples' t concentrates (the mode of the histogram, +-1/8 octave holding >= 40 % of them: a cloud with one
-// dominant density), the grid is stretched so that the mode lands on t = 0.12: cubes of ~50 points.  The estimate reads
-// ~0.065 octave high on the 10M scene (samples near the rim of the dense part see half-empty balls; E[log V_8] != log E):
-// calibrated out.  No concentration (blobs whose density varies continuously: every t equally likely) -> nothing to choose.
-constexpr float PROBE_TARGET_T = 0.12f, PROBE_BIAS_T = 0.065f;
+// dominant density), the grid is stretched so that the mode lands on the cheapest leaf THIS k can use.  A leaf's searched
+// box is the leaf grown by one cell c (half its longest side), and a query is certified iff its k-th neighbour is nearer
+// than the box's faces, so the shape must leave  c / r_k = (n / (a k))^(1/3) >= ~1.12  (n points per leaf; a = 1.91 for a
+// cube, 0.955 for 2:2:1, 0.477 for 2:1:1) -- below it the fallback kernels get every rim query: at k = 32 cubes of 50 points
+// (ratio 0.94) send 1.1 M of 10 M queries there, 11.2 ms against 7.2 with 2:2:1 boxes (profiles/r04_tree_scale.txt).
+// Candidates per query grow 8 : 12 : 18 with the shape, n stays clear of 64 (a node a few points above it splits into
+// halves whose margin is too small) and of two drains (2:1:1, n > 48):
+//   k <= 16: cubes of ~50 points (t = 0.12) | k <= 32: 2:2:1 boxes of ~48 (t = 0.805) | k <= 64: 2:1:1 boxes of ~38 (t = 0.59)
+// The estimate reads ~0.065 octave high on the 10M scene (samples near the rim of the dense part see half-empty balls;
+// E[log V_8] != log E): calibrated out.  No concentration (blobs whose density varies continuously: every t equally
+// likely) -> nothing to choose.
+constexpr float PROBE_BIAS_T = 0.065f;
+__host__ __device__ constexpr float probe_target_t(int k) { return k <= 16 ? 0.12f : (k <= 32 ? 0.805f : 0.59f); }
 
-__device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int lane, const unsigned *hist)   // one whole wave
+__device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int lane, const unsigned *hist, int k)   // one whole wave
 {
     const int l = lane & (PROBE_BINS - 1);
     const float h_mine = (float)hist[l];
@@ -289,7 +298,7 @@ __device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int
     if (lane != arg) return;
     tp->probe_ticket = 0;
     if (total < PROBE_S / 8 || win < 0.40f * total) return;   // too few usable samples / no dominant density
-    float delta = ((float)l + 0.5f + mom / win) / PROBE_BINS - PROBE_BIAS_T - PROBE_TARGET_T;
+    float delta = ((float)l + 0.5f + mom / win) / PROBE_BINS - PROBE_BIAS_T - probe_target_t(k);
     delta -= floorf(delta);
     const double s = tp->s * exp2((double)delta);
     tp->s = s;
@@ -300,7 +309,7 @@ __device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int
 // of its 64 candidates per sample, the wave pops the 8 nearest of those.  The last wave to finish turns the histogram into
 // the scale.  (One sample per wave straight from L2 was a chain of 64 dependent loads: 90 us.)
 constexpr int PROBE_PER_WAVE = 2;   // samples a wave takes at once (1: 37 us, 2: 28 us, 4: 31 us per launch)
-__global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restrict__ smp, int n, TreeParams *__restrict__ tp,
+__global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restrict__ smp, int n, int k, TreeParams *__restrict__ tp,
                                                          unsigned char *__restrict__ bins /* [PROBE_S]: histogram bin of every sample, 0xff = none */)
 {
     __shared__ unsigned s_hist[PROBE_BINS];
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restric
         if (b < PROBE_BINS) atomicAdd(&s_hist[b], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64) tree_pick_scale(tp, lane, s_hist);
+    if (threadIdx.x < 64) tree_pick_scale(tp, lane, s_hist, k);
 }
 
 __global__ __launch_bounds__(256) void tree_keys_kernel(const float *__restrict__ x, const float *__restrict__ y,
@@ -1563,7 +1572,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     if (ctx->tree_scale == 0.0 && n_ref >= PROBE_MIN_N) {   // the shape of the leaves: see "density probe" above
         float4 *smp = w.keys[1].as<float4>();              // (free until the sort)
         hipLaunchKernelGGL(tree_probe_gather_kernel, dim3(PROBE_S / 256), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, smp);
-        hipLaunchKernelGGL(tree_probe_kernel, dim3(PROBE_S / (4 * PROBE_PER_WAVE)), dim3(256), 0, ctx->stream, smp, (int)n_ref, tp,
+        hipLaunchKernelGGL(tree_probe_kernel, dim3(PROBE_S / (4 * PROBE_PER_WAVE)), dim3(256), 0, ctx->stream, smp, (int)n_ref, k, tp,
                            reinterpret_cast<unsigned char *>(smp + PROBE_S));
     }
     hipLaunchKernelGGL(tree_keys_kernel, dim3(tree_blocks(ctx, n_ref, 4)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, tp,

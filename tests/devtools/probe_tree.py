@@ -60,7 +60,7 @@ def timeit(L, kind, n, tree, reps=3):
     ctx.set_param("tree", tree)
     for kv in sys.argv[5:]:
         ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
-    b = bench.SorBench(L, ctx, xyz, 16, 1.0)
+    b = bench.SorBench(L, ctx, xyz, int(os.environ.get("PROBE_K", "16")), 1.0)
     b.step(); ctx.synchronize()
     os.environ["GSX_TRACE_LEVELS"] = "1"
     ts = []
