@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 // by the same wave.  EXTRA == true (second launch) spreads those items over the whole chip.
 // waves per SIMD the register allocator must leave room for (the top-k list is 2*KCAP VGPRs)
 // Round 3 (profiles/r03_variants.txt): phase 2 takes the candidates in blocks of 8 (TopNet::BS) -- the list, one block and
-// four gathers in flight then need ~95 VGPRs and five waves per SIMD are resident for k <= 16 (three for k <= 32).  The
+// four gathers in flight then need ~95 VGPRs and five waves per SIMD are resident for k <= 16 (four for k <= 32: round 4, -3 % at k = 25 / 32; five spill into the loops: +70 %).  The
 // kernel is bound by latency as much as by issue: 3 -> 5 waves took knn_brick from 1.92 to 1.68 ms at 10M splats, the
 // setup code's spills (outside the loops) notwithstanding; six waves push spills into the loops (2.39 ms).
 // (tuning builds override these constants with -D; tools/build_variants.sh)
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #define GSX_NET_WAVES17 5
 #endif
 #ifndef GSX_NET_WAVES33
-#define GSX_NET_WAVES33 3
+#define GSX_NET_WAVES33 4
 #endif
 #ifndef GSX_NET_HB
 #define GSX_NET_HB 4
