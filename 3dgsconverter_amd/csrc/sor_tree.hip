@@ -602,7 +602,13 @@ __global__ __launch_bounds__(256) void tree_leaf_max_kernel(TreeParams *__restri
 }
 
 // ---------------------------------------------------------------- knn_leaf
-constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? 3 : 2); }
+#ifndef GSX_LEAF_WAVES33
+#define GSX_LEAF_WAVES33 4   // (round 4: -5 % at k = 25 against 3)
+#endif
+#ifndef GSX_LEAF_WAVES65
+#define GSX_LEAF_WAVES65 2
+#endif
+constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? GSX_LEAF_WAVES33 : GSX_LEAF_WAVES65); }
 
 template <int KCAP>
 __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_kernel(
