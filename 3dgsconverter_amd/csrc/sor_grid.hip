@@ -701,13 +701,20 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #ifndef GSX_NET_HB
 #define GSX_NET_HB 4
 #endif
-constexpr int NET_WAVES9 = 5, NET_WAVES17 = GSX_NET_WAVES17, NET_WAVES33 = GSX_NET_WAVES33;
+#ifndef GSX_NET_WAVES25
+#define GSX_NET_WAVES25 4
+#endif
+#ifndef GSX_NET_WAVES49
+#define GSX_NET_WAVES49 3
+#endif
+constexpr int NET_WAVES9 = 5, NET_WAVES17 = GSX_NET_WAVES17, NET_WAVES25 = GSX_NET_WAVES25, NET_WAVES33 = GSX_NET_WAVES33,
+              NET_WAVES49 = GSX_NET_WAVES49;
 constexpr int NET_HB = GSX_NET_HB;   // candidate gathers in flight per lane (8: no change)
 constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
     // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
-    if (net) return kcap <= 9 ? NET_WAVES9 : (kcap <= 17 ? NET_WAVES17 : (kcap <= 33 ? NET_WAVES33 : 2));
+    if (net) return kcap <= 9 ? NET_WAVES9 : (kcap <= 17 ? NET_WAVES17 : (kcap <= 25 ? NET_WAVES25 : (kcap <= 33 ? NET_WAVES33 : (kcap <= 49 ? NET_WAVES49 : 2))));
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
@@ -2295,8 +2302,8 @@ static int dispatch_heavy(gsx_ctx *ctx, KnnWs &w, const BrickLaunch &a, int64_t 
     return launch_heavy<65>(ctx, w, a, n_ref, heavy_count);
 }
 
-// list-capacity buckets.  Sorting-network selection (default): the list holds k neighbours, capacities 8, 16,
-// 32, 64 (template argument = capacity + 1).  Bubble-insert selection (phase2_net = 0, kept for A/B): k + 1
+// list-capacity buckets.  Sorting-network selection (default): the list holds k neighbours, capacities 8, 16, 24,
+// 32, 48, 64 (template argument = capacity + 1; 24 and 48: round 4, TopNet's padded merge).  Bubble-insert selection (phase2_net = 0, kept for A/B): k + 1
 // entries incl. the query; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10).
 static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net)
 {
@@ -2305,7 +2312,9 @@ static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net
 #define GSX_BRICKS(K) (mf ? launch_bricks<K, true, true>(ctx, a) : launch_bricks<K, false, true>(ctx, a))
         if (kk <= 9) return GSX_BRICKS(9);
         if (kk <= 17) return GSX_BRICKS(17);
+        if (kk <= 25) return GSX_BRICKS(25);   // 24 and 48 entries: the reference CLI's k = 18 ... 24 and 33 ... 48
         if (kk <= 33) return GSX_BRICKS(33);
+        if (kk <= 49) return GSX_BRICKS(49);
         return GSX_BRICKS(65);
 #undef GSX_BRICKS
     }
@@ -2414,6 +2423,15 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         const double fill = n_ref >= 4000000 ? 54.0 : 58.0;
         for (int cells = 8; cells >= 1; cells /= 2)
             if (pts_per_cell * cells > fill && pts_per_cell * cells <= 66.0) pts_per_cell = fill / cells;
+        // k = 17 ... 20 (round 4; the reference CLI's --sor_intensity 3 is k = 18): 0.47 (k + 1) points per cell would
+        // halve the brick to 2x2x1 cells -- 36 of 64 lanes busy, 12x instead of 8x its points as candidates.  Smaller cells
+        // keep the 2x2x2 brick full at the price of ring queries (10M uniform, step ms: k = 18 3.16 -> 2.60 with 175 k ring
+        // queries, k = 20 3.17 -> 2.90 with 186 k; from k = 23 on the ring queries cost more than the full lanes save)
+        if (k >= 17 && k <= 20) pts_per_cell = std::min(pts_per_cell, fill / 8.0 + 0.375 * (double)std::max(0, k - 18));
+        // ... and k = 35 ... 52 (--sor_intensity 7 ... 10: k = 36, 41, 45, 50) keeps 2x2x1 bricks instead of 2x1x1 (10M uniform, step ms:
+        // k = 36 6.28 -> 4.52, k = 41 6.10 -> 5.02, k = 45 7.26 -> 5.73, k = 48 7.50 -> 6.3, k = 50 10.3 -> 8.3; k >= 56: the ring
+        // queries win -- profiles/r04_variants.txt)
+        if (k >= 35 && k <= 52) pts_per_cell = std::min(pts_per_cell, (k <= 38 ? 13.5 : (k <= 46 ? 14.5 : 15.0)) * fill / 54.0);
     }
     GSX_CHECK(w.packed.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(w.bucketpts.reserve(sizeof(float4) * (size_t)n_ref));

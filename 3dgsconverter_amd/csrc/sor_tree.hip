@@ -608,7 +608,16 @@ __global__ __launch_bounds__(256) void tree_leaf_max_kernel(TreeParams *__restri
 #ifndef GSX_LEAF_WAVES65
 #define GSX_LEAF_WAVES65 2
 #endif
-constexpr int leaf_min_waves(int kcap) { return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 33 ? GSX_LEAF_WAVES33 : GSX_LEAF_WAVES65); }
+#ifndef GSX_LEAF_WAVES25
+#define GSX_LEAF_WAVES25 4
+#endif
+#ifndef GSX_LEAF_WAVES49
+#define GSX_LEAF_WAVES49 3
+#endif
+constexpr int leaf_min_waves(int kcap)
+{
+    return kcap <= 17 ? GSX_LEAF_WAVES17 : (kcap <= 25 ? GSX_LEAF_WAVES25 : (kcap <= 33 ? GSX_LEAF_WAVES33 : (kcap <= 49 ? GSX_LEAF_WAVES49 : GSX_LEAF_WAVES65)));
+}
 
 template <int KCAP>
 __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_kernel(
@@ -1616,7 +1625,9 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     const int kk = k + 1;
     if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 25) GSX_CHECK(launch_leaves<25>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 49) GSX_CHECK(launch_leaves<49>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));

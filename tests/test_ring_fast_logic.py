@@ -99,3 +99,42 @@ def test_row_trim_never_drops_a_point_inside_the_ball():
             dxc = np.sqrt(rem) + 1e-3
             xa, xb = int(np.floor(u[0] - dxc)), int(np.floor(u[0] + dxc))
             assert xa <= p_cell[0] <= xb
+
+
+def _padded_bitonic_merge(L, BS, a, b):
+    """csrc/knn_common.h: TopNet<L>::merge_block restated -- the list of L sorted values takes a block of BS values through
+    c[L-BS+i] = min(a[L-BS+i], b_sorted[BS-1-i]) and a bitonic merge network of the next power of two P, whose first P - L
+    positions are an imagined -inf (compare-exchanges with them are not emitted)"""
+    a, b = list(a), sorted(b)
+    P = 8
+    while P < L:
+        P *= 2
+    off = P - L
+    for i in range(BS):
+        a[L - BS + i] = min(a[L - BS + i], b[BS - 1 - i])
+    half, nce = P // 2, 0
+    while half >= 1:
+        for p in range(off, P):
+            if p & half == 0:
+                x, y = a[p - off], a[p + half - off]
+                a[p - off], a[p + half - off] = min(x, y), max(x, y)
+                nce += 1
+        half //= 2
+    return a, nce
+
+
+def test_padded_bitonic_merge():
+    """0-1 principle: every sorted 0/1 list x every 0/1 block, for every list length the kernels instantiate (and the
+    other multiples of 8); plus random reals.  The compare-exchange counts are the ones the kernel comments quote."""
+    rng = np.random.default_rng(5)
+    counts = {}
+    for L in (8, 16, 24, 32, 40, 48, 56, 64):
+        for za in range(L + 1):
+            for zb in range(9):
+                a, b = [0] * za + [1] * (L - za), [0] * zb + [1] * (8 - zb)
+                out, counts[L] = _padded_bitonic_merge(L, 8, a, b)
+                assert out == sorted(a + b)[:L], (L, za, zb)
+        for _ in range(200):
+            a, b = sorted(rng.random(L).tolist()), rng.random(8).tolist()
+            assert _padded_bitonic_merge(L, 8, a, b)[0] == sorted(a + b)[:L]
+    assert counts == {8: 12, 16: 32, 24: 52, 32: 80, 40: 100, 48: 128, 56: 156, 64: 192}
