@@ -2431,6 +2431,7 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         // ... and k = 35 ... 52 (--sor_intensity 7 ... 10: k = 36, 41, 45, 50) keeps 2x2x1 bricks instead of 2x1x1 (10M uniform, step ms:
         // k = 36 6.28 -> 4.52, k = 41 6.10 -> 5.02, k = 45 7.26 -> 5.73, k = 48 7.50 -> 6.3, k = 50 10.3 -> 8.3; k >= 56: the ring
         // queries win -- profiles/r04_variants.txt)
+        if (k >= 26 && k <= 31) pts_per_cell = std::min(pts_per_cell, 12.0 * fill / 54.0);   // (k = 27: 3.49 -> 3.36, k = 30: 3.58 -> 3.42)
         if (k >= 35 && k <= 52) pts_per_cell = std::min(pts_per_cell, (k <= 38 ? 13.5 : (k <= 46 ? 14.5 : 15.0)) * fill / 54.0);
     }
     GSX_CHECK(w.packed.reserve(sizeof(float4) * (size_t)n_ref));
