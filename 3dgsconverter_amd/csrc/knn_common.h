@@ -137,7 +137,7 @@ __device__ __forceinline__ void oe_sort(double *v)
 template <int L>
 struct TopNet {
     static_assert(L % 8 == 0 && L >= 8 && L <= 64, "list length: a multiple of 8");
-    // Lengths that are not a power of two (24, 48: round 4 -- the reference's CLI asks for k = 18 ... 50, and a 64-entry list
+    // Lengths that are not a power of two (24, 40, 48, 56: round 4 -- the reference's CLI asks for k = 18 ... 50, and a 64-entry list
     // for k = 36 is 2.2x the time of a 32-entry one) merge through the next power of two P with P - L entries of -inf
     // imagined IN FRONT of the list: [-inf ..., sorted head, bitonic tail] is still bitonic, and a compare-exchange whose
     // lower partner is -inf does nothing, so it is not emitted: 52 CE at L = 24 (80 at 32), 128 at L = 48 (192 at 64).

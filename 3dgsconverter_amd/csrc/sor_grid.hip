@@ -714,7 +714,7 @@ constexpr int brick_min_waves(int kcap, bool mf, bool net)
 {
     (void)mf;  // the MFMA filter's registers are not live together with the top-k list (single-drain path)
     // NET: list of KCAP-1 doubles + a 16-candidate block + 8 gathers in flight
-    if (net) return kcap <= 9 ? NET_WAVES9 : (kcap <= 17 ? NET_WAVES17 : (kcap <= 25 ? NET_WAVES25 : (kcap <= 33 ? NET_WAVES33 : (kcap <= 49 ? NET_WAVES49 : 2))));
+    if (net) return kcap <= 9 ? NET_WAVES9 : (kcap <= 17 ? NET_WAVES17 : (kcap <= 25 ? NET_WAVES25 : (kcap <= 33 ? NET_WAVES33 : (kcap <= 49 ? NET_WAVES49 : 2))));   // (41 -> like 49, 57 -> like 65)
     return kcap <= 17 ? 5 : (kcap <= 26 ? 4 : (kcap <= 33 ? 3 : 2));
 }
 
@@ -2303,7 +2303,8 @@ static int dispatch_heavy(gsx_ctx *ctx, KnnWs &w, const BrickLaunch &a, int64_t 
 }
 
 // list-capacity buckets.  Sorting-network selection (default): the list holds k neighbours, capacities 8, 16, 24,
-// 32, 48, 64 (template argument = capacity + 1; 24 and 48: round 4, TopNet's padded merge).  Bubble-insert selection (phase2_net = 0, kept for A/B): k + 1
+// 32, 40, 48, 56, 64 (template argument = capacity + 1; the multiples of 8 that are no power of two: round 4, TopNet's
+// padded merge).  Bubble-insert selection (phase2_net = 0, kept for A/B): k + 1
 // entries incl. the query; 26 and 51 are the CLI's default k=25 and its maximum k=50 (--sor_intensity 10).
 static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net)
 {
@@ -2314,7 +2315,9 @@ static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net
         if (kk <= 17) return GSX_BRICKS(17);
         if (kk <= 25) return GSX_BRICKS(25);   // 24 and 48 entries: the reference CLI's k = 18 ... 24 and 33 ... 48
         if (kk <= 33) return GSX_BRICKS(33);
+        if (kk <= 41) return GSX_BRICKS(41);   // (40 and 56 entries: -10 % at k = 36, -13 % at 40, -8 % at 56 against the next capacity)
         if (kk <= 49) return GSX_BRICKS(49);
+        if (kk <= 57) return GSX_BRICKS(57);
         return GSX_BRICKS(65);
 #undef GSX_BRICKS
     }

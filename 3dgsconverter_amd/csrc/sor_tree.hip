@@ -1627,7 +1627,9 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else if (kk <= 25) GSX_CHECK(launch_leaves<25>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 41) GSX_CHECK(launch_leaves<41>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else if (kk <= 49) GSX_CHECK(launch_leaves<49>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    else if (kk <= 57) GSX_CHECK(launch_leaves<57>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
