@@ -821,7 +821,9 @@ class DeviceChain:
         self.empty = False                  # keep_none(): no survivor, whatever self.orig says
         self.mask = self.ctx.alloc(self.n0 + 16)
         self._md = self._st = None          # SOR work buffers (mean distances, statistics), allocated on first use
-        self._box = None                    # box of the uploaded rows (lazily; a superset of every later state of the chain)
+        self._box = None                    # box of the rows at the first density_filter() (a superset of every LATER state of the
+                                            # chain; restart() drops it).  gsx_density_filter_dev re-derives the frame itself when
+                                            # a row falls outside the box it was given (status word `oob` of the device result)
 
     def restart(self):
         """back to the state right after the upload (needs keep_pristine): device-to-device copy, identity survivor list"""
@@ -832,6 +834,9 @@ class DeviceChain:
             self._pool.append(self.orig)
         self.orig = None
         self.n, self.empty = self.n0, False
+        # the cached box is the box of the rows that were current at the first density_filter() -- after a restart
+        # the pristine rows may reach beyond it: drop it, the next density_filter() measures again
+        self._box = None
 
     def _xyz(self):
         p = self.rows.ptr

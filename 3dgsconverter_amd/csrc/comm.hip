@@ -41,6 +41,7 @@ struct Rccl {
     int (*GetUniqueId)(rcclUniqueId *) = nullptr;
     int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
     int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*CommAbort)(rcclComm_t) = nullptr;    // optional
     const char *(*GetErrorString)(int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t) = nullptr;
@@ -74,6 +75,7 @@ static int rccl_load()
     GSX_SYM(GroupStart, "ncclGroupStart");
     GSX_SYM(GroupEnd, "ncclGroupEnd");
 #undef GSX_SYM
+    *reinterpret_cast<void **>(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
     g_rccl.h = h;
     return 0;
 }
@@ -208,6 +210,7 @@ struct gsx_comm {
     int rank = 0, world = 1;
     rcclComm_t comm = nullptr;   // transport "rccl"
     HostWire *hw = nullptr;      // transport "hostwire"
+    bool aborted = false;        // gsx_comm_abort ran: every later collective fails instead of touching a dead communicator
     bool self_wire = false;      // GSX_COMM_SELF_WIRE=1 (test knob): a rank's block for ITSELF also travels as ncclSend + ncclRecv in
                                  // the group instead of a device copy -- the grouped point-to-point calls (data type, counts, offsets,
                                  // stream) run through the real library on a box with one GPU
@@ -288,6 +291,14 @@ template <class T, class Op>
 static void hw_reduce(T *acc, const T *src, int64_t n, Op op)
 {
     for (int64_t i = 0; i < n; ++i) acc[i] = op(acc[i], src[i]);
+}
+
+// A hostwire collective that fails LOCALLY (outbox cannot grow, a copy or an mmap fails) must not leave the peers spinning in
+// hw_barrier until the timeout: whatever the reason, a non-zero return raises the shared `failed` flag.
+static int hw_guard(gsx_comm *m, int rc)
+{
+    if (rc != 0 && m->hw && m->hw->ctl) m->hw->ctl->failed.store(1u);
+    return rc;
 }
 
 static int hw_all_reduce(gsx_ctx *c, gsx_comm *m, void *buf_dev, int64_t count, int kind)
@@ -447,6 +458,11 @@ int gsx_comm_abort(gsx_ctx *c)
     if (!c || !c->comm) return 0;
     gsx_comm *m = static_cast<gsx_comm *>(c->comm);
     if (m->hw && m->hw->ctl) m->hw->ctl->failed.store(1u);
+    if (!m->hw && m->comm && g_rccl.CommAbort && !m->aborted) {   // frees this rank's resources, fails its queued operations
+        g_rccl.CommAbort(m->comm);
+        m->comm = nullptr;
+    }
+    m->aborted = true;
     return 0;
 }
 
@@ -480,9 +496,10 @@ int gsx_comm_all_reduce(gsx_ctx *c, void *buf_dev, int64_t count, int kind)
     if (!c || !c->comm || !buf_dev || count < 0) GSX_FAIL("gsx_comm_all_reduce: no communicator / null buffer");
     if (kind < GSX_COMM_F32_MAX || kind > GSX_COMM_I64_MIN) GSX_FAIL("gsx_comm_all_reduce: unknown kind %d", kind);
     gsx_comm *m = static_cast<gsx_comm *>(c->comm);
+    if (m->aborted) GSX_FAIL("gsx_comm: the communicator was aborted");
     GSX_HIP(hipSetDevice(c->device));
     if (count == 0) return 0;
-    if (m->hw) return hw_all_reduce(c, m, buf_dev, count, kind);
+    if (m->hw) return hw_guard(m, hw_all_reduce(c, m, buf_dev, count, kind));
     static const int dts[5] = {RCCL_FLOAT32, RCCL_FLOAT32, RCCL_INT64, RCCL_FLOAT64, RCCL_INT64};
     static const int ops[5] = {RCCL_MAX, RCCL_SUM, RCCL_SUM, RCCL_MAX, RCCL_MIN};
     GSX_RCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, dts[kind], ops[kind], m->comm, c->stream));
@@ -493,8 +510,9 @@ int gsx_comm_all_gather(gsx_ctx *c, const void *send_dev, void *recv_dev, int64_
 {
     if (!c || !c->comm || !send_dev || !recv_dev || bytes_per_rank < 0) GSX_FAIL("gsx_comm_all_gather: no communicator / null buffer");
     gsx_comm *m = static_cast<gsx_comm *>(c->comm);
+    if (m->aborted) GSX_FAIL("gsx_comm: the communicator was aborted");
     GSX_HIP(hipSetDevice(c->device));
-    if (m->hw) return hw_all_gather(c, m, send_dev, recv_dev, bytes_per_rank);
+    if (m->hw) return hw_guard(m, hw_all_gather(c, m, send_dev, recv_dev, bytes_per_rank));
     GSX_RCCL(g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, RCCL_INT8, m->comm, c->stream));
     return 0;
 }
@@ -508,6 +526,7 @@ int gsx_comm_all_to_all_segs(gsx_ctx *c, const void *send_dev, void *recv_dev, i
     if (!c || !c->comm || !send_off || !send_cnt || !recv_off || !recv_cnt || nseg < 1 || nseg > COMM_MAX_SEGS)
         GSX_FAIL("gsx_comm_all_to_all: no communicator / null argument / more than %d segments", COMM_MAX_SEGS);
     gsx_comm *m = static_cast<gsx_comm *>(c->comm);
+    if (m->aborted) GSX_FAIL("gsx_comm: the communicator was aborted");
     GSX_HIP(hipSetDevice(c->device));
     const int G = m->world, me = m->rank;
     int dt;
@@ -518,7 +537,7 @@ int gsx_comm_all_to_all_segs(gsx_ctx *c, const void *send_dev, void *recv_dev, i
         if (send_cnt[i] < 0 || recv_cnt[i] < 0 || send_off[i] < 0 || recv_off[i] < 0) GSX_FAIL("gsx_comm_all_to_all: negative size");
     for (int s = 0; s < nseg; ++s)
         if (send_cnt[s * G + me] != recv_cnt[s * G + me]) GSX_FAIL("gsx_comm_all_to_all: local block sizes differ");
-    if (m->hw) return hw_all_to_all(c, m, send_dev, recv_dev, nseg, send_off, send_cnt, recv_off, recv_cnt, eb);
+    if (m->hw) return hw_guard(m, hw_all_to_all(c, m, send_dev, recv_dev, nseg, send_off, send_cnt, recv_off, recv_cnt, eb));
     const bool self_wire = m->self_wire;
     bool remote = false;
     for (int i = 0; i < nseg * G; ++i) remote |= ((i % G) != me || self_wire) && (send_cnt[i] > 0 || recv_cnt[i] > 0);
@@ -558,6 +577,7 @@ int gsx_comm_barrier(gsx_ctx *c)
 {
     if (!c || !c->comm) GSX_FAIL("gsx_comm_barrier: no communicator");
     gsx_comm *m = static_cast<gsx_comm *>(c->comm);
+    if (m->aborted) GSX_FAIL("gsx_comm: the communicator was aborted");
     GSX_HIP(hipSetDevice(c->device));
     if (m->hw) {
         GSX_HIP(hipStreamSynchronize(c->stream));

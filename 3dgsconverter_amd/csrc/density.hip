@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void voxel_count_kernel(const float *__restric
                                                           const float *__restrict__ z, int64_t stride, int64_t n,
                                                           float voxel, const VoxelFrame *__restrict__ vfp,
                                                           unsigned long long *__restrict__ tkeys, unsigned *__restrict__ tkb,
-                                                          unsigned *__restrict__ tcnt, unsigned tmask)
+                                                          unsigned *__restrict__ tcnt, unsigned tmask,
+                                                          unsigned *__restrict__ oob /* nullable: the frame came from a caller's box */)
 {
     __shared__ unsigned long long lkeys[VOX_LDS];
     __shared__ unsigned lkb[WIDE ? VOX_LDS : 1];
@@ -201,8 +202,19 @@ __global__ __launch_bounds__(256) void voxel_count_kernel(const float *__restric
         for (int j = threadIdx.x; j < VOX_TILE; j += 256) {
             int64_t i = t * VOX_TILE + j;
             if (i >= n) break;
-            const VKey key = pack_key<WIDE>(f, voxel_key(x[i * stride], voxel), voxel_key(y[i * stride], voxel),
-                                            voxel_key(z[i * stride], voxel));
+            const int kx = voxel_key(x[i * stride], voxel), ky = voxel_key(y[i * stride], voxel), kz = voxel_key(z[i * stride], voxel);
+            if (oob) {
+                // A frame derived from a box the CALLER supplied is only a promise: a row outside it would wrap in pack_key
+                // and collide with a valid voxel, and more distinct keys than the table was sized for would make the linear
+                // probe spin forever.  Such a row is not inserted; the host sees the flag and repeats the
+                // call with the frame of the rows themselves.
+                if ((unsigned)(kx - f.kmin[0]) >= (unsigned)f.dim[0] || (unsigned)(ky - f.kmin[1]) >= (unsigned)f.dim[1] ||
+                    (unsigned)(kz - f.kmin[2]) >= (unsigned)f.dim[2]) {
+                    *oob = 1u;
+                    continue;
+                }
+            }
+            const VKey key = pack_key<WIDE>(f, kx, ky, kz);
             unsigned h = hash_vkey<WIDE>(key) & (VOX_LDS - 1);
             bool done = false;
             for (int probe = 0; probe < 8 && !done; ++probe) {
@@ -403,14 +415,14 @@ static int collect_dense(gsx_ctx *c, const VoxelFrame &hvf, const VoxTable &t, i
 }
 
 static int count_points(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, float voxel,
-                        const VoxelFrame *dvf, const VoxTable &t)
+                        const VoxelFrame *dvf, const VoxTable &t, unsigned *oob = nullptr)
 {
     if (t.wide)
         hipLaunchKernelGGL((voxel_count_kernel<true>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
-                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1));
+                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1), oob);
     else
         hipLaunchKernelGGL((voxel_count_kernel<false>), dim3(blocks_for(c, n, VOX_TILE)), dim3(256), 0, c->stream, x, y, z, stride, n,
-                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1));
+                           voxel, dvf, t.tkeys, t.tkb, t.tcnt, (unsigned)(t.tsize - 1), oob);
     GSX_HIP(hipGetLastError());
     return 0;
 }
@@ -649,6 +661,7 @@ constexpr int CL_MAX = 1024;
 
 struct ClusterOut {          // device-side result block (gsx_density_info's device half)
     unsigned n_unique, n_dense, n_kept_voxels, kept_clusters, largest, status;
+    unsigned oob, pad;       // oob: a row fell outside the frame derived from the caller's box -- nothing of this block is valid
 };
 
 template <bool WIDE>
@@ -680,6 +693,8 @@ __global__ __launch_bounds__(256) void voxel_cluster_kernel(const unsigned long 
         out->kept_clusters = 0;
         out->largest = 0;
         out->status = D == 0 ? 1u : ((D > (unsigned)CL_MAX || D > dense_cap) ? 2u : 0u);
+        out->oob = counters[2];
+        out->pad = 0;
     }
     if (D == 0 || D > (unsigned)CL_MAX || D > dense_cap) return;
     // ---- sorted keys (np.unique's row order; the mask kernel's binary search needs it too): bitonic sort, padded with max keys
@@ -895,14 +910,14 @@ int density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *
     const int64_t dense_cap = std::min<int64_t>(n, n / std::max<int64_t>(min_points, 1) + 1);
     const size_t cap = (size_t)std::max<int64_t>(std::min<int64_t>(dense_cap, CL_MAX + 1), 1);
     GSX_CHECK(alloc_table(c, hvf, n, 16 * cap + 64 + 12 * (size_t)CL_MAX + 64, &t));
-    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t));
     unsigned long long *okeys = reinterpret_cast<unsigned long long *>(t.out_base);
     unsigned *ocnt = reinterpret_cast<unsigned *>(t.out_base + sizeof(unsigned long long) * cap);
     unsigned *okb = ocnt + cap;
     unsigned *ctr = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(okb + cap) + 15) & ~(uintptr_t)15);
     unsigned long long *kept_a = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctr) + 32);
     unsigned *kept_b = reinterpret_cast<unsigned *>(kept_a + CL_MAX);
-    GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));
+    GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));   // [0] unique, [1] dense, [2] a row outside the caller's box
+    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t, from_box ? ctr + 2 : nullptr));
     const unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
     hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)t.tsize, 1024)), dim3(256), 0, c->stream, t.tkeys, t.tkb,
                        t.tcnt, (unsigned)t.tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
@@ -922,6 +937,8 @@ int density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *
     ClusterOut h;
     GSX_HIP(hipMemcpyAsync(&h, dco, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));      // the call's one synchronisation
+    if (from_box && h.oob)   // the box was not a superset of the rows: once more with the frame of the rows themselves
+        return density_filter_dev(c, x, y, z, stride, n, voxel_size, min_points, keep_multi, nullptr, mask_dev, info);
     info->status = (int32_t)h.status;
     info->n_unique = h.n_unique;
     info->n_dense = h.n_dense;

@@ -551,7 +551,21 @@ int gsx_slab_plan(const uint32_t *words, int world, int rank, int64_t n_local, i
  * [the step's one host synchronisation: plan] -> partition -> rows to the slab owners (+ halo) -> exact KNN -> certificate
  * -> all-reduce -> means back -> un-permute -> numpy-exact statistics from all-gathered piece sums -> mask.
  * Returns 0 with out->status != 0 when the step declines (decided from gathered data: every rank declines together). */
+static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, int k, double threshold_factor, double halo_cells,
+                          uint8_t *mask_out_dev, gsx_slab_step_t *out);
+
 int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, int k, double threshold_factor, double halo_cells,
+                          uint8_t *mask_out_dev, gsx_slab_step_t *out)
+{
+    // A rank that fails BETWEEN collectives (a reservation, the planner's row-count check, a launch) would leave its peers
+    // blocked in the next one: every error exit tells them (hostwire: their barriers fail at once; RCCL: ncclCommAbort of
+    // this rank's communicator, the peers' watchdog -- launch.comm_watchdog -- ends them).  ADVICE round 4.
+    const int rc = slab_step_body(c, rows_dev, n_local, k, threshold_factor, halo_cells, mask_out_dev, out);
+    if (rc != 0 && c && c->comm) gsx_comm_abort(c);
+    return rc;
+}
+
+static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, int k, double threshold_factor, double halo_cells,
                           uint8_t *mask_out_dev, gsx_slab_step_t *out)
 {
     if (!c || !out || n_local < 0 || (n_local > 0 && !rows_dev)) GSX_FAIL("gsx_sor_slab_step_dev: bad arguments");

@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_anyk_kernel(GridParams *__r
                 if (covers) {   // N < k + 1: cKDTree pads with inf -> the mean is inf
                     if (lane == 0) {
                         mean_out[(int)__float_as_uint(qp.w) - q_begin] = __builtin_inff();
-                        if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = __builtin_inf();
+                        kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, __builtin_inf(), qp.x, qp.y, qp.z);
                     }
                     break;
                 }
@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_anyk_kernel(GridParams *__r
             if (lane == 0) {
                 const double sum = pairwise_sum_np<5>([&](int i) { return sel[1 + i]; }, 0, k);   // entry 0 is the query itself
                 mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
-                if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+                kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, kth, qp.x, qp.y, qp.z);   // (slab mode: the certificate is counted here)
                 if (covers && !(kth <= rH * rH)) atomicAdd(&gp->exhaustive_count, 1u);
             }
             wave_sync();
@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void knn_heavy_merge_kernel(GridPara
         atomicAdd(&gp->exhaustive_count, 1u);
         double sum = pairwise_sum_le128([&](int i) { return out[1 + i]; }, k);
         mean_out[(int)__float_as_uint(qp.w) - q_begin] = __double2float_rn(__ddiv_rn(sum, (double)k));
-        if (kth_out) kth_out[(int)__float_as_uint(qp.w) - q_begin] = kth;
+        kth_emit(gp, kth_out, (int)__float_as_uint(qp.w) - q_begin, kth, qp.x, qp.y, qp.z);   // (slab mode: the certificate is counted here)
     }
 }
 
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(256) void merge_sub_kernel(GridParams *__restrict__
     const double kth = subkth[i];
     if (rsafe > 0.0f && kth <= (double)rsafe * (double)rsafe) {
         mean_out[orig - q_begin] = submean[i];
-        if (kth_out) kth_out[orig - q_begin] = kth;
+        kth_emit(gp, kth_out, orig - q_begin, kth, q[0], q[1], q[2]);
     } else {
         faillist[atomicAdd(&gp->fail_count, 1u)] = sub_sorted[i];
     }

@@ -45,14 +45,61 @@ def _parent_tag() -> str:
     return "%d_%s" % (ppid, start)
 
 
+def _rendezvous_dir() -> str:
+    """a directory only this user can enter (0700, owned by us, not a symlink): the id and device files of a job are not
+    plantable or readable by another local user"""
+    d = os.path.join(tempfile.gettempdir(), "gsx_rdzv_u%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("rendezvous directory %s is not a private directory of uid %d" % (d, os.getuid()))
+    return d
+
+
 def rendezvous_path() -> str:
     """the file the unique id travels through: GSX_RDZV_FILE (spawn_ranks sets it) or a name every rank of one launcher
-    derives identically (parent process identity + MASTER_PORT + torchrun's run id)"""
+    derives identically (parent process identity + MASTER_PORT + torchrun's run id + its restart count: workers restarted
+    by the same launcher must not meet the id file of the attempt that died)"""
     p = os.environ.get("GSX_RDZV_FILE")
     if p:
         return p
-    tag = "%s_%s_%s" % (_parent_tag(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
-    return os.path.join(tempfile.gettempdir(), "gsx_rdzv_" + "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in tag))
+    tag = "%s_%s_%s_r%s" % (_parent_tag(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return os.path.join(_rendezvous_dir(), "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in tag))
+
+
+def _write_private(path: str, data: bytes):
+    """atomic publish: an exclusive, no-follow temporary (a pre-placed symlink or file makes it fail, not follow), renamed"""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    try:
+        os.write(fd, data)
+        os.fsync(fd)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)   # atomic: a reader sees nothing or everything
+
+
+def _read_private(path: str):
+    """bytes of a file of OURS, or None while it does not exist (never follows a symlink)"""
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except FileNotFoundError:
+        return None
+    try:
+        if os.fstat(fd).st_uid != os.getuid():
+            raise PermissionError("%s is not owned by uid %d" % (path, os.getuid()))
+        return os.read(fd, 4096)
+    finally:
+        os.close(fd)
 
 
 def exchange_unique_id(rank: int, make_id, path: str | None = None, timeout_s: float = 300.0) -> bytes:
@@ -60,22 +107,13 @@ def exchange_unique_id(rank: int, make_id, path: str | None = None, timeout_s: f
     path = path or rendezvous_path()
     if rank == 0:
         uid = make_id()
-        tmp = "%s.tmp%d" % (path, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(uid)
-            f.flush()
-            os.fsync(f.fileno())
-        os.replace(tmp, path)   # atomic: a reader sees nothing or all 128 bytes
+        _write_private(path, uid)
         return uid
     t0 = time.time()
     while True:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
-        except FileNotFoundError:
-            pass
+        uid = _read_private(path)
+        if uid is not None and len(uid) == 128:
+            return uid
         if time.time() - t0 > timeout_s:
             raise TimeoutError("rank %d: no unique id at %s after %.0f s (did rank 0 start?)" % (rank, path, timeout_s))
         time.sleep(0.01)
@@ -110,23 +148,16 @@ def agree_transport(rank: int, world: int, device_uid: str, path: str | None = N
     if forced:
         return forced
     path = path or rendezvous_path()
-    mine = "%s.dev%d" % (path, rank)
-    tmp = "%s.tmp%d" % (mine, os.getpid())
-    with open(tmp, "w") as f:
-        f.write(device_uid + "\n")
-    os.replace(tmp, mine)
+    _write_private("%s.dev%d" % (path, rank), (device_uid + "\n").encode())
     seen, t0 = {}, time.time()
     while len(seen) < world:
         for r in range(world):
             if r in seen:
                 continue
-            try:
-                with open("%s.dev%d" % (path, r)) as f:
-                    txt = f.read()
-                if txt.endswith("\n"):
-                    seen[r] = txt.strip()
-            except FileNotFoundError:
-                pass
+            raw = _read_private("%s.dev%d" % (path, r))
+            txt = raw.decode() if raw is not None else ""
+            if txt.endswith("\n"):
+                seen[r] = txt.strip()
         if len(seen) < world:
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("rank %d: %d of %d ranks announced their device at %s.dev*" % (rank, len(seen), world, path))

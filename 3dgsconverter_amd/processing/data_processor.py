@@ -84,7 +84,11 @@ class DataProcessor:
     def data(self, value):
         # a deferred cap_sh_degree belongs to the table it was called on: the reference zeroes that table at once
         # (data_processor.py:313), so it is applied to the OLD table before the new one replaces it
-        if self._pending_zero and isinstance(self._data, np.ndarray):
+        # -- unless a filter's compaction is still pending in the chain: the reference had by then replaced self.data
+        # with the filtered COPY and zeroed that, leaving the caller's array alone; the copy would be discarded here, so
+        # the pending fills are simply dropped
+        compaction_pending = self._chain is not None and self._chain.n != self._chain.n0
+        if self._pending_zero and isinstance(self._data, np.ndarray) and not compaction_pending:
             names, self._pending_zero = self._pending_zero, []
             _lib.host_zero_columns(self._data, names)
         self._pending_zero = []

@@ -156,3 +156,27 @@ def test_lazy_cap_sh_degree_belongs_to_the_table_it_was_called_on():
     proc.data = b
     assert float(a["f_rest_9"].sum()) == 0.0 and float(a["f_rest_44"].sum()) == 0.0 and float(a["f_rest_8"].sum()) == 50.0
     assert proc.data is b and float(b["f_rest_9"].sum()) == 60.0                     # the new table is untouched
+
+
+def test_lazy_cap_sh_degree_with_a_pending_compaction_leaves_the_callers_array_alone():
+    """filters pending in the chain + a deferred cap_sh_degree + `processor.data = other`: the reference had
+    replaced self.data with the filtered COPY before it zeroed anything, so the caller's original array stays untouched"""
+    import importlib
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    dt = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4")] + [("f_rest_%d" % i, "f4") for i in range(45)])
+    a, b = np.ones(50, dtype=dt), np.ones(30, dtype=dt)
+    for name in dt.names:
+        a[name], b[name] = 1.0, 2.0
+
+    class Chain:   # what a DeviceChain looks like after a filter removed rows (no GPU needed for the setter's decision)
+        n0, n, closed = 50, 20, False
+
+        def close(self):
+            self.closed = True
+
+    proc = dp.DataProcessor(a, lazy=True)
+    proc._chain = ch = Chain()
+    assert proc.cap_sh_degree(1) is None
+    proc.data = b
+    assert ch.closed and float(a["f_rest_9"].sum()) == 50.0 and float(a["f_rest_44"].sum()) == 50.0
+    assert proc.data is b and float(b["f_rest_9"].sum()) == 60.0
