@@ -314,6 +314,40 @@ __device__ __forceinline__ float mean_from_list(const TopList<KCAP> &lst, int k)
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// ---- whole-wave reductions without address registers (round 5) --------------------------------------------------------
+// __shfl_xor(v, off) is ds_bpermute with a per-lane ADDRESS ((lane ^ off) << 2).  The compiler computes the six address
+// registers of a butterfly once and keeps them for every later butterfly of the kernel -- in knn_leaf that meant six
+// dwords per lane spilled to scratch per leaf.  ds_swizzle (bit-mask mode: lane ^ OFF inside each half-wave, the pattern is an
+// immediate) and v_permlane32_swap (the two half-waves) need no address at all.  Every lane gets the result.
+template <int OFF>
+__device__ __forceinline__ int swz_xor(int v)   // v of lane (l ^ OFF), OFF < 32
+{
+    return __builtin_amdgcn_ds_swizzle(v, (OFF << 10) | 0x1f);
+}
+template <class Op>
+__device__ __forceinline__ int wave_reduce_bits(int v, Op op)   // op: (int, int) -> int on the value's bit pattern
+{
+    v = op(v, swz_xor<1>(v));
+    v = op(v, swz_xor<2>(v));
+    v = op(v, swz_xor<4>(v));
+    v = op(v, swz_xor<8>(v));
+    v = op(v, swz_xor<16>(v));
+    // (x, y) = (v, v) -> x' = [v.lo | v.lo], y' = [v.hi | v.hi]: lane l holds v[l mod 32] and v[l mod 32 + 32]
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return op((int)r[0], (int)r[1]);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return wave_reduce_bits(v, [](int a, int b) { return a + b; }); }
+__device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_bits(v, [](int a, int b) { return a < b ? a : b; }); }
+__device__ __forceinline__ int wave_max_i32(int v) { return wave_reduce_bits(v, [](int a, int b) { return a > b ? a : b; }); }
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+    return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); }));
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); }));
+}
+
 // wave-uniform value known to the compiler as scalar
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Values the optimiser must not hoist out of a loop or a branch: whatever is computed from the result stays where the

@@ -49,7 +49,10 @@ namespace gsx {
 constexpr int MAX_DIM = 1024;       // cells per axis (keeps the cell-index rounding bound, see r_safe)
 constexpr int MAX_BUCKETS = 4096;         // LDS histogram bins of the coarse pass
 constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 KiB)
-constexpr int BUCKET_POINTS = 4096;       // target points per bucket
+#ifndef GSX_BUCKET_POINTS
+#define GSX_BUCKET_POINTS 4096
+#endif
+constexpr int BUCKET_POINTS = GSX_BUCKET_POINTS;   // target points per bucket (tuning builds: -DGSX_BUCKET_POINTS, with GSX_SORT_THREADS)
 constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass (4096 / 16384: no better)
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
@@ -497,8 +500,14 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bucket_scatter_kernel(const f
     }
 }
 
-constexpr int SORT_THREADS = 512;
-constexpr int SORT_PPT = 16;                          // points per thread kept in registers
+#ifndef GSX_SORT_THREADS
+#define GSX_SORT_THREADS 512
+#endif
+#ifndef GSX_SORT_PPT
+#define GSX_SORT_PPT 16
+#endif
+constexpr int SORT_THREADS = GSX_SORT_THREADS;
+constexpr int SORT_PPT = GSX_SORT_PPT;                // points per thread kept in registers
 constexpr unsigned SORT_CAP = SORT_THREADS * SORT_PPT;  // buckets up to 8192 points are read ONCE
 
 __global__ __launch_bounds__(SORT_THREADS) void bucket_sort_kernel(const GridParams *__restrict__ gp,

@@ -30,7 +30,14 @@ __device__ __forceinline__ float elem(float v, float mean)
     return v;
 }
 
-constexpr int CHUNK_THREADS = 128;  // one workgroup (2 waves) per 8192-element piece
+// Round 5: one WAVE per 8192-element piece, four pieces per 256-thread workgroup (GSX_CS_WAVE=1, default): no LDS, no
+// barrier and a quarter of the workgroups / arrival tickets of the two-wave version (GSX_CS_WAVE=0: round 1-4, one
+// 128-thread workgroup per piece).
+#ifndef GSX_CS_WAVE
+#define GSX_CS_WAVE 1
+#endif
+constexpr int CHUNK_THREADS = GSX_CS_WAVE ? 256 : 128;
+constexpr int CHUNK_PIECES = GSX_CS_WAVE ? 4 : 1;   // pieces per workgroup
 
 // numpy's split: left half = n/2 rounded down to a multiple of 8
 __device__ __forceinline__ int np_split(int n)
@@ -146,6 +153,7 @@ struct StatsFold {
 template <bool SQ>
 __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int64_t n, const float *__restrict__ stats,
                                                float *__restrict__ chunk_sum);
+__host__ __device__ constexpr int64_t chunk_blocks(int64_t nchunks) { return (nchunks + CHUNK_PIECES - 1) / CHUNK_PIECES; }
 
 template <bool SQ>
 __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *__restrict__ a, int64_t n,
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(CHUNK_THREADS) void chunk_sums_kernel(const float *
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) *fold.ticket = 0;
-    stats_finalize_body(chunk_sum, n, (int64_t)gridDim.x, SQ ? 1 : 0, fold.factor, fold.stats_out);
+    stats_finalize_body(chunk_sum, n, (n + NP_BUF - 1) / NP_BUF, SQ ? 1 : 0, fold.factor, fold.stats_out);
 }
 
 template <bool SQ>
@@ -171,11 +179,48 @@ __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int6
     __shared__ int s_leaf_start[160];
     __shared__ int s_leaf_len[160];
     __shared__ float s_leaf_val[160];
-    __shared__ float s_half[2];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int64_t c = blockIdx.x;
     const float mean = SQ ? stats[0] : 0.0f;
+    const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
+#if GSX_CS_WAVE
+    // ---- wave wv of the workgroup owns piece 4 * blockIdx.x + wv.  A full piece = 64 leaves of 128 elements; two lanes per
+    // leaf: lane (leaf, hh) owns accumulators 4hh..4hh+3 (numpy's r[0..7]) and walks the leaf's 16 rows with one 16-byte
+    // load per row; the wave takes leaves 0..31, then 32..63 (16 loads in flight each time) and combines the two 4096-element
+    // halves -- the balanced tree numpy's recursion produces for 8192.
+    int64_t c = (int64_t)blockIdx.x * CHUNK_PIECES + wv;
+    const bool ragged_block = (n % NP_BUF) != 0 && (int64_t)blockIdx.x == chunk_blocks(nchunks) - 1;   // block-uniform: it holds the ragged piece
+    if (c < n / NP_BUF) {   // wave-uniform: a full piece
+        const float *pp = a + c * NP_BUF;
+        float half[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int leaf = hf * 32 + (lane >> 1), hh = lane & 1;
+            const float4 *q = reinterpret_cast<const float4 *>(pp + leaf * 128 + hh * 4);
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = q[2 * i];  // +8 floats per row
+            float r0 = elem<SQ>(v[0].x, mean), r1 = elem<SQ>(v[0].y, mean), r2 = elem<SQ>(v[0].z, mean), r3 = elem<SQ>(v[0].w, mean);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                r0 += elem<SQ>(v[i].x, mean); r1 += elem<SQ>(v[i].y, mean); r2 += elem<SQ>(v[i].z, mean); r3 += elem<SQ>(v[i].w, mean);
+            }
+            float s = (r0 + r1) + (r2 + r3);      // (r0+r1)+(r2+r3)  |  (r4+r5)+(r6+r7)
+            s = s + __shfl_xor(s, 1);             // leaf sum (both lanes of the pair hold it)
+#pragma unroll
+            for (int off = 2; off < 64; off <<= 1) s = s + __shfl_xor(s, off);   // 128 -> 256 -> ... -> 4096
+            half[hf] = s;
+        }
+        if (lane == 0) __hip_atomic_store(&chunk_sum[c], half[0] + half[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 4096 + 4096
+    }
+    if (!ragged_block) return;
+    // the ragged last piece: the whole workgroup (the waves that summed full pieces above included)
+    c = n / NP_BUF;
+    const float *p = a + c * NP_BUF;
+    const int len = (int)(n - c * NP_BUF);
+#else
+    __shared__ float s_half[2];
+    const int64_t c = blockIdx.x;
     const float *p = a + c * NP_BUF;
     const int len = (int)((n - c * NP_BUF) < NP_BUF ? (n - c * NP_BUF) : NP_BUF);
 
@@ -203,6 +248,7 @@ __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int6
         if (threadIdx.x == 0) __hip_atomic_store(&chunk_sum[c], s_half[0] + s_half[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 4096 + 4096
         return;
     }
+#endif
 
     // ragged last piece.  Every leaf of numpy's recursion is >= 57 elements, so it contains a multiple
     // of 32: each thread descends the recursion for two such positions (registers only) and the
@@ -211,12 +257,12 @@ __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int6
     // the tree over the leaf sums with a compile-time-expanded recursion.
     int *ls = s_leaf_start, *ll = s_leaf_len;
     float *lv = s_leaf_val;
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[CHUNK_THREADS / 64];
     int my_lo[2], my_n[2];
     bool own[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int pos = 32 * ((int)threadIdx.x * 2 + u);   // positions in increasing thread order
+        const int pos = 32 * ((int)threadIdx.x * 2 + u);   // positions in increasing thread order (threads >= 128: beyond any piece)
         own[u] = false;
         my_lo[u] = 0; my_n[u] = 0;
         if (pos < len || (pos == 0 && len > 0)) {
@@ -234,8 +280,12 @@ __device__ __forceinline__ void chunk_sum_body(const float *__restrict__ a, int6
     }
     if (lane == 63) s_cnt[wv] = inc;
     __syncthreads();
-    int rank = inc - mine + (wv == 1 ? s_cnt[0] : 0);
-    const int nleaf = s_cnt[0] + s_cnt[1];
+    int rank = inc - mine, nleaf = 0;
+#pragma unroll
+    for (int i = 0; i < CHUNK_THREADS / 64; ++i) {
+        if (i < wv) rank += s_cnt[i];
+        nleaf += s_cnt[i];
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
         if (own[u]) {
@@ -298,7 +348,7 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
     const int64_t nchunks = (n + NP_BUF - 1) / NP_BUF;
     GSX_CHECK(ctx->statspart.reserve(sizeof(float) * (size_t)nchunks));
     float *cs = ctx->statspart.as<float>();
-    const int blocks = (int)nchunks;
+    const int blocks = (int)chunk_blocks(nchunks);
     const float tf = (float)factor;  // python float is a weak scalar: rounded to f32 first
     const StatsFold fold{ctx->devflags.as<unsigned>() + 8, tf, stats_dev};   // word 8 of the flag block: arrival ticket
     hipLaunchKernelGGL((chunk_sums_kernel<false>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, md, n, stats_dev, cs, fold);
@@ -311,7 +361,7 @@ int launch_sor_stats(gsx_ctx *ctx, const float *md, int64_t n, double factor, fl
 // so the piece sums can be computed wherever the elements live and combined anywhere, bit-exactly.
 int launch_sor_piece_sums(gsx_ctx *ctx, const float *a, int64_t n, const float *mean_dev, float *piece_out)
 {
-    const int blocks = (int)((n + NP_BUF - 1) / NP_BUF);
+    const int blocks = (int)chunk_blocks((n + NP_BUF - 1) / NP_BUF);
     if (mean_dev)
         hipLaunchKernelGGL((chunk_sums_kernel<true>), dim3(blocks), dim3(CHUNK_THREADS), 0, ctx->stream, a, n, mean_dev, piece_out, StatsFold{nullptr, 0.0f, nullptr});
     else

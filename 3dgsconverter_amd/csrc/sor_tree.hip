@@ -633,6 +633,17 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     // per mask word: the (pre-adjusted) first index of up to four key ranges and where in the word each one ends
     __shared__ unsigned s_wb[TREE_THREADS / 64][4][TWCAP];
     __shared__ unsigned s_wcut[TREE_THREADS / 64][TWCAP];
+    // Per-leaf geometry, wave-uniform, PARKED IN LDS (round 5).  These values are computed on the VALU (there is no scalar
+    // float64 unit), so each of them is a VGPR -- and at 96 VGPRs the register allocator kept them alive across the batch
+    // loop by spilling them per LANE: 26 dwords x 64 lanes of scratch written per leaf, 2.2 GB per 10M-splat launch
+    // (profiles/r04_tree_pmc_floaters_10m.txt).  One lane writes the record once per leaf; the uses read it back through a
+    // volatile pointer (a broadcast ds_read at the point of use, nothing for the allocator to keep).
+    struct LeafRec {
+        double plane_lo[3], plane_hi[3];   // faces of the searched box with space behind them (-inf / +inf: none)
+        double r_f, cell;
+        float ccx, ccy, ccz, inv_h;
+    };
+    __shared__ LeafRec s_rec[TREE_THREADS / 64];
 
     if (tp->bad_input) return;
     const int lane = lane_id();
@@ -640,6 +651,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     unsigned(*mask)[64] = s_mask[wv];
     unsigned *wb0 = s_wb[wv][0], *wb1 = s_wb[wv][1], *wb2 = s_wb[wv][2], *wb3 = s_wb[wv][3];
     unsigned *wcut = s_wcut[wv];
+    volatile LeafRec *rec = &s_rec[wv];
 
     const int n = tp->n;
     const int nblk = (n + KEY_BLOCK - 1) / KEY_BLOCK;
@@ -707,20 +719,33 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             rs_start = __builtin_amdgcn_ds_permute(dst << 2, r_lo);
             rs_len = __builtin_amdgcn_ds_permute(dst << 2, r_len);
         }
-        int ncand = rs_len;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off);
-        ncand = uniform(ncand);
+        const int ncand = uniform(wave_sum_i32(rs_len));
 
-        // geometry shared by the batches of this leaf
-        const double cell = uniform_f64(s * (double)(1 << Lc));   // cell edge (real units)
-        const float g_inv_h = uniform_f32((float)(1.0 / cell));
-        const float ccx = uniform_f32((float)(ox + ((double)fx + 0.5 * (double)(1 << bxb)) * s));
-        const float ccy = uniform_f32((float)(oy + ((double)fy + 0.5 * (double)(1 << byb)) * s));
-        const float ccz = uniform_f32((float)(oz + ((double)fz + 0.5 * (double)(1 << bzb)) * s));
-        // radius inside which ~2 (k+1) points are expected at the leaf's own density (the uniform grid's cell edge), x rf_scale
-        const double vol = s * s * s * ldexp(1.0, bl);
-        const double r_f = uniform_f64((GSX_TREE_ABL & 32) ? 1e30 : (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1)));
+        // geometry shared by the batches of this leaf -> the wave's LDS record
+        {
+            const double cell = s * (double)(1 << Lc);   // cell edge (real units)
+            const double vol = s * s * s * ldexp(1.0, bl);
+            // radius inside which ~2 (k+1) points are expected at the leaf's own density (the uniform grid's cell edge), x rf_scale
+            const double r_f = (GSX_TREE_ABL & 32) ? 1e30 : (double)rf_scale * cbrt(0.397 * (double)(k + 1) * vol / (double)max(nq, 1));
+            wave_sync();   // the previous leaf's last reads of the record are done
+            if (lane == 0) {
+                const double od[3] = {ox, oy, oz};
+                const int c0[3] = {CX0, CY0, CZ0};
+                const int rr[3] = {rx, ry, rz};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    rec->plane_lo[a] = c0[a] > 0 ? od[a] + (double)c0[a] * cell : -__builtin_inf();
+                    rec->plane_hi[a] = c0[a] + rr[a] < cmax ? od[a] + (double)(c0[a] + rr[a]) * cell : __builtin_inf();
+                }
+                rec->r_f = r_f;
+                rec->cell = cell;
+                rec->ccx = (float)(ox + ((double)fx + 0.5 * (double)(1 << bxb)) * s);
+                rec->ccy = (float)(oy + ((double)fy + 0.5 * (double)(1 << byb)) * s);
+                rec->ccz = (float)(oz + ((double)fz + 0.5 * (double)(1 << bzb)) * s);
+                rec->inv_h = (float)(1.0 / cell);
+            }
+            wave_sync();
+        }
         const bool irregular = ncand > TREE_CAND_LIMIT;
 
         for (int qb = 0; qb < nq; qb += 64) {
@@ -740,12 +765,10 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 float lo3[3] = {live ? qx : 3.0e38f, live ? qy : 3.0e38f, live ? qz : 3.0e38f};
                 float hi3[3] = {live ? qx : -3.0e38f, live ? qy : -3.0e38f, live ? qz : -3.0e38f};
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], off));
-                        hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], off));
-                    }
+                for (int a = 0; a < 3; ++a) {
+                    lo3[a] = wave_min_f32(lo3[a]);
+                    hi3[a] = wave_max_f32(hi3[a]);
+                }
                 const double e3[3] = {(double)hi3[0] - (double)lo3[0], (double)hi3[1] - (double)lo3[1], (double)hi3[2] - (double)lo3[2]};
                 const double emx = fmax(fmax(e3[0], e3[1]), e3[2]);
                 const double vt = fmax(e3[0], 1e-3 * emx) * fmax(e3[1], 1e-3 * emx) * fmax(e3[2], 1e-3 * emx);
@@ -757,23 +780,27 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 }
                 continue;
             }
-            // ---- acceptance radius: distance to the nearest face of the searched box with space behind it, capped at r_f
-            double racc_sq;
-            {
-                double rs = r_f;
-                const double qd[3] = {(double)qx, (double)qy, (double)qz};
-                const double od[3] = {ox, oy, oz};
-                const int c0[3] = {CX0, CY0, CZ0};
-                const int rr[3] = {rx, ry, rz};
+            // ---- acceptance radius: distance to the nearest face of the searched box with space behind it, capped at r_f.
+            // Evaluated TWICE from the wave's LDS record (here for the filter bound, after phase 2 for the acceptance test)
+            // instead of carried through both phases in two registers per lane, and from coordinates widened on the spot
+            // (pinned: the float64 copies of qx, qy, qz would otherwise be shared with phase 2's and live -- i.e. spilled --
+            // across the matrix-core loop).  Same inputs, same instructions: the same bits both times.
+            auto accept_radius_sq = [&]() __attribute__((always_inline)) {
+                double rs = rec->r_f;
+                const double qd[3] = {(double)pinned_here(qx), (double)pinned_here(qy), (double)pinned_here(qz)};
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (c0[a] > 0) rs = fmin(rs, (qd[a] - uniform_f64(od[a] + (double)c0[a] * cell)) - slack);
-                    if (c0[a] + rr[a] < cmax) rs = fmin(rs, (uniform_f64(od[a] + (double)(c0[a] + rr[a]) * cell) - qd[a]) - slack);
+                for (int a = 0; a < 3; ++a) {   // (no face: -inf / +inf, the distance is +inf and fmin keeps rs)
+                    rs = fmin(rs, (qd[a] - rec->plane_lo[a]) - slack);
+                    rs = fmin(rs, (rec->plane_hi[a] - qd[a]) - slack);
                 }
                 rs = fmax(rs, 0.0);
-                racc_sq = rs * rs;
+                return rs * rs;
+            };
+            float tau;
+            {
+                const double racc_sq = accept_radius_sq();
+                tau = is_query ? bound_from(racc_sq) : -1.0f;
             }
-            float tau = is_query ? bound_from(racc_sq) : -1.0f;
 
             Net lst;
             bool lst_empty = true;
@@ -782,7 +809,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
 
             // ---- phase 2 (as knn_brick's): walk this lane's set bits, exact float64 distances, network selection
             auto drain = [&]() __attribute__((always_inline)) {
-                const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
+                const double qxd = (double)pinned_here(qx), qyd = (double)pinned_here(qy), qzd = (double)pinned_here(qz);
                 wave_sync();
                 if (GSX_TREE_ABL & 1) nzw = 0;
                 unsigned m = 0, cut = 0x202020u;
@@ -861,6 +888,8 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             bool parked = ncand <= TWCAP * 32;
             if (parked) {
                 // ---- phase 1, matrix cores: cell-unit coordinates relative to the leaf centre (|u| <= 2); see knn_mfma.h
+                const float ccx = uniform_f32(rec->ccx), ccy = uniform_f32(rec->ccy), ccz = uniform_f32(rec->ccz);
+                const float g_inv_h = uniform_f32(rec->inv_h);
                 const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
                 const float nq2 = __builtin_fmaf(uqz, uqz, __builtin_fmaf(uqy, uqy, uqx * uqx));
                 const bool upper = lane >= 32;
@@ -943,6 +972,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
 
             if (is_query) {
                 const double kth_d2 = lst.kth(k);
+                const double racc_sq = accept_radius_sq();
                 if (GSX_TREE_ABL) {
                     mean_out[qorig] = (float)kth_d2;   // keeps the list live, never fails
                 } else if (kth_d2 <= racc_sq) {
@@ -953,7 +983,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                     faillist[slot] = (unsigned)qidx;
                     // the filter only let candidates inside the acceptance radius through, of which there were fewer than k (a full
                     // list would bound the k-th distance): the next ball to try is 1.3x wider -- 2.2x the volume
-                    failbound[slot] = kth_d2 < __builtin_inf() ? kth_d2 : -fmax(1.69 * racc_sq, 0.25 * cell * cell);
+                    { const double cell = rec->cell; failbound[slot] = kth_d2 < __builtin_inf() ? kth_d2 : -fmax(1.69 * racc_sq, 0.25 * cell * cell); }
                 }
             }
         }
@@ -1092,12 +1122,17 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
                     break;
                 }
                 if (len <= 64u)
-                    for (unsigned j = 0; j < len; ++j) {   // a handful of points per cell: the lane that found it scans it
-                        const float4 p = refs[a0 + j];
-                        const double d = dist2_f64(qd[0], qd[1], qd[2], p.x, p.y, p.z);
-                        if (__float_as_uint(p.w) != self_w && d <= T) {
-                            const unsigned at = atomicAdd(cnt, 1u);
-                            if (at < (unsigned)TQ_CAND) cand[at] = d;
+                    for (unsigned j = 0; j < len; j += 4u) {   // a handful of points per cell: the lane that found it scans it,
+                        float4 p[4];                           // four loads in flight (round 5: one at a time was a chain of
+#pragma unroll                                                  // ~8 memory round trips per query)
+                        for (unsigned u = 0; u < 4u; ++u) p[u] = refs[a0 + (j + u < len ? j + u : j)];
+#pragma unroll
+                        for (unsigned u = 0; u < 4u; ++u) {
+                            const double d = dist2_f64(qd[0], qd[1], qd[2], p[u].x, p[u].y, p[u].z);
+                            if (j + u < len && __float_as_uint(p[u].w) != self_w && d <= T) {
+                                const unsigned at = atomicAdd(cnt, 1u);
+                                if (at < (unsigned)TQ_CAND) cand[at] = d;
+                            }
                         }
                     }
                 // a cell of up to TQ_DENSE points (the query sits at the edge of something denser): the whole wave takes it, block
