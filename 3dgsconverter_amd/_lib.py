@@ -157,6 +157,7 @@ SIGNATURES = {
     "gsx_density_hist_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, C.POINTER(_I64), _P, _P]),
     "gsx_density_merge_dev": (_I, [_P, _P, _P, _I64, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_kmeans_lloyd_dev": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
+    "gsx_kmeans_lloyd_batch_dev": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "gsx_quantize_sorted_codebook_dev": (_I, [_P, _P, _I64, _P, _I, _P]),
 }
 
@@ -491,6 +492,11 @@ def kmeans_lloyd_many(problems, max_iter: int, lanes: int = PALETTE_LANES, devic
     require_hip()
     if not problems:
         return []
+    shapes = {(p[0].shape[1], p[1].shape[0], p[1].shape[1]) for p in problems}
+    if len(shapes) == 1 and len(problems) > 1 and all(len(p[0]) > 0 for p in problems):
+        # the palette's usual case: every chunk the same d and k -> one batched call, the problem is a grid dimension
+        # (round 5: gsx_kmeans_lloyd_batch_dev; per problem the same kernels, launch order and arithmetic)
+        return kmeans_lloyd_batch(problems, max_iter, device)
     lanes = max(1, min(int(lanes), len(problems)))
     ctxs = [Context(device, own_stream=True) for _ in range(lanes)]
     out = [None] * len(problems)
@@ -524,6 +530,40 @@ def kmeans_lloyd_many(problems, max_iter: int, lanes: int = PALETTE_LANES, devic
         for c in ctxs:
             c.close()
     return out
+
+
+def kmeans_lloyd_batch(problems, max_iter: int, device: int = 0):
+    """problems of ONE shape (same d, same k): rows concatenated in HBM, gsx_kmeans_lloyd_batch_dev runs every iteration of
+    all of them as one set of launches -> list of (centroids f32[k,d], labels i32[n_p]) like kmeans_lloyd_many"""
+    require_hip()
+    d, k = problems[0][0].shape[1], problems[0][1].shape[0]
+    rows = [len(p[0]) for p in problems]
+    off = np.zeros(len(problems) + 1, dtype=np.int64)
+    np.cumsum(rows, out=off[1:])
+    n_total = int(off[-1])
+    ctx = Context(device)
+    bd = bc = bl = None
+    try:
+        bd, bc, bl = ctx.alloc(4 * n_total * d), ctx.alloc(4 * len(problems) * k * d), ctx.alloc(4 * n_total + 16)
+        keep = []
+        for i, (data, init) in enumerate(problems):   # chunk by chunk: no second host copy of the whole table
+            a = np.ascontiguousarray(data, dtype=np.float32)
+            b = np.ascontiguousarray(init, dtype=np.float32)
+            keep.append((a, b))
+            check(ctx.lib.gsx_dev_upload_async(ctx.handle, bd.ptr + 4 * d * int(off[i]), a.ctypes.data, a.nbytes), "gsx_dev_upload_async")
+            check(ctx.lib.gsx_dev_upload_async(ctx.handle, bc.ptr + 4 * k * d * i, b.ctypes.data, b.nbytes), "gsx_dev_upload_async")
+        check(ctx.lib.gsx_dev_memset(ctx.handle, bl.ptr, 0, 4 * n_total), "gsx_dev_memset")   # max_iter == 0: labels stay 0
+        check(ctx.lib.gsx_kmeans_lloyd_batch_dev(ctx.handle, bd.ptr, off.ctypes.data, len(problems), d, k, int(max_iter), bc.ptr, bl.ptr),
+              "gsx_kmeans_lloyd_batch_dev")
+        cent = bc.download(np.float32, len(problems) * k * d).reshape(len(problems), k, d)
+        lab = bl.download(np.int32, n_total)
+        del keep
+        return [(cent[i].copy(), lab[int(off[i]):int(off[i + 1])].copy()) for i in range(len(problems))]
+    finally:
+        for b in (bd, bc, bl):
+            if b is not None:
+                b.free()
+        ctx.close()
 
 
 def quantize_sorted_codebook(vals: np.ndarray, codebook: np.ndarray) -> np.ndarray:
@@ -708,6 +748,13 @@ class DeviceArray:
         out = np.empty(count, dtype=dtype)
         assert out.nbytes <= self.nbytes
         check(self.ctx.lib.gsx_dev_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "gsx_dev_download")
+        return out
+
+    def download_at(self, byte_offset: int, dtype, count: int) -> np.ndarray:
+        """`count` elements starting `byte_offset` bytes into the buffer"""
+        out = np.empty(count, dtype=dtype)
+        assert 0 <= byte_offset and byte_offset + out.nbytes <= self.nbytes
+        check(self.ctx.lib.gsx_dev_download(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes), "gsx_dev_download")
         return out
 
     def free(self):

@@ -98,6 +98,7 @@ int density_filter_dev(gsx_ctx *, const float *, const float *, const float *, i
 int density_mask_dev(gsx_ctx *, const float *, const float *, const float *, int64_t, int64_t, double, const int64_t *,
                      int64_t, uint8_t *);
 int kmeans_lloyd_dev(gsx_ctx *, const float *, int64_t, int, int, int, float *, int32_t *);
+int kmeans_lloyd_batch_dev(gsx_ctx *, const float *, const int64_t *, int, int, int, int, float *, int32_t *);
 int quantize_dev(gsx_ctx *, const float *, int64_t, const float *, int, uint8_t *);
 
 }  // namespace gsx
@@ -575,6 +576,15 @@ int gsx_kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, in
     if (max_iter < 0) GSX_FAIL("gsx_kmeans_lloyd_dev: negative max_iter");
     GSX_HIP(hipSetDevice(c->device));
     return kmeans_lloyd_dev(c, data_dev, n, d, k, max_iter, centroids_dev, labels_dev);
+}
+
+int gsx_kmeans_lloyd_batch_dev(gsx_ctx *c, const float *data_dev, const int64_t *row_off, int nprob, int d, int k, int max_iter,
+                               float *centroids_dev, int32_t *labels_dev)
+{
+    if (!c || !data_dev || !row_off || !centroids_dev || !labels_dev) GSX_FAIL("gsx_kmeans_lloyd_batch_dev: null argument");
+    if (max_iter < 0) GSX_FAIL("gsx_kmeans_lloyd_batch_dev: negative max_iter");
+    GSX_HIP(hipSetDevice(c->device));
+    return kmeans_lloyd_batch_dev(c, data_dev, row_off, nprob, d, k, max_iter, centroids_dev, labels_dev);
 }
 
 int gsx_kmeans_lloyd(const float *data, int64_t n, int d, int k, int max_iter, const float *init_centroids,

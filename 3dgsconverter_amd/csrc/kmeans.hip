@@ -213,6 +213,24 @@ __device__ __forceinline__ float km_med3(float a, float b, float c)
     return r;
 }
 
+// ---- many independent problems per launch (round 5: gsx_kmeans_lloyd_batch_dev) ------------------------------------------
+// The SOG palette is 64 independent Lloyd problems of the same shape (formats/sog.py:536-552).  Run one after the other --
+// or on a few concurrent streams -- their iterations are ~400 latency-bound launches; here every kernel of the matrix-core
+// path takes the PROBLEM from blockIdx.y and rebases its pointers: rows / labels / list by the problem's row offset,
+// centroids / sums by k*D, counts / starts / cursors by k, operand words and the meta block by their sizes.  One problem
+// (the former launches) is the batch of one: off == nullptr, blockIdx.y == 0, every offset 0.
+struct KmBatch {
+    const int64_t *off;   // device: nprob + 1 row offsets (nullptr: ONE problem of n1 rows)
+    int64_t n1;
+};
+__device__ __forceinline__ int64_t km_problem_rows(const KmBatch &b, int64_t &n)
+{
+    const int64_t r0 = b.off ? b.off[blockIdx.y] : 0;
+    n = b.off ? b.off[blockIdx.y + 1] - r0 : b.n1;
+    return r0;
+}
+constexpr int KM_META_WORDS = 32;   // per problem: 2 x 16 words, alternating by iteration
+
 constexpr int km_dp(int d) { return (d + 3 + 15) / 16 * 16; }  // K-dimension incl. the three |c|^2 slots: 16, 32, 48
 
 // Centroid operands for the whole iteration: for tile t (32 centroids), 16-dimension slice j, variant v (0 = high pieces
@@ -223,6 +241,9 @@ __global__ __launch_bounds__(64) void kmeans_centroid_operands_kernel(const floa
                                                                       ku32x4 *__restrict__ opnd, float *__restrict__ cmax2)
 {
     constexpr int DP = km_dp(D), NS = DP / 16;
+    cent += (size_t)blockIdx.y * k * D;                                  // problem blockIdx.y (KmBatch)
+    opnd += (size_t)blockIdx.y * ((k + 31) / 32) * NS * 2 * 64;
+    cmax2 += (size_t)blockIdx.y * KM_META_WORDS;
     const int t = blockIdx.x / NS, j = blockIdx.x % NS;
     const int lane = threadIdx.x;
     const int c = 32 * t + (lane & 31), k0 = 16 * j + 8 * (lane >> 5);
@@ -276,6 +297,12 @@ __global__ __launch_bounds__(64) void kmeans_finalize_operands_kernel(const doub
                                                                       unsigned *__restrict__ meta_next, unsigned *__restrict__ meta_done)
 {
     constexpr int DP = km_dp(D), NS = DP / 16;
+    sums += (size_t)blockIdx.y * k * D;                                  // problem blockIdx.y (KmBatch)
+    counts += (size_t)blockIdx.y * k;
+    cent += (size_t)blockIdx.y * k * D;
+    opnd += (size_t)blockIdx.y * ((k + 31) / 32) * NS * 2 * 64;
+    meta_next += (size_t)blockIdx.y * KM_META_WORDS;
+    meta_done += (size_t)blockIdx.y * KM_META_WORDS;
     const int t = blockIdx.x / NS, j = blockIdx.x % NS;
     const int lane = threadIdx.x;
     const int c = 32 * t + (lane & 31), k0 = 16 * j + 8 * (lane >> 5);
@@ -346,10 +373,20 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
                                                                              const ku32x4 *__restrict__ opnd, int ktiles,
                                                                              const float *__restrict__ cmax2,
                                                                              int32_t *__restrict__ labels,
-                                                                             unsigned *__restrict__ unc_list, unsigned *__restrict__ unc_count)
+                                                                             unsigned *__restrict__ unc_list, unsigned *__restrict__ unc_count,
+                                                                             KmBatch kb)
 {
     constexpr int DP = km_dp(D), NS = DP / 16, LS = DP + 1;   // odd LDS row stride
     constexpr int AW = NS * 2 * 64;                           // operand words (16 B) of one centroid tile
+    {
+        const int64_t r0 = km_problem_rows(kb, n);             // problem blockIdx.y
+        data += r0 * D;
+        labels += r0;
+        unc_list += r0;
+        opnd += (size_t)blockIdx.y * ktiles * AW;
+        cmax2 += (size_t)blockIdx.y * KM_META_WORDS;
+        unc_count += (size_t)blockIdx.y * KM_META_WORDS;
+    }
     __shared__ float s_tile[KM_MF_TILE * LS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -503,8 +540,19 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
                                                                        const unsigned *__restrict__ list,
                                                                        const unsigned *__restrict__ list_count,
                                                                        int32_t *__restrict__ labels,
-                                                                       unsigned *__restrict__ zero_counts /* nullable: k words to clear */)
+                                                                       unsigned *__restrict__ zero_counts /* nullable: k words to clear */,
+                                                                       KmBatch kb)
 {
+    {
+        int64_t n_;
+        const int64_t r0 = km_problem_rows(kb, n_);            // problem blockIdx.y
+        data += r0 * D;
+        labels += r0;
+        list += r0;
+        cent += (size_t)blockIdx.y * k * D;
+        list_count += (size_t)blockIdx.y * KM_META_WORDS;
+        if (zero_counts) zero_counts += (size_t)blockIdx.y * k;
+    }
     if (zero_counts)   // the label histogram that follows accumulates into these (round 4: nobody else re-zeroes them)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < k; i += gridDim.x * 256) zero_counts[i] = 0u;
     // round 4: one WORKGROUP per point, its four waves take every fourth 64-centroid stripe (a point is a latency chain of
@@ -606,9 +654,16 @@ __device__ __forceinline__ void kmeans_label_scan_body(const unsigned *__restric
 // launch of its own, 4.6 of the ~120 us of a SOG chunk iteration
 __global__ __launch_bounds__(256) void kmeans_label_hist_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
                                                                 unsigned *__restrict__ counts, unsigned *__restrict__ ticket,
-                                                                unsigned *__restrict__ starts, unsigned *__restrict__ cursor)
+                                                                unsigned *__restrict__ starts, unsigned *__restrict__ cursor, KmBatch kb)
 {
     extern __shared__ unsigned s_h[];
+    {
+        labels += km_problem_rows(kb, n);                      // problem blockIdx.y
+        counts += (size_t)blockIdx.y * k;
+        starts += (size_t)blockIdx.y * k;
+        cursor += (size_t)blockIdx.y * k;
+        ticket += (size_t)blockIdx.y * KM_META_WORDS;
+    }
     const bool use_lds = k <= 8192;
     if (use_lds) {
         for (int i = threadIdx.x; i < k; i += 256) s_h[i] = 0;
@@ -637,8 +692,15 @@ __global__ __launch_bounds__(256) void kmeans_label_hist_kernel(const int32_t *_
 // reserves the run -- a global atomic per point serialises on the K cursors (35 us per SOG chunk)
 __global__ __launch_bounds__(256) void kmeans_label_scatter_kernel(const int32_t *__restrict__ labels, int64_t n, int k,
                                                                    unsigned *__restrict__ cursor, unsigned *__restrict__ perm,
-                                                                   double *__restrict__ zero_sums, int64_t n_sums)
+                                                                   double *__restrict__ zero_sums, int64_t n_sums, KmBatch kb)
 {
+    {
+        const int64_t r0 = km_problem_rows(kb, n);             // problem blockIdx.y
+        labels += r0;
+        perm += r0;
+        cursor += (size_t)blockIdx.y * k;
+        if (zero_sums) zero_sums += (size_t)blockIdx.y * n_sums;
+    }
     if (zero_sums)     // the segmented sums that follow accumulate into these (round 4: finalize no longer re-zeroes them)
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_sums; i += (int64_t)gridDim.x * 256) zero_sums[i] = 0.0;
     extern __shared__ unsigned s_h[];   // [k] counts, then [k] run bases (k <= 8192)
@@ -724,8 +786,18 @@ __global__ __launch_bounds__(256) void kmeans_segment_sum_kernel(const float *__
                                                                  const unsigned *__restrict__ perm,
                                                                  const unsigned *__restrict__ starts,
                                                                  const unsigned *__restrict__ counts, int k,
-                                                                 const int32_t *__restrict__ labels, double *__restrict__ sums)
+                                                                 const int32_t *__restrict__ labels, double *__restrict__ sums, KmBatch kb)
 {
+    {
+        int64_t n_;
+        const int64_t r0 = km_problem_rows(kb, n_);            // problem blockIdx.y
+        data += r0 * D;
+        labels += r0;
+        perm += r0;
+        starts += (size_t)blockIdx.y * k;
+        counts += (size_t)blockIdx.y * k;
+        sums += (size_t)blockIdx.y * k * D;
+    }
     const int64_t n = (int64_t)starts[k - 1] + counts[k - 1];   // rows with a label (unassignable rows are not in the permutation)
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * 4;
@@ -866,61 +938,69 @@ static void launch_assign_t(gsx_ctx *c, const float *data, int64_t n, const floa
                            cent, k, labels, sums, counts);
 }
 
+// One Lloyd iteration (assign + update) of `nprob` problems of the same k and D in ONE set of launches (blockIdx.y = problem).
+// n: rows of the largest problem (sizes the grids), n_total: rows of all of them (off_dev[nprob]); off_dev == nullptr: one problem.
 template <int D>
 static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float *cent, int k, int32_t *labels, double *sums,
-                                unsigned *counts, int it)
+                                unsigned *counts, int it, int nprob = 1, const int64_t *off_dev = nullptr, int64_t n_total = -1)
 {
     constexpr int NS = km_dp(D) / 16;
+    if (n_total < 0) n_total = n;
+    const unsigned P = (unsigned)nprob;
+    const KmBatch kb{off_dev, n};
     const int ktiles = (k + 31) / 32;
-    const size_t opnd_bytes = sizeof(ku32x4) * (size_t)ktiles * NS * 2 * 64;
-    // operand words | meta (2 x 16 words, alternating by iteration) | uncertain list / permutation (n words) | starts (k) | cursor (k)
-    GSX_CHECK(c->scratch5.reserve(opnd_bytes + sizeof(unsigned) * (size_t)(32 + n + 2 * (size_t)k + 16)));
+    const size_t opnd_bytes = sizeof(ku32x4) * (size_t)ktiles * NS * 2 * 64 * P;
+    // operand words | meta (per problem 2 x 16 words, alternating by iteration) | uncertain list / permutation (n_total words)
+    // | starts (k per problem) | cursor (k per problem)
+    GSX_CHECK(c->scratch5.reserve(opnd_bytes + sizeof(unsigned) * ((size_t)KM_META_WORDS * P + (size_t)n_total + 2 * (size_t)k * P + 16)));
     ku32x4 *opnd = c->scratch5.as<ku32x4>();
     unsigned *meta2 = reinterpret_cast<unsigned *>(c->scratch5.as<char>() + opnd_bytes);
     unsigned *meta = meta2 + 16 * (it & 1);            // [0] = max |c|^2 (float bits), [1] = list length, [2] = histogram ticket
     unsigned *meta_next = meta2 + 16 * ((it + 1) & 1);
-    unsigned *list = meta2 + 32, *starts = list + n, *cursor = starts + k;
+    unsigned *list = meta2 + (size_t)KM_META_WORDS * P, *starts = list + n_total, *cursor = starts + (size_t)k * P;
     const bool fused_update = D <= 64;                 // (always: D is 9, 24 or 45)
+    const int per = std::max(1, c->num_cu / nprob);    // workgroups per problem where one launch used to fill the chip
     if (it == 0 || !fused_update) {
         // the first iteration's operands come from the caller's centroids; every later one's were written by the
         // finalize + operands kernel at the end of the iteration before
-        GSX_HIP(hipMemsetAsync(meta2, 0, sizeof(unsigned) * 32, c->stream));
-        hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, cent, k, opnd,
+        GSX_HIP(hipMemsetAsync(meta2, 0, sizeof(unsigned) * KM_META_WORDS * P, c->stream));
+        hipLaunchKernelGGL((kmeans_centroid_operands_kernel<D>), dim3(ktiles * NS, P), dim3(64), 0, c->stream, cent, k, opnd,
                            reinterpret_cast<float *>(meta));
     }
     if (c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
-        // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h)
-        const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)c->num_cu);
-        hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
-                           ktiles, reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+        // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h); in a
+        // batch a workgroup stays with ONE problem's centroids for all of its share of that problem's rows
+        const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)per);
+        hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks, P), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
+                           ktiles, reinterpret_cast<const float *>(meta), labels, list, meta + 1, kb);
     } else {
         const int64_t tiles = div_up(n, KM_MF_TILE);
-        const int blocks = (int)std::min<int64_t>(tiles, (int64_t)c->num_cu * 8);
-        hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
-                           reinterpret_cast<const float *>(meta), labels, list, meta + 1);
+        const int blocks = (int)std::min<int64_t>(tiles, (int64_t)per * 8);
+        hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks, P), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
+                           reinterpret_cast<const float *>(meta), labels, list, meta + 1, kb);
     }
-    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(c->num_cu * c->km_exact_blocks), dim3(256), 0, c->stream, data, cent, k, list,
-                       meta + 1, labels, fused_update && it > 0 ? counts : nullptr);
+    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(per * c->km_exact_blocks, P), dim3(256), 0, c->stream, data, cent, k, list,
+                       meta + 1, labels, fused_update && it > 0 ? counts : nullptr, kb);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
     GSX_CHECK(timing_begin(c, GSX_T_KMEANS_UPDATE));
     // update (the list is dead now: its storage becomes the permutation)
-    const int hb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)c->num_cu * 4));
-    hipLaunchKernelGGL(kmeans_label_hist_kernel, dim3(hb), dim3(256), k <= 8192 ? sizeof(unsigned) * (size_t)k : 0, c->stream, labels, n,
-                       k, counts, meta + 2, starts, cursor);   // (+ the scan of the counts, in its last workgroup)
-    hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
-                       labels, n, k, cursor, list, fused_update && it > 0 ? sums : nullptr, (int64_t)k * D);
+    const int hb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 2048), (int64_t)per * 4));
+    hipLaunchKernelGGL(kmeans_label_hist_kernel, dim3(hb, P), dim3(256), k <= 8192 ? sizeof(unsigned) * (size_t)k : 0, c->stream, labels, n,
+                       k, counts, meta + 2, starts, cursor, kb);   // (+ the scan of the counts, in each problem's last workgroup)
+    hipLaunchKernelGGL(kmeans_label_scatter_kernel, dim3(hb, P), dim3(256), k <= 8192 ? 2 * sizeof(unsigned) * (size_t)k : 0, c->stream,
+                       labels, n, k, cursor, list, fused_update && it > 0 ? sums : nullptr, (int64_t)k * D, kb);
     if (fused_update) {
         const int rows = c->km_seg_rows;
-        const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4 * rows), (int64_t)c->num_cu * 8));
+        const int sb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4 * rows), (int64_t)per * 8));
         if (rows == 64)
-            hipLaunchKernelGGL(kmeans_segment_sum_kernel<64>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<64>, dim3(sb, P), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums, kb);
         else if (rows == 32)
-            hipLaunchKernelGGL(kmeans_segment_sum_kernel<32>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<32>, dim3(sb, P), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums, kb);
         else
-            hipLaunchKernelGGL(kmeans_segment_sum_kernel<16>, dim3(sb), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums);
+            hipLaunchKernelGGL(kmeans_segment_sum_kernel<16>, dim3(sb, P), dim3(256), 0, c->stream, data, D, list, starts, counts, k, labels, sums, kb);
         // finalize + the NEXT iteration's operands + the meta block of the one after, in one launch
-        hipLaunchKernelGGL((kmeans_finalize_operands_kernel<D>), dim3(ktiles * NS), dim3(64), 0, c->stream, sums, counts, k, cent, opnd,
+        hipLaunchKernelGGL((kmeans_finalize_operands_kernel<D>), dim3(ktiles * NS, P), dim3(64), 0, c->stream, sums, counts, k, cent, opnd,
                            meta_next, meta);
     } else {
         hipLaunchKernelGGL(kmeans_centroid_reduce_kernel, dim3(k), dim3(256), 0, c->stream, data, D, list, starts, counts, k, cent);
@@ -985,6 +1065,46 @@ int kmeans_lloyd_dev(gsx_ctx *c, const float *data_dev, int64_t n, int d, int k,
         GSX_HIP(hipGetLastError());
         GSX_CHECK(timing_end(c, GSX_T_KMEANS_UPDATE));
     }
+    return 0;
+}
+
+// nprob independent problems of the same d and k, rows concatenated: problem p = rows [off[p], off[p+1]) of data_dev / labels_dev,
+// centroids p * k * d ... of cent_dev (in: init, out: result).  The matrix-core path runs every iteration of ALL problems in
+// one set of launches (launch_assign_mfma_t); other shapes run the problems one after the other -- the same kernels, launch
+// order and arithmetic per problem as kmeans_lloyd_dev either way.
+int kmeans_lloyd_batch_dev(gsx_ctx *c, const float *data_dev, const int64_t *off_host, int nprob, int d, int k, int max_iter,
+                           float *cent_dev, int32_t *labels_dev)
+{
+    if (nprob <= 0 || d <= 0 || k <= 0 || !off_host) GSX_FAIL("kmeans batch: bad shape nprob=%d d=%d k=%d", nprob, d, k);
+    int64_t n_max = 0;
+    for (int p = 0; p < nprob; ++p) {
+        const int64_t rows = off_host[p + 1] - off_host[p];
+        if (rows <= 0 || off_host[0] != 0) GSX_FAIL("kmeans batch: problem %d has %lld rows (offsets must start at 0 and increase)", p, (long long)rows);
+        n_max = std::max(n_max, rows);
+    }
+    const int64_t n_total = off_host[nprob];
+    const bool batched = c->kmeans_mfma && k >= 64 && (d == 9 || d == 24 || d == 45) && nprob > 1 && nprob <= 65535;
+    if (!batched) {
+        for (int p = 0; p < nprob; ++p)
+            GSX_CHECK(kmeans_lloyd_dev(c, data_dev + off_host[p] * d, off_host[p + 1] - off_host[p], d, k, max_iter,
+                                       cent_dev + (size_t)p * k * d, labels_dev + off_host[p]));
+        return 0;
+    }
+    const size_t kd = (size_t)k * d * nprob, kk = (size_t)k * nprob;
+    const size_t off_at = (sizeof(double) * kd + sizeof(unsigned) * kk + 63) & ~(size_t)63;
+    GSX_CHECK(c->scratch3.reserve(off_at + sizeof(int64_t) * (size_t)(nprob + 1) + 64));
+    double *sums = c->scratch3.as<double>();
+    unsigned *counts = reinterpret_cast<unsigned *>(c->scratch3.as<char>() + sizeof(double) * kd);
+    int64_t *off_dev = reinterpret_cast<int64_t *>(c->scratch3.as<char>() + off_at);
+    GSX_HIP(hipMemcpyAsync(off_dev, off_host, sizeof(int64_t) * (size_t)(nprob + 1), hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * kd + sizeof(unsigned) * kk, c->stream));
+    for (int it = 0; it < max_iter; ++it) {
+        GSX_CHECK(timing_begin(c, GSX_T_KMEANS_ASSIGN));
+        if (d == 9) GSX_CHECK(launch_assign_mfma_t<9>(c, data_dev, n_max, cent_dev, k, labels_dev, sums, counts, it, nprob, off_dev, n_total));
+        else if (d == 24) GSX_CHECK(launch_assign_mfma_t<24>(c, data_dev, n_max, cent_dev, k, labels_dev, sums, counts, it, nprob, off_dev, n_total));
+        else GSX_CHECK(launch_assign_mfma_t<45>(c, data_dev, n_max, cent_dev, k, labels_dev, sums, counts, it, nprob, off_dev, n_total));
+    }
+    GSX_HIP(hipStreamSynchronize(c->stream));   // off_host (the caller's, possibly pageable) must outlive its async copy
     return 0;
 }
 

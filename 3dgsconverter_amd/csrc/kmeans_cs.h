@@ -20,10 +20,19 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
                                                                                 const float *__restrict__ cmax2,
                                                                                 int32_t *__restrict__ labels,
                                                                                 unsigned *__restrict__ unc_list,
-                                                                                unsigned *__restrict__ unc_count)
+                                                                                unsigned *__restrict__ unc_count, KmBatch kb)
 {
     constexpr int DP = km_dp(D), NS = DP / 16;
     constexpr int AW = NS * 2 * 64;
+    {
+        const int64_t r0 = km_problem_rows(kb, n);             // problem blockIdx.y: its rows, its centroid operands
+        data += r0 * D;
+        labels += r0;
+        unc_list += r0;
+        opnd += (size_t)blockIdx.y * ktiles * AW;
+        cmax2 += (size_t)blockIdx.y * KM_META_WORDS;
+        unc_count += (size_t)blockIdx.y * KM_META_WORDS;
+    }
     // double buffered: block b+1 is fetched and split while block b runs through the matrix cores, and block b's
     // per-wave results are merged while block b+1 runs
     __shared__ ku32x4 s_x[2][KM_CS_PTILES][NS][2][64];   // point operand words: (tile, slice, hi/lo, lane)

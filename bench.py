@@ -366,24 +366,54 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=
     # the chunks are independent problems (sog.py:536-552): they are dealt out to a few contexts with streams of their own,
     # exactly as the product's palette path does (_lib.kmeans_lloyd_many), so that one chunk's small kernels fill the tails
     # of another's
-    nlanes = max(1, min(lanes if lanes else L.PALETTE_LANES, nch))
+    # round 5: the product's palette path (_lib.kmeans_lloyd_many -> kmeans_lloyd_batch) runs the chunks as ONE batched call,
+    # the chunk being a grid dimension of every kernel; `--lanes N` (N > 0) times the former scheme instead: the chunks dealt
+    # out to N contexts with streams of their own
+    batched = not lanes
+    nlanes = 1 if batched else max(1, min(lanes, nch))
     lane_ctx = [L.Context(0, own_stream=True) for _ in range(nlanes)]
-    chunks, inits, cents, labels, first_host = [], [], [], [], None
+    rows_of = [min(cs, n_scene - i * cs) for i in range(nch)]
+    off = np.zeros(nch + 1, dtype=np.int64)
+    np.cumsum(rows_of, out=off[1:])
+    n_total = int(off[-1])
+    data_all = ctx.alloc(4 * n_total * d)          # all chunks' rows, concatenated (what the writer's SH table is)
+    init_all = ctx.alloc(4 * nch * k * d)
+    cent_all = ctx.alloc(4 * nch * k * d)
+    label_all = ctx.alloc(4 * n_total + 16)
+    first_host = None
+
+    class _View:   # a chunk's slice of the big buffers
+        def __init__(self, base, ptr):
+            self.base, self.ptr = base, ptr
+
+        def download(self, dtype, count):
+            return self.base.download_at(self.ptr - self.base.ptr, dtype, count)
+
+    chunks, inits, cents, labels = [], [], [], []
     for i in range(nch):
-        rows = min(cs, n_scene - i * cs)
+        rows = rows_of[i]
         x = rng.standard_normal((rows, d), dtype=np.float32) * np.float32(0.1)
-        init = x[np.random.choice(rows, k, replace=False)]
+        init = np.ascontiguousarray(x[np.random.choice(rows, k, replace=False)])
         if i == 0:
             first_host = x
-        chunks.append((ctx.alloc(x.nbytes).upload(x), rows))
-        inits.append(ctx.alloc(init.nbytes).upload(np.ascontiguousarray(init)))
-        cents.append(ctx.alloc(init.nbytes))
-        labels.append(ctx.alloc(4 * rows + 16))
+        L.check(ctx.lib.gsx_dev_upload_async(ctx.handle, data_all.ptr + 4 * d * int(off[i]), x.ctypes.data, x.nbytes), "gsx_dev_upload_async")
+        L.check(ctx.lib.gsx_dev_upload_async(ctx.handle, init_all.ptr + 4 * k * d * i, init.ctypes.data, init.nbytes), "gsx_dev_upload_async")
+        ctx.synchronize()                          # (x / init are released at the end of the iteration)
+        chunks.append((_View(data_all, data_all.ptr + 4 * d * int(off[i])), rows))
+        inits.append(_View(init_all, init_all.ptr + 4 * k * d * i))
+        cents.append(_View(cent_all, cent_all.ptr + 4 * k * d * i))
+        labels.append(_View(label_all, label_all.ptr + 4 * int(off[i])))
     for c in lane_ctx:
         for name, val in params:
             c.set_param(name, val)
 
     def step():
+        if batched:
+            c = lane_ctx[0]
+            L.check(c.lib.gsx_dev_copy(c.handle, cent_all.ptr, init_all.ptr, 4 * nch * k * d), "gsx_dev_copy")
+            L.check(c.lib.gsx_kmeans_lloyd_batch_dev(c.handle, data_all.ptr, off.ctypes.data, nch, d, k, iters, cent_all.ptr, label_all.ptr),
+                    "gsx_kmeans_lloyd_batch_dev")
+            return
         for j in range(nch):
             c = lane_ctx[j % nlanes]
             L.check(c.lib.gsx_dev_copy(c.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
@@ -404,15 +434,20 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=
         c0.set_param("timing_mask", (1 << L.T_KMEANS_ASSIGN) | (1 << L.T_KMEANS_UPDATE))
         c0.set_timing(True)
         c0.reset_timing()
-        for j in range(nch):
-            L.check(c0.lib.gsx_dev_copy(c0.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
-            L.check(c0.lib.gsx_kmeans_lloyd_dev(c0.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
-                    "gsx_kmeans_lloyd_dev")
+        if batched:
+            step()
+        else:
+            for j in range(nch):
+                L.check(c0.lib.gsx_dev_copy(c0.handle, cents[j].ptr, inits[j].ptr, 4 * k * d), "gsx_dev_copy")
+                L.check(c0.lib.gsx_kmeans_lloyd_dev(c0.handle, chunks[j][0].ptr, chunks[j][1], d, k, iters, cents[j].ptr, labels[j].ptr),
+                        "gsx_kmeans_lloyd_dev")
         c0.synchronize()
         n_as, ms_as = c0.timing(L.T_KMEANS_ASSIGN)
         n_up, ms_up = c0.timing(L.T_KMEANS_UPDATE)
         c0.set_timing(False)
-        assign_ms = ms_as / max(n_as, 1)            # one interval = operand prep + matrix-core assign + exact list, one chunk iteration
+        # one interval = operand prep + matrix-core assign + exact list of ONE iteration: of one chunk (lanes) or of all chunks
+        # (batched) -- the roofline below is per chunk iteration either way
+        assign_ms = ms_as / max(n_as, 1) / (nch if batched else 1)
         rows0 = chunks[0][1]
         ktiles, ns = (k + 31) // 32, 3              # 32-centroid tiles, three 16-wide slices of the 45 (+3) dimensions
         # three v_mfma_f32_32x32x16_bf16 per slice (xh.ch + xh.cl + xl.ch), 2*32*32*16 flops each, per (32 points x 32 centroids)
@@ -423,11 +458,13 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=
                            "compression_level %d -> %d chunks of %d rows, K=%d per chunk, %d Lloyd iterations, rows resident in HBM"
                            % (n_scene, level, nch, cs, k, iters),
                "value": round(n_scene * steps / t["dt"] / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(t["ms_per_step"], 3), "steps": steps,
-               "lanes": nlanes,
+               "lanes": nlanes, "batched": batched,
                "kernel_ms_per_step": {"assign (operands + mfma + exact list)": round(ms_as / side, 3),
                                       "update (label sort + segmented reduce)": round(ms_up / side, 3),
-                                      "note": "HIP-event sums of a separate pass on ONE lane (%d launches back to back); the timed region "
-                                              "runs the chunks on %d concurrent lanes" % (nch * iters, nlanes)},
+                                      "note": ("HIP-event sums of a separate pass: %d iterations, each ONE set of launches for all %d chunks "
+                                               "(gsx_kmeans_lloyd_batch_dev: the chunk is a grid dimension)" % (iters, nch)) if batched else
+                                              ("HIP-event sums of a separate pass on ONE lane (%d launches back to back); the timed region "
+                                               "runs the chunks on %d concurrent lanes" % (nch * iters, nlanes))},
                "roofline": {"bound": "mfma", "kernel": "kmeans_assign_mfma_cs_kernel<45> (+ operand prep and exact list kernel in the same interval)",
                             "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(assign_ms, 4),
@@ -460,9 +497,7 @@ def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=
     finally:
         for c in lane_ctx:
             c.synchronize()
-        for b, _ in chunks:
-            b.free()
-        for b in inits + cents + labels:
+        for b in (data_all, init_all, cent_all, label_all):
             b.free()
         for c in lane_ctx:
             c.close()

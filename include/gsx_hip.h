@@ -410,6 +410,17 @@ int gsx_kmeans_pp_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, int
 /* device-resident variants: centroids_dev holds the init on entry and the result on exit */
 int gsx_kmeans_lloyd_dev(gsx_ctx *ctx, const float *data_dev, int64_t n, int d, int k, int max_iter,
                          float *centroids_dev, int32_t *labels_dev);
+/*
+ * nprob INDEPENDENT Lloyd problems of the same d and k in one call -- the SH palette of the SOG writer is 64 such problems
+ * (formats/sog.py:536-552: `for i in range(num_chunks): ... kmeans(chunk, k_per_chunk, max_iter=10)`).  Rows concatenated:
+ * problem p = rows [row_off[p], row_off[p+1]) of data_dev / labels_dev (row_off: HOST array of nprob + 1 offsets, row_off[0]
+ * = 0), its k x d centroids at centroids_dev + p*k*d (init on entry, result on exit), labels local to the problem (0..k-1,
+ * as gpu_ops.kmeans returns them; the writer adds the chunk's offset, sog.py:546-552).  Per problem the same kernels,
+ * launch order and arithmetic as gsx_kmeans_lloyd_dev; for the matrix-core shapes (d in {9, 24, 45}, k >= 64) every
+ * iteration of ALL problems is one set of launches (the problem is a grid dimension) instead of nprob x 6.
+ */
+int gsx_kmeans_lloyd_batch_dev(gsx_ctx *ctx, const float *data_dev, const int64_t *row_off, int nprob, int d, int k,
+                               int max_iter, float *centroids_dev, int32_t *labels_dev);
 int gsx_quantize_sorted_codebook_dev(gsx_ctx *ctx, const float *vals_dev, int64_t n,
                                      const float *codebook_dev, int kcb, uint8_t *idx_out_dev);
 

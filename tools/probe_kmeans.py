@@ -11,7 +11,7 @@ import bench  # noqa: E402
 
 gsx = importlib.import_module("3dgsconverter_amd")
 L = gsx._lib
-lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # 0 = the batched call (round 5), N > 0 = N concurrent lanes
 params = [(kv.split("=")[0], float(kv.split("=")[1])) for kv in sys.argv[2:]]
 r = bench.run_kmeans(L, L.Context(0), gsx, 10_000_000, 2, 1, cpu=False, lanes=lanes, params=params)
 print(lanes, params, r["ms_per_step"], r["kernel_ms_per_step"])
