@@ -534,8 +534,9 @@ __global__ __launch_bounds__(64 * KM_MF_WAVES) void kmeans_assign_mfma_kernel(co
 // (gpu_ops.py:57-73) over ALL centroids, one wave per point; lane = centroids lane, lane + 64, ...; the lowest index wins
 // inside a lane by the strict '<' and across lanes by the merge.  D is a compile-time constant so that a lane's 45 loads
 // per centroid are all in flight (a runtime loop was latency-bound: 90 us for a few hundred points).
+constexpr int KM_EX_WAVES = 16;   // waves per workgroup of the exact-list kernel: each scans K / 16 centroids for the same 64 points
 template <int D>
-__global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const float *__restrict__ data,
+__global__ __launch_bounds__(64 * KM_EX_WAVES) void kmeans_assign_exact_list_kernel(const float *__restrict__ data,
                                                                        const float *__restrict__ cent, int k,
                                                                        const unsigned *__restrict__ list,
                                                                        const unsigned *__restrict__ list_count,
@@ -554,30 +555,33 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
         if (zero_counts) zero_counts += (size_t)blockIdx.y * k;
     }
     if (zero_counts)   // the label histogram that follows accumulates into these (round 4: nobody else re-zeroes them)
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < k; i += gridDim.x * 256) zero_counts[i] = 0u;
-    // round 4: one WORKGROUP per point, its four waves take every fourth 64-centroid stripe (a point is a latency chain of
-    // K / 64 row fetches per lane -- 16 at K = 1024 -- and the list holds fewer points than the chip has workgroups:
-    // 15 -> ~5 us per SOG chunk iteration); the four partial winners meet in LDS, lowest index on ties
-    __shared__ float s_best[4];
-    __shared__ int s_bi[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int i = blockIdx.x * 64 * KM_EX_WAVES + threadIdx.x; i < k; i += gridDim.x * 64 * KM_EX_WAVES) zero_counts[i] = 0u;
+    // Round 5: one LANE per point, the point's D coordinates in registers; a workgroup takes 64 points of the list, its sixteen
+    // waves scan a sixteenth of the centroids each in index order -- every centroid row is a WAVE-UNIFORM address (scalar
+    // loads, one fetch serves 64 points) -- with the reference's arithmetic (gpu_ops.py:57-73: diff, fma chain over d,
+    // strict '<' keeps the first minimum); the parts meet in LDS, lower part first, strict '<' again: the lowest
+    // index among equal distances wins, as in the sequential scan.  (Round 4 gave every point a workgroup of its own, which
+    // read all K x D centroid values per point through the vector memory path: 184 KB per point at K = 1024, D = 45 --
+    // 0.88 ms per iteration of the 10M-splat palette, a fifth of it, for 0.3 % of the points.)
+    __shared__ float s_best[KM_EX_WAVES][64];
+    __shared__ int s_bi[KM_EX_WAVES][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned cnt = *list_count;
-    for (unsigned it = blockIdx.x; it < cnt; it += gridDim.x) {
-        const int64_t i = list[it];
+    const int c_lo = (int)(((long long)k * wv) / KM_EX_WAVES), c_hi = (int)(((long long)k * (wv + 1)) / KM_EX_WAVES);
+    for (unsigned g = blockIdx.x * 64u; g < cnt; g += gridDim.x * 64u) {
+        const bool live = g + (unsigned)lane < cnt;
+        const int64_t i = list[live ? g + (unsigned)lane : g];
         float x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = data[i * D + d];
         float best = 1e20f;  // gpu_ops.py:60
         int bi = -1;
-        for (int c = wv * 64 + lane; c < k; c += 256) {
-            const float *__restrict__ cc = cent + (int64_t)c * D;
-            float cv[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) cv[d] = cc[d];
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float *__restrict__ cc = cent + (int64_t)c * D;   // wave-uniform
             float dist = 0.0f;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float diff = x[d] - cv[d];
+                const float diff = x[d] - cc[d];
                 dist = __builtin_fmaf(diff, diff, dist);
             }
             if (dist < best) {
@@ -585,26 +589,16 @@ __global__ __launch_bounds__(256) void kmeans_assign_exact_list_kernel(const flo
                 bi = c;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off);
-            // the sequential scan keeps the FIRST minimum: smaller value, or equal value and smaller (valid) index
-            const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
-            best = take ? ob : best;
-            bi = take ? oi : bi;
-        }
-        if (lane == 0) {
-            s_best[wv] = best;
-            s_bi[wv] = bi;
-        }
+        s_best[wv][lane] = best;
+        s_bi[wv][lane] = bi;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wv == 0 && live) {
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float ob = s_best[w];
-                const int oi = s_bi[w];
-                const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+            for (int w = 1; w < KM_EX_WAVES; ++w) {
+                const float ob = s_best[w][lane];
+                const int oi = s_bi[w][lane];
+                // the sequential scan keeps the FIRST minimum: a later part only wins with a strictly smaller distance
+                const bool take = oi >= 0 && (bi < 0 || ob < best);
                 best = take ? ob : best;
                 bi = take ? oi : bi;
             }
@@ -979,7 +973,9 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
         hipLaunchKernelGGL((kmeans_assign_mfma_kernel<D>), dim3(blocks, P), dim3(64 * KM_MF_WAVES), 0, c->stream, data, n, opnd, ktiles,
                            reinterpret_cast<const float *>(meta), labels, list, meta + 1, kb);
     }
-    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(per * c->km_exact_blocks, P), dim3(256), 0, c->stream, data, cent, k, list,
+    // (round 5: a workgroup takes 64 list entries at a time; the list holds ~0.3 % of the rows)
+    const int eb = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 64 * 64), (int64_t)per * c->km_exact_blocks));
+    hipLaunchKernelGGL((kmeans_assign_exact_list_kernel<D>), dim3(eb, P), dim3(64 * KM_EX_WAVES), 0, c->stream, data, cent, k, list,
                        meta + 1, labels, fused_update && it > 0 ? counts : nullptr, kb);
     GSX_HIP(hipGetLastError());
     GSX_CHECK(timing_end(c, GSX_T_KMEANS_ASSIGN));
