@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("GSX_LIB_PATH") or os.path.join(_HERE, "libgsx_hip.so"
 
 KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_TREE = 0, 1, 2, 3
 T_SOR_KNN, T_SOR_BIN, T_SOR_FALLBACK, T_SOR_STATS, T_DENSITY, T_KMEANS_ASSIGN, T_KMEANS_UPDATE, T_QUANTIZE = range(8)
+T_SLAB_PREP, T_SLAB_ROWS, T_SLAB_MEANS, T_SLAB_COLL = range(8, 12)   # multi-GPU slab step (round 5)
 
 
 class GsxError(RuntimeError):

@@ -264,6 +264,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->km_exact_blocks = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     } else if (!strcmp(name, "km_seg_rows")) {
         c->km_seg_rows = value >= 64 ? 64 : (value >= 32 ? 32 : 16);
+    } else if (!strcmp(name, "km_group_mb")) {
+        c->km_group_mb = value < 0 ? 0 : (int)value;
     } else if (!strcmp(name, "kmeans_cs")) {
         c->kmeans_cs = value != 0.0;
     } else if (!strcmp(name, "ring_fast")) {

@@ -595,19 +595,31 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     unsigned *cursor = w.small.as<unsigned>();
     unsigned *unc = cursor + 32;
     float *stats = reinterpret_cast<float *>(cursor + 36);
+    GSX_CHECK(timing_begin(c, GSX_T_SLAB_PREP));
     hipLaunchKernelGGL(slab_clear_kernel, dim3(1), dim3(256), 0, c->stream, b7, hist_mine, cursor);
     if (n_local > 0) {
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 2048), (int64_t)c->num_cu * 2));
         hipLaunchKernelGGL(slab_bbox_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, b7);
     }
     GSX_HIP(hipGetLastError());
-    if (G > 1) GSX_CHECK(gsx_comm_all_reduce(c, b7, 7, GSX_COMM_F32_MAX));
+    GSX_CHECK(timing_end(c, GSX_T_SLAB_PREP));
+    if (G > 1) {
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_COLL));
+        GSX_CHECK(gsx_comm_all_reduce(c, b7, 7, GSX_COMM_F32_MAX));
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_COLL));
+    }
     if (n_local > 0) {
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_PREP));
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 4096), (int64_t)c->num_cu * 4));
         hipLaunchKernelGGL(slab_hist_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, b7, hist_mine);
         GSX_HIP(hipGetLastError());
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_PREP));
     }
-    if (G > 1) GSX_CHECK(gsx_comm_all_gather(c, hist_mine, hist_all, 4 * SLAB_BINS));
+    if (G > 1) {
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_COLL));
+        GSX_CHECK(gsx_comm_all_gather(c, hist_mine, hist_all, 4 * SLAB_BINS));
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_COLL));
+    }
     GSX_HIP(hipMemcpyAsync(w.host, w.plan_in.p, 4 * plan_words, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(hipStreamSynchronize(c->stream));                                    // <- the step's host synchronisation
     gsx_slab_plan_t &p = out->plan;
@@ -631,11 +643,13 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
         sp.off[2 * s + 1] = (unsigned)p.halo_off[s];
     }
     if (n_local > 0) {
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_PREP));
         // (over a wire the rows this rank owns itself go straight into its slab: no self-copy of 1/G of the cloud)
         hipLaunchKernelGGL(slab_partition_kernel, dim3(div_up(n_local, 2048)), dim3(256), 0, c->stream, x, y, z, (int64_t)3, n_local, sp,
                            cursor, w.send.as<float>(), w.send_src.as<unsigned>(), wire ? 2 * r : -1, w.slab.as<float>(),
                            p.r_own_off[r] - p.own_off[r]);
         GSX_HIP(hipGetLastError());
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_PREP));
     }
     const float *slab_rows = w.slab.as<float>();
     if (wire) {
@@ -645,7 +659,9 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
             so[G + q] = p.halo_off[q]; sc[G + q] = p.halo_cnt[q]; ro[G + q] = p.r_halo_off[q]; rc[G + q] = p.in_halo[q];
         }
         sc[r] = rc[r] = 0;   // already in place
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_ROWS));
         GSX_CHECK(gsx_comm_all_to_all_segs(c, w.send.p, w.slab.p, 2, so, sc, ro, rc, 12));
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_ROWS));
     } else {
         slab_rows = w.send.as<float>();   // no communicator: the (permuted) send buffer IS the slab
     }
@@ -687,7 +703,9 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
             sc[q] = q == r ? 0 : p.in_own[q];    // the own queries' means are read where the KNN left them
             rc[q] = q == r ? 0 : p.own_cnt[q];
         }
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_MEANS));
         GSX_CHECK(gsx_comm_all_to_all_segs(c, w.md_slab.p, w.ret.p, 1, p.r_own_off, sc, p.own_off, rc, 4));
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_MEANS));
         ret = w.ret.as<float>();
     }
     float *md = w.md.as<float>();
@@ -717,12 +735,14 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     GSX_CHECK(w.packed.reserve(4 * (size_t)std::max(total_pieces, 1)));
     unsigned *unc_total = cursor + 34;
     if (n_local > 0) {   // (also hands this rank's certificate count to the tail of the piece buffer)
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_PREP));
         const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n_local, 1024), (int64_t)c->num_cu * 8));
         const int64_t self_lo = wire ? p.own_off[r] : 0, self_hi = wire ? p.own_off[r] + p.own_cnt[r] : 0;
         hipLaunchKernelGGL(slab_unpermute_kernel, dim3(blocks), dim3(256), 0, c->stream, ret, w.send_src.as<unsigned>(), n_local, md,
                            unc, w.pieces.as<unsigned>() + (stride - 2), self_lo, self_hi,
                            w.md_slab.as<float>() + (p.r_own_off[r] - p.own_off[r]));
         GSX_HIP(hipGetLastError());
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_PREP));
     }
     const float *st_in;
     if (head % 4 == 0) {
@@ -737,6 +757,7 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
         if (r > 0) sc[r - 1] = head;
         if (r + 1 < G) rc[r + 1] = nxt_head;
         // (send from md[0..head), receive behind the own elements of md / of the aligned copy)
+        GSX_CHECK(timing_begin(c, GSX_T_SLAB_MEANS));
         if (head % 4 == 0) {
             for (int q = 0; q < G; ++q) ro[q] = n_local;
             GSX_CHECK(gsx_comm_all_to_all_segs(c, md, md, 1, so, sc, ro, rc, 4));
@@ -744,12 +765,17 @@ static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
             for (int q = 0; q < G; ++q) ro[q] = n_local - head;
             GSX_CHECK(gsx_comm_all_to_all_segs(c, md, w.md_stats.p, 1, so, sc, ro, rc, 4));
         }
+        GSX_CHECK(timing_end(c, GSX_T_SLAB_MEANS));
     }
     for (int mode = 0; mode < 2; ++mode) {
+        GSX_CHECK(timing_begin(c, GSX_T_SOR_STATS));
         if (n_mine > 0) GSX_CHECK(launch_sor_piece_sums(c, st_in, n_mine, mode ? stats : nullptr, w.pieces.as<float>()));
+        GSX_CHECK(timing_end(c, GSX_T_SOR_STATS));
         const float *pieces = w.pieces.as<float>();
         if (G > 1) {
+            GSX_CHECK(timing_begin(c, GSX_T_SLAB_COLL));
             GSX_CHECK(gsx_comm_all_gather(c, w.pieces.p, w.allpieces.p, 4 * (int64_t)stride));
+            GSX_CHECK(timing_end(c, GSX_T_SLAB_COLL));
             hipLaunchKernelGGL(slab_pack_pieces_kernel, dim3(4), dim3(256), 0, c->stream, w.allpieces.as<float>(), pk, w.packed.as<float>(),
                                mode == 0 ? reinterpret_cast<unsigned long long *>(unc_total) : nullptr);
             GSX_HIP(hipGetLastError());

@@ -17,6 +17,8 @@
 // (SURVEY.md 8(d)).  Cluster sums are float64 hardware atomics (order-insensitive to ~1e-16,
 // unlike the reference's f32 atomics), in HBM or -- for small codebooks -- in LDS; one small
 // kernel per iteration divides and re-zeroes.
+#include <vector>
+
 #include "gsx_common.h"
 
 namespace gsx {
@@ -1085,6 +1087,30 @@ int kmeans_lloyd_batch_dev(gsx_ctx *c, const float *data_dev, const int64_t *off
             GSX_CHECK(kmeans_lloyd_dev(c, data_dev + off_host[p] * d, off_host[p + 1] - off_host[p], d, k, max_iter,
                                        cent_dev + (size_t)p * k * d, labels_dev + off_host[p]));
         return 0;
+    }
+    if (c->km_group_mb > 0) {
+        // groups of consecutive problems whose rows fit km_group_mb: every iteration of a group runs before the next group
+        // starts, so its rows are read from the Infinity Cache after the first pass
+        const int64_t cap_rows = std::max<int64_t>(1, (int64_t)c->km_group_mb * (1 << 20) / (4 * (int64_t)d));
+        int first = 0;
+        while (first < nprob) {
+            int last = first + 1;
+            while (last < nprob && off_host[last + 1] - off_host[first] <= cap_rows) ++last;
+            if (last - first < nprob) {   // (a single group = the plain batch below)
+                std::vector<int64_t> sub((size_t)(last - first + 1));
+                for (int p = first; p <= last; ++p) sub[(size_t)(p - first)] = off_host[p] - off_host[first];
+                const int keep = c->km_group_mb;
+                c->km_group_mb = 0;
+                const int rc = kmeans_lloyd_batch_dev(c, data_dev + off_host[first] * d, sub.data(), last - first, d, k, max_iter,
+                                                      cent_dev + (size_t)first * k * d, labels_dev + off_host[first]);
+                c->km_group_mb = keep;
+                if (rc != 0) return rc;
+                first = last;
+                continue;
+            }
+            break;
+        }
+        if (first >= nprob) return 0;
     }
     const size_t kd = (size_t)k * d * nprob, kk = (size_t)k * nprob;
     const size_t off_at = (sizeof(double) * kd + sizeof(unsigned) * kk + 63) & ~(size_t)63;

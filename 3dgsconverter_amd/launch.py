@@ -165,6 +165,45 @@ def agree_transport(rank: int, world: int, device_uid: str, path: str | None = N
     return "rccl" if len(set(seen.values())) == world else "hostwire"
 
 
+class comm_watchdog:
+    """A multi-process job must end with a line its driver can parse, not with the driver's own timeout: if a STAGE of the
+    run (communicator set-up, a timed region, ...) does not finish within `timeout_s`, rank 0 writes ONE JSON line with an
+    "error" field to `json_fd` and every rank leaves with exit code 124.  The blocking calls are ctypes calls into librccl /
+    libgsx_hip, which release the GIL, so this thread runs while the main one is stuck.  stage(name) restarts the clock."""
+
+    def __init__(self, rank: int, world: int, json_fd: int, timeout_s: float, fields: dict | None = None):
+        import threading
+        self.rank, self.world, self.json_fd, self.timeout_s = rank, world, json_fd, float(timeout_s)
+        self.fields = dict(fields or {})
+        self._stage, self._t0, self._done = "communicator set-up", time.time(), threading.Event()
+        self._lock = threading.Lock()
+        if self.timeout_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def stage(self, name: str):
+        with self._lock:
+            self._stage, self._t0 = name, time.time()
+
+    def done(self):
+        self._done.set()
+
+    def _run(self):
+        while not self._done.wait(0.25):
+            with self._lock:
+                late, stage = time.time() - self._t0 > self.timeout_s, self._stage
+            if late:
+                msg = "rank %d of %d: no progress for %.0f s after stage '%s' (GSX_COMM_TIMEOUT)" % (self.rank, self.world, self.timeout_s, stage)
+                sys.stderr.write("[gsx launch] " + msg + "\n")
+                if self.rank == 0:
+                    import json
+                    line = dict(self.fields, value=None, ms_per_step=None, vs_baseline=None, error=msg)
+                    try:
+                        os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+                    except OSError:
+                        pass
+                os._exit(124)
+
+
 def spawn_ranks(world: int, argv=None, env_extra=None, timeout_s: float | None = None) -> int:
     """start `world` copies of the calling script (same arguments), one rank each, and wait for them.  stdout / stderr are
     inherited (only rank 0 prints the result line).  -> the first non-zero exit code, else 0"""

@@ -49,6 +49,7 @@ CLOCK_HZ = 2.4e9
 # f64 transcendental seed (v_rsq_f64) at a quarter of the f64 rate = 16
 CYC_F32, CYC_F64, CYC_TRANS_F64 = 2.0, 4.0, 16.0
 BF16_MFMA_PEAK_TFLOPS = 2500.0
+ONE_GPU_CONFIG3_MS = 16.67     # BASELINE configs[3] (50M splats, k=32) on ONE MI355X: ms per step, profiles/r05_bench_50m_k32.json
 
 
 # --------------------------------------------------------------------------------------------------- synthetic inputs
@@ -107,12 +108,16 @@ def sor_roofline(n, k, knn_ms, algo=0, n_total=None, single=True):
     alg_bytes = bytes_per_splat * n
     achieved = alg_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
     pmc = load_pmc(kernel, n, k) if single else None
-    traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc and "fetch_bytes" in pmc else None
+    # round 5: FETCH_SIZE calibrated on this code's own access patterns (tools/ubench/fetch_calib.hip, profiles/r05_fetch_calib.txt):
+    # coalesced reads AND per-lane 16-byte gathers are counted at half their bytes (64 B per 128-byte request), writes exactly
+    # (32-byte sectors) -> traffic = 2 x FETCH_SIZE + WRITE_SIZE, as MI355X_MICROARCH.md prescribes
+    traffic = (2 * pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc and "fetch_bytes" in pmc else None
     hbm = {"bound": "hbm", "kernel": kernel, "kernel_ms": round(knn_ms, 4), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(alg_bytes),
            "algorithmic_bytes_per_splat": bytes_per_splat, "traffic": traffic,
-           "traffic_note": ("static: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch from profiles/pmc_latest.json (fetch as "
-                            "counted; the guide's x2 correction applies to wide streaming reads only)") if traffic else None,
+           "traffic_note": ("static: 2 x FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc passes committed in profiles/pmc_latest.json "
+                            "(fetch x2: the gfx950 correction of MI355X_MICROARCH.md, confirmed for this kernel's access patterns by "
+                            "profiles/r05_fetch_calib.txt; writes are counted exactly, one 32-byte sector per isolated 4-byte store)") if traffic else None,
            "note": "BASELINE.json's metric: algorithmic HBM bytes of one launch / its HIP-event duration vs 8 TB/s.  The kernel "
                    "is bound by VALU issue and latency, not by HBM (see valu_issue)"}
     if pmc and pmc.get("valu_insts") and knn_ms > 0:
@@ -570,12 +575,78 @@ def main_single(args):
             r["roofline"]["note"] = "knn_leaf (one wave per Morton leaf), priced like knn_brick; " + r["roofline"]["note"]
             return r
 
+        def config1_brute():
+            # BASELINE.json configs[1] AS WORDED: "1M splats SOR k=16, 1xMI355X (LDS-tiled brute-force KNN)" -- csrc/sor_brute.hip,
+            # --algo 1.  Its roofline is FP32 VALU issue: >= 7 slots per (query, reference) pair, 78.6 T slots/s
+            x1 = synth_uniform(1_000_000, 10.0, 0)
+            r = run_sor(L, ctx, x1, args.k, args.sigma, 3, 1, algo=1)
+            pairs = 1e6 * 1e6
+            rate = pairs / (r["knn_kernel_ms"] * 1e-3) if r["knn_kernel_ms"] > 0 else 0.0
+            r["workload"] = "BASELINE.json configs[1] as worded: 1000000 uniform-random splats (L=10, seed 0), SOR k=%d, LDS-tiled BRUTE-FORCE exact KNN (--algo 1)" % args.k
+            r["roofline"] = {"bound": "valu", "kernel": "knn_brute_kernel", "kernel_ms": r["knn_kernel_ms"], "achieved": round(rate / 1e12, 3),
+                             "peak": 11.2, "unit": "Tpair/s", "frac": round(rate / 11.2e12, 4), "pairs_per_launch": int(pairs), "traffic": None,
+                             "hbm": sor_roofline(1_000_000, args.k, r["knn_kernel_ms"], algo=1, single=False),
+                             "note": "N^2 = 1e12 (query, reference) pairs per launch over the HIP-event kernel time against SURVEY.md 8(d)'s "
+                                     "ceiling of 11.2 T pairs/s (7 FP32 VALU slots per pair: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz / 7); its "
+                                     "streaming bytes (16 B per reference point per 512-query workgroup) are under `hbm` -- brute force "
+                                     "cannot be HBM-bound.  The grid kernel (configs.config1) answers the same 1M cloud ~500x faster"}
+            return r
+
+        def blobs_k25():
+            # what `gsconverter --sor_k 25 --sor_sigma 10.5` (the CLI's defaults, converter.py:228-234) runs on a cloud that is
+            # NOT uniform: six Gaussian blobs of very different density + far flyers -> the Morton-tree path
+            xb = synth_clustered(args.n, 0)
+            r = run_sor(L, ctx, xb, 25, 10.5, small, 2, cpu=want_cpu, adaptive=True)
+            r["workload"] = ("%d splats in six Gaussian blobs (sigma 0.05...1.5) + 2 %% far flyers, SOR k=25 sigma=10.5 (the reference CLI's "
+                             "defaults), adaptive mode (Morton-tree path, csrc/sor_tree.hip)" % args.n)
+            r["roofline"] = sor_roofline(args.n, 25, r["knn_kernel_ms"], single=False)
+            r["roofline"]["kernel"] = "knn_leaf_kernel<25> + the rim kernels (knn_tree_near, knn_tree_query) in the same interval"
+            r["roofline"]["algorithmic_bytes_per_splat"] = 8 * 16 + 16 + 4
+            r["roofline"]["note"] = "knn_leaf (one wave per Morton leaf), priced like knn_brick; " + r["roofline"]["note"]
+            return r
+
+        def dropin_e2e():
+            # what a `gsconverter` user sees (converter.py:150-259): the 62 x f4 = 248-byte rows of a real 3DGS table on the host,
+            # DataProcessor (the lazy class install() binds) -> density filter -> SOR -> `.data` (ONE host compaction)
+            dpmod = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+            names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(45)] + \
+                    ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+            dt = np.dtype([(nm, "f4") for nm in names])
+            assert dt.itemsize == 248
+            table = np.zeros(args.n, dtype=dt)
+            table["x"], table["y"], table["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+            times, kept = [], 0
+            for rep in range(3):
+                t0 = time.perf_counter()
+                proc = dpmod.DataProcessor(table, lazy=True)
+                proc.apply_density_filter(sensitivity=0.5)
+                proc.remove_flyers(k=args.k, threshold_factor=args.sigma)
+                result = proc.data                      # the chain's survivor list applied to the 248-byte rows, once
+                times.append(time.perf_counter() - t0)
+                kept = len(result)
+                del result, proc
+            best = min(times[1:])
+            host_bytes = args.n * 12 + args.n * 248 + kept * 248      # gather xyz (strided read) + read every row + write the survivors
+            return {"workload": "%d x 248-byte host rows (62 f4 fields, uniform xyz L=%g): DataProcessor(lazy) density s=0.5 -> SOR k=%d "
+                                "sigma=%g -> .data, host to host" % (args.n, args.extent, args.k, args.sigma),
+                    "value": round(args.n / best / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(best * 1e3, 2), "steps": 2, "survivors": kept,
+                    "all_runs_ms": [round(t * 1e3, 2) for t in times],
+                    "roofline": {"bound": "host-dram", "achieved": round(host_bytes / best / 1e9, 2), "unit": "GB/s", "peak": None, "frac": None,
+                                 "traffic": None, "algorithmic_bytes": int(host_bytes),
+                                 "note": "host side: threaded gather of the 12-byte xyz out of 248-byte rows, 120 MB over PCIe, the device "
+                                         "chain (configs.config2: ~2.7 ms), survivor list back, ONE threaded compaction of the 2.5 GB table "
+                                         "(read every row, write the survivors).  The reference does np.column_stack + vertices[mask] twice: "
+                                         "~2.6 s at this size (profiles/r01_e2e_probe.log)"}}
+
         attempt("config1", config1)
+        attempt("config1_brute", config1_brute)
         attempt("host_to_host", lambda: run_host_to_host(L, ctx, xyz, args.k, args.sigma, head["ms_per_step"]))
         attempt("config2", lambda: run_chain(L, ctx, gsx, xyz, 0.5, args.k, args.sigma, small, 2, cpu=want_cpu))
         attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu, lanes=args.lanes))
         attempt("clustered_1m", clustered)
         attempt("floaters_10m", floaters)
+        attempt("blobs_10m_k25", blobs_k25)
+        attempt("dropin_e2e_10m", dropin_e2e)
         out["configs"] = configs
         # SURVEY.md 8(d) names two numbers for the metric; both at the top level, unambiguously: `value` (= value_resident) is
         # the whole step with the rows already in HBM -- the harness's definition --, value_host_to_host the call a user of
@@ -637,6 +708,12 @@ def main_multi(args):
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # A rank that never gets past communicator set-up (ncclCommInitRank waiting for a peer that died, a GPU the launcher
+    # did not show) must not hang the job: after GSX_COMM_TIMEOUT seconds (default 600; the ctypes calls release the GIL, so
+    # this thread runs while the main one sits inside librccl) rank 0 prints a JSON line saying so and every rank exits.
+    watchdog = launch.comm_watchdog(rank, world, json_fd, float(os.environ.get("GSX_COMM_TIMEOUT", "600")),
+                                    {"metric": "Msplats/sec SOR k=%d" % args.k, "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
+                                     "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "data": "synthetic"})
     gsx = importlib.import_module("3dgsconverter_amd")
     gdist = importlib.import_module("3dgsconverter_amd.dist")
     gslab = importlib.import_module("3dgsconverter_amd.dist_slab")
@@ -647,11 +724,14 @@ def main_multi(args):
         name, val = kv.split("=")
         ctx.set_param(name, float(val))
     be = gslab.HipSlabBackend(ctx=ctx)
+    if os.environ.get("GSX_TEST_STALL_RANK") == str(rank):   # tests/test_dist_gpu.py: a rank that never shows up
+        time.sleep(1e6)
     transport = launch.agree_transport(rank, world, L.device_uid(device))   # distinct GPUs -> RCCL, shared -> hostwire
     uid = launch.exchange_unique_id(rank, lambda: gslab.RcclComm.unique_id(transport))
     comm = gslab.RcclComm(ctx, rank, world, uid)
     comm.barrier()                      # every rank holds its communicator: the id file has done its job
     launch.retire_unique_id(rank)
+    watchdog.stage("communicator up (%s)" % comm.transport)
     exchange = {"path": "replicated (requested)" if args.exchange == "replicated" else "slab"}
 
     def run(n, extent, steps, warmup, k=None):
@@ -713,11 +793,33 @@ def main_multi(args):
         n_knn, ms_knn = ctx.timing(L.T_SOR_KNN)
         ctx.set_timing(False)
         mask, stats = host(res)
+        # ---- where a step's time goes: a separate pass with every slot recording (HIP events on this rank's stream; not in
+        # the timed region), the slowest rank's figure per phase
+        phases = None
+        if exchange["path"] == "slab":
+            slots = {"knn_ms": L.T_SOR_KNN, "bin_ms": L.T_SOR_BIN, "fallback_ms": L.T_SOR_FALLBACK, "stats_ms": L.T_SOR_STATS,
+                     "slab_kernels_ms": L.T_SLAB_PREP, "exchange_rows_ms": L.T_SLAB_ROWS, "exchange_means_ms": L.T_SLAB_MEANS,
+                     "collectives_ms": L.T_SLAB_COLL}
+            side = max(2, min(steps, 5))
+            ctx.set_param("timing_mask", 0xfff)
+            ctx.set_timing(True)
+            ctx.reset_timing()
+            comm.barrier()
+            for _ in range(side):
+                step()
+            comm.barrier()
+            phases = {}
+            for name, slot in slots.items():
+                phases[name] = round(float(comm.reduce_scalar(ctx.timing(slot)[1] / side, gslab.KIND_F64_MAX)), 4)
+            ctx.set_timing(False)
+            phases["note"] = ("HIP events around each phase on every rank's stream, a separate pass of %d steps, MAX over the ranks; "
+                              "an exchange interval includes the wait for the slowest peer to arrive" % side)
         rows.free()
-        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "survivors": int(mask.sum()), "threshold": float(stats[2])}
+        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "survivors": int(mask.sum()), "threshold": float(stats[2]), "phases": phases}
 
     try:
         main_run = run(args.n, args.extent, args.steps, args.warmup)
+        watchdog.stage("headline timed")
         config3 = None
         if not args.no_secondary:
             # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
@@ -730,10 +832,30 @@ def main_multi(args):
                                        "sigma=%g" % (n3 * world, world, args.sigma),
                            "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
                            "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
-                           "knn_kernel_ms": round(r3["knn_ms"], 4), "survivors_rank0": r3["survivors"]}
+                           "scaling": "strong", "n_gpus": world, "one_gpu_ms_per_step": ONE_GPU_CONFIG3_MS,
+                           "speedup_vs_one_gpu": round(ONE_GPU_CONFIG3_MS / (r3["dt"] / s3 * 1e3), 3),
+                           "speedup_note": "strong scaling of BASELINE configs[3]: the same 50M splats on 1 GPU take %.2f ms per step "
+                                           "(profiles/r05_bench_50m_k32.json, measured on 1xMI355X); this line divides that by this run's "
+                                           "step time" % ONE_GPU_CONFIG3_MS,
+                           "knn_kernel_ms": round(r3["knn_ms"], 4), "survivors_rank0": r3["survivors"], "phases": r3["phases"]}
             except gsx._lib.GsxError as e:   # the headline line must survive a failure here (a GsxError is raised by every
                 config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}   # rank that hits it; anything else aborts)
         ctx.check()
+        watchdog.stage("configs[3] timed")
+        # cpu_baseline leg (rank 0, its own shard: what one GPU of the job replaces), while the other ranks wait at the barrier
+        cpu = None
+        if rank == 0 and not args.no_cpu_baseline:
+            from oracle import sor as osor
+            xyz0 = synth_uniform(args.n, args.extent, 0)
+            workers = max(1, (os.cpu_count() or 2) - 1)
+            t0 = time.perf_counter()
+            osor.mean_dists_ckdtree(xyz0, args.k, workers=workers)
+            cdt = time.perf_counter() - t0
+            cpu = {"value": round(args.n / cdt / 1e6, 4), "unit": "Msplats/s", "cores": workers, "kind": "port",
+                   "sample": "rank 0's shard (%d splats), once (%.2f s): scipy cKDTree build + query(k+1) workers=%d, as "
+                             "data_processor.py:156-173 does -- the work ONE GPU of this job replaces; the job's CPU equivalent is the "
+                             "same call on all %d splats" % (args.n, cdt, workers, args.n * world)}
+        watchdog.stage("cpu baseline done")
     except BaseException:
         comm.abort()
         raise
@@ -756,18 +878,23 @@ def main_multi(args):
             "roofline": sor_roofline(args.n, args.k, main_run["knn_ms"], args.algo, n_total=n_total, single=False),
             "kernel_ms_per_step": {"knn": round(main_run["knn_ms"], 4)},
             "survivors_rank0": main_run["survivors"], "threshold": main_run["threshold"]}
+        if main_run["phases"] is not None:
+            out["phases_ms_per_step"] = main_run["phases"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         if config3 is not None:
             out["config3"] = config3
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     comm.barrier()
+    watchdog.done()
     comm.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # (no flags: a 0.2 s timed region; the driver passes its own K and W)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sor", choices=["sor", "kmeans"])
     ap.add_argument("--n", type=int, default=10_000_000, help="splats per GPU")
     ap.add_argument("--k", type=int, default=16)

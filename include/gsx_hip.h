@@ -51,7 +51,12 @@ enum {
     GSX_T_KMEANS_ASSIGN = 5,
     GSX_T_KMEANS_UPDATE = 6,
     GSX_T_QUANTIZE = 7,
-    GSX_T_SLOTS = 8
+    /* multi-GPU slab step (gsx_sor_slab_step_dev), round 5: where a step's time goes besides the KNN slots above */
+    GSX_T_SLAB_PREP = 8,   /* this rank's own passes: clear, box, histogram, partition, un-permute            */
+    GSX_T_SLAB_ROWS = 9,   /* rows (own + halo) to the slab owners: the grouped send / receive over xGMI     */
+    GSX_T_SLAB_MEANS = 10, /* mean distances back to the index owners (+ the < 8192 head elements)            */
+    GSX_T_SLAB_COLL = 11,  /* the small collectives: box all-reduce, histogram and piece-sum all-gathers     */
+    GSX_T_SLOTS = 12
 };
 
 /* diagnostics of one SOR KNN call (all counts are exact) */

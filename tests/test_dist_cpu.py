@@ -491,3 +491,37 @@ def test_unique_id_rendezvous_through_a_file(tmp_path):
     assert not os.path.exists(path)
     assert launch.pick_device_and_transport(3, 8, 8)[:2] == (3, os.environ.get("GSX_COMM_TRANSPORT") or "rccl")
     assert launch.pick_device_and_transport(1, 2, 1)[:2] == (0, os.environ.get("GSX_COMM_TRANSPORT") or "hostwire")
+
+
+def test_comm_watchdog_ends_a_stuck_job_with_a_json_line():
+    """launch.comm_watchdog (no GPU needed): a stage that does not finish within the timeout -> rank 0 writes one JSON line
+    with an "error" field and the process exits 124; stage() restarts the clock, done() disarms it"""
+    import json
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import importlib, time
+        launch = importlib.import_module("3dgsconverter_amd.launch")
+        w = launch.comm_watchdog(0, 2, 1, 1.0, {"metric": "m", "n_gpus": 2})
+        w.stage("first")
+        time.sleep(0.6)
+        w.stage("second")          # the clock restarts: 0.6 + 0.6 s pass without a timeout
+        time.sleep(0.6)
+        w.stage("third")
+        time.sleep(30)
+        print("not reached")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=60)
+    assert r.returncode == 124
+    d = json.loads(r.stdout.strip())
+    assert d["value"] is None and d["n_gpus"] == 2 and "'third'" in d["error"]
+    code2 = textwrap.dedent("""
+        import importlib, time
+        launch = importlib.import_module("3dgsconverter_amd.launch")
+        w = launch.comm_watchdog(1, 2, 1, 0.3, {})
+        w.done()
+        time.sleep(1.0)
+        print("finished")
+    """)
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=ROOT, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "finished"

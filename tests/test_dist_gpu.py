@@ -452,8 +452,37 @@ def test_bench_gpus_2_end_to_end(launcher, tmp_path):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_ms"] > 0
     c3 = d["config3"]
     assert "error" not in c3 and c3["value"] > 0 and c3["exchange"] == "slab"
+    # round 5: where the step's time goes (HIP events per phase, MAX over the ranks), the CPU baseline of rank 0's shard,
+    # configs[3] as a strong-scaling line
+    ph = d["phases_ms_per_step"]
+    for key in ("knn_ms", "bin_ms", "exchange_rows_ms", "exchange_means_ms", "collectives_ms", "slab_kernels_ms", "stats_ms"):
+        assert ph[key] > 0, (key, ph)
+    assert ph["knn_ms"] < d["ms_per_step"] * 1.5
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert c3["scaling"] == "strong" and c3["n_gpus"] == 2 and c3["speedup_vs_one_gpu"] > 0 and c3["phases"]["knn_ms"] > 0
     # the survivors of rank 0's shard of the 2 x 400 000 cloud, against the oracle on the whole cloud
     full = np.concatenate([datasets.uniform(400000, 5.0, r) for r in range(2)])
     ref = osor.sor(full, 16, 1.0)
     assert d["survivors_rank0"] == int(ref["mask"][:400000].sum())
     assert np.float32(d["threshold"]).tobytes() == np.float32(ref["threshold"]).tobytes()
+
+
+def test_bench_gpus_2_rank_that_never_arrives_ends_with_a_json_error_line():
+    """round 5: a rank stuck before the communicator exists -- here rank 1 simply sleeps -- must not hang
+    the job until the DRIVER's timeout: after GSX_COMM_TIMEOUT seconds rank 0 prints ONE parseable JSON line with an "error"
+    field and the job exits non-zero (3dgsconverter_amd/launch.py: comm_watchdog)."""
+    import json
+    import subprocess
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "100000", "--no-secondary"]
+    env = dict(os.environ, GSX_TEST_STALL_RANK="1", GSX_COMM_TIMEOUT="6")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GSX_RDZV_FILE"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert time.time() - t0 < 120
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (lines, out.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "GSX_COMM_TIMEOUT" in d["error"] and "communicator set-up" in d["error"]
