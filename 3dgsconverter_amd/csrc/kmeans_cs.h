@@ -9,6 +9,14 @@
 // and the uncertain list are those of kmeans_assign_mfma_kernel (gpu_ops.py:57-73 is what both replace).
 #pragma once
 
+// Round 5 experiment: the four waves of a SIMD leave every workgroup barrier in phase -- their dependent MFMA chains interleave
+// in the matrix pipe and end together, then all four run their selection on the VALU while the matrix pipe idles (matrix pipe
+// 39 % + VALU 46 % busy, ADDING up: profiles/r04_variants.txt).  GSX_KM_SKEW > 0: the waves 4..7 and 12..15 (every second
+// wave of each SIMD) sleep 64 x GSX_KM_SKEW cycles after a barrier, so that one pair of waves selects while the other
+// pair's chains run.
+#ifndef GSX_KM_SKEW
+#define GSX_KM_SKEW 0
+#endif
 constexpr int KM_CS_WAVES = 16;                // 8 waves x 4 centroid tiles: equal (profiles/r02_variants.txt)
 constexpr int KM_CS_CT = 32 / KM_CS_WAVES;    // centroid tiles per wave -> K <= KM_CS_WAVES * KM_CS_CT * 32 = 1024
 constexpr int KM_CS_PTILES = 4;              // 32-point tiles per block
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     // in front of the MFMA chain for the first trip's sake, which in every later trip waits for the NEXT block's prefetch
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     __syncthreads();
+    if (GSX_KM_SKEW > 0 && ((wv >> 2) & 1)) __builtin_amdgcn_s_sleep(GSX_KM_SKEW);
     int cur = 0;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
         const int64_t base = blk * KM_CS_BLOCK;
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
         }
         if (has_next) split_store(cur ^ 1);
         __syncthreads();   // this block's views are complete, the next block's operand words are in place
+        if (GSX_KM_SKEW > 0 && ((wv >> 2) & 1)) __builtin_amdgcn_s_sleep(GSX_KM_SKEW);
         // (one thread per point loops over the 16 views: 47 us; 8 lanes per point + three shuffle rounds measured 51)
         if ((int)threadIdx.x < rows) {
             const int p = threadIdx.x;

@@ -773,10 +773,16 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 const double emx = fmax(fmax(e3[0], e3[1]), e3[2]);
                 const double vt = fmax(e3[0], 1e-3 * emx) * fmax(e3[1], 1e-3 * emx) * fmax(e3[2], 1e-3 * emx);
                 const double rt = 1.3 * cbrt(0.397 * (double)(k + 1) * vt / (double)min(nq - qb, 64));
-                if (is_query) {
-                    const unsigned slot = atomicAdd(&tp->fail_count, 1u);
-                    faillist[slot] = (unsigned)qidx;
-                    failbound[slot] = -fmax(rt * rt, 0.25 * s * s);
+                {   // one run of list entries per leaf (knn_tree_near takes neighbouring entries together)
+                    const unsigned long long fb = __ballot(is_query);
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&tp->fail_count, (unsigned)__popcll(fb));
+                    base = (unsigned)uniform((int)base);
+                    if (is_query) {
+                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u));
+                        faillist[slot] = (unsigned)qidx;
+                        failbound[slot] = -fmax(rt * rt, 0.25 * s * s);
+                    }
                 }
                 continue;
             }
@@ -970,16 +976,24 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             }
             drain();
 
-            if (is_query) {
+            {
                 const double kth_d2 = lst.kth(k);
                 const double racc_sq = accept_radius_sq();
-                if (GSX_TREE_ABL) {
+                const bool failed = is_query && !GSX_TREE_ABL && !(kth_d2 <= racc_sq);
+                // the queries this leaf could not certify: ONE run of list entries (one atomic per leaf; knn_tree_near takes
+                // neighbouring entries together)
+                const unsigned long long fb = __ballot(failed);
+                unsigned fbase = 0;
+                if (fb != 0ull && lane == 0) fbase = atomicAdd(&tp->fail_count, (unsigned)__popcll(fb));
+                fbase = (unsigned)uniform((int)fbase);
+                if (!is_query) {
+                } else if (GSX_TREE_ABL) {
                     mean_out[qorig] = (float)kth_d2;   // keeps the list live, never fails
                 } else if (kth_d2 <= racc_sq) {
                     if (kth_out) kth_out[qorig] = kth_d2;
                     mean_out[qorig] = mean_from_net(lst, k);
                 } else {
-                    const unsigned slot = atomicAdd(&tp->fail_count, 1u);
+                    const unsigned slot = fbase + __builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u));
                     faillist[slot] = (unsigned)qidx;
                     // the filter only let candidates inside the acceptance radius through, of which there were fewer than k (a full
                     // list would bound the k-th distance): the next ball to try is 1.3x wider -- 2.2x the volume
