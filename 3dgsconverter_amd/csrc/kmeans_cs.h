@@ -9,18 +9,19 @@
 // and the uncertain list are those of kmeans_assign_mfma_kernel (gpu_ops.py:57-73 is what both replace).
 #pragma once
 
-// Round 5 experiment: the four waves of a SIMD leave every workgroup barrier in phase -- their dependent MFMA chains interleave
-// in the matrix pipe and end together, then all four run their selection on the VALU while the matrix pipe idles (matrix pipe
-// 39 % + VALU 46 % busy, ADDING up: profiles/r04_variants.txt).  GSX_KM_SKEW > 0: the waves 4..7 and 12..15 (every second
-// wave of each SIMD) sleep 64 x GSX_KM_SKEW cycles after a barrier, so that one pair of waves selects while the other
-// pair's chains run.
-#ifndef GSX_KM_SKEW
-#define GSX_KM_SKEW 0
+// Round 5: profiling builds only (results become wrong).  GSX_KM_ABL bit 0: no merge of the 16 per-wave views / no label store,
+// bit 1: the next block is neither fetched nor split (every block computes on the first block's operands).
+#ifndef GSX_KM_ABL
+#define GSX_KM_ABL 0
+#endif
+#ifndef GSX_KM_ML   // lanes per point in the merge of the per-wave views: 1 (rounds 2-4), 2, 4 or 8
+#define GSX_KM_ML 1
 #endif
 constexpr int KM_CS_WAVES = 16;                // 8 waves x 4 centroid tiles: equal (profiles/r02_variants.txt)
 constexpr int KM_CS_CT = 32 / KM_CS_WAVES;    // centroid tiles per wave -> K <= KM_CS_WAVES * KM_CS_CT * 32 = 1024
 constexpr int KM_CS_PTILES = 4;              // 32-point tiles per block
 constexpr int KM_CS_BLOCK = 32 * KM_CS_PTILES;
+constexpr int KM_CS_ML = GSX_KM_ML;
 
 template <int D>
 __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel(const float *__restrict__ data, int64_t n,
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     // per-wave results are merged while block b+1 runs
     __shared__ ku32x4 s_x[2][KM_CS_PTILES][NS][2][64];   // point operand words: (tile, slice, hi/lo, lane)
     __shared__ float s_part[2][KM_CS_BLOCK][NS * 2];     // |x|^2 by operand word (summed in a fixed order by the merge)
-    __shared__ float s_best[2][KM_CS_WAVES][KM_CS_BLOCK], s_second[2][KM_CS_WAVES][KM_CS_BLOCK];
-    __shared__ int s_idx[2][KM_CS_WAVES][KM_CS_BLOCK];
+    // (rows padded by two words: the merge reads view 2 sub + u of point p with 8 lanes per point -- bank 4 sub + 2 u + p)
+    __shared__ float s_best[2][KM_CS_WAVES][KM_CS_BLOCK + 2], s_second[2][KM_CS_WAVES][KM_CS_BLOCK + 2];
+    __shared__ int s_idx[2][KM_CS_WAVES][KM_CS_BLOCK + 2];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float nc2 = *cmax2, nc = __builtin_sqrtf(nc2);
@@ -110,12 +112,11 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     // in front of the MFMA chain for the first trip's sake, which in every later trip waits for the NEXT block's prefetch
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     __syncthreads();
-    if (GSX_KM_SKEW > 0 && ((wv >> 2) & 1)) __builtin_amdgcn_s_sleep(GSX_KM_SKEW);
     int cur = 0;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
         const int64_t base = blk * KM_CS_BLOCK;
         const int rows = (int)(n - base < KM_CS_BLOCK ? n - base : KM_CS_BLOCK);
-        const bool has_next = blk + gridDim.x < nblocks;
+        const bool has_next = blk + gridDim.x < nblocks && !(GSX_KM_ABL & 2);
         if (has_next) fetch(blk + gridDim.x);
         // ---- every point tile of the block against this wave's centroid tiles
 #pragma unroll 1
@@ -168,20 +169,45 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
         }
         if (has_next) split_store(cur ^ 1);
         __syncthreads();   // this block's views are complete, the next block's operand words are in place
-        if (GSX_KM_SKEW > 0 && ((wv >> 2) & 1)) __builtin_amdgcn_s_sleep(GSX_KM_SKEW);
-        // (one thread per point loops over the 16 views: 47 us; 8 lanes per point + three shuffle rounds measured 51)
-        if ((int)threadIdx.x < rows) {
-            const int p = threadIdx.x;
+        // The merge of the 16 per-wave views: KM_CS_ML lanes per point, 16 / KM_CS_ML views per lane, log2(KM_CS_ML) shuffle
+        // rounds, by the first 128 x KM_CS_ML threads.  (The min / second-min of a multiset does not depend on the merge order;
+        // an exact tie of the two smallest makes the point uncertain whichever index is kept.)  Round 5 measured where this
+        // sits: WITHOUT it (GSX_KM_ABL=1) the kernel is a quarter faster -- the merging waves start the next block late and the
+        // others wait for them at its barrier -- but spreading it over all 16 waves (KM_CS_ML = 8) is slower still (41.4 against
+        // 39.5 ms per palette): every wave then pays the LDS round trips.  profiles/r05_variants.txt.
+        {
+            constexpr int ML = KM_CS_ML, VPL = KM_CS_WAVES / ML;
+            if ((int)threadIdx.x >= KM_CS_BLOCK * ML) continue;   // (whole waves: KM_CS_BLOCK * ML is a multiple of 64)
+            const int p = (int)threadIdx.x / ML, sub = (int)threadIdx.x % ML;
             const int nw = min(KM_CS_WAVES, (ktiles + KM_CS_CT - 1) / KM_CS_CT);
-            float mb = s_best[cur][0][p], ms = s_second[cur][0][p];
-            int mi = s_idx[cur][0][p];
-            for (int w = 1; w < nw; ++w) {
-                const float b = s_best[cur][w][p], sc = s_second[cur][w][p];
-                const float nsec = fminf(fmaxf(mb, b), fminf(ms, sc));
-                mi = b < mb ? s_idx[cur][w][p] : mi;
-                mb = fminf(mb, b);
+            float mb = __builtin_inff(), ms = __builtin_inff();
+            int mi = 0;
+            if (p < rows) {
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) {
+                    const int w = VPL * sub + u;
+                    if (w < nw) {
+                        const float b = s_best[cur][w][p], sc = s_second[cur][w][p];
+                        const int ix = s_idx[cur][w][p];
+                        const float nsec = fminf(fmaxf(mb, b), fminf(ms, sc));
+                        mi = b < mb ? ix : mi;
+                        mb = fminf(mb, b);
+                        ms = nsec;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < ML; off <<= 1) {
+                const float ob = __shfl_xor(mb, off), os = __shfl_xor(ms, off);
+                const int oi = __shfl_xor(mi, off);
+                const float nsec = fminf(fmaxf(mb, ob), fminf(ms, os));
+                // on an exact tie both lanes keep the index of the lower view group (such a point is uncertain anyway)
+                const bool take = ob < mb || (ob == mb && (sub & off) != 0);
+                mi = take ? oi : mi;
+                mb = fminf(mb, ob);
                 ms = nsec;
             }
+            if (sub != 0 || p >= rows || (GSX_KM_ABL & 1)) continue;
             float nx2 = 0.0f;
 #pragma unroll
             for (int q = 0; q < NS * 2; ++q) nx2 += s_part[cur][p][q];
