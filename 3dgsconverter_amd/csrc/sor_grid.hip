@@ -53,7 +53,10 @@ constexpr int MAX_BUCKET_CELLS = 4096;    // LDS counters of the fine pass (16 K
 #define GSX_BUCKET_POINTS 4096
 #endif
 constexpr int BUCKET_POINTS = GSX_BUCKET_POINTS;   // target points per bucket (tuning builds: -DGSX_BUCKET_POINTS, with GSX_SORT_THREADS)
-constexpr int BIN_TILE = 8192;            // points per workgroup tile in the coarse pass (4096 / 16384: no better)
+#ifndef GSX_BIN_TILE
+#define GSX_BIN_TILE 8192
+#endif
+constexpr int BIN_TILE = GSX_BIN_TILE;    // points per workgroup tile in the coarse pass (4096 / 16384: no better)
 constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
 constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of knn_heavy_scan covers (512 per lane: the
@@ -444,7 +447,10 @@ __device__ void bucket_scan_body(int nb, unsigned *bk_cnt, unsigned *bk_start, u
     if (threadIdx.x == 0) bk_start[nb] = carry;
 }
 
-constexpr int SCATTER_THREADS = 1024;
+#ifndef GSX_SCATTER_THREADS
+#define GSX_SCATTER_THREADS 1024
+#endif
+constexpr int SCATTER_THREADS = GSX_SCATTER_THREADS;
 constexpr int SCATTER_PPT = BIN_TILE / SCATTER_THREADS;  // points per thread, kept in registers
 
 // One 8192-point tile per workgroup of 1024 threads, every point read ONCE: coordinates, bucket and the rank the

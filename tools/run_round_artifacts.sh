@@ -3,7 +3,7 @@
 # commands, PMC passes (separate passes: TCC FETCH / WRITE, SQ issue counters).  usage: run_round_artifacts.sh r02
 set -u
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -28,10 +28,11 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MU
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 -d $OUT/pmc_sq4_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 # the clouds a uniform grid is bad at: adaptive mode -> Morton-tree path (csrc/sor_tree.hip)
-for C in "clustered 1000000" "floaters 10000000" "clustered 10000000"; do
+for C in "clustered 1000000 16" "floaters 10000000 16" "clustered 10000000 16" "clustered 10000000 25"; do
   set -- $C
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_tree_$1_$2 -o trace -- python $ROOT/tests/devtools/probe_tree.py time $1 $2 1 > $OUT/tree_trace_${R}_$1_$2.log 2>&1
-  python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_tree_$1_$2/trace_results.db > $OUT/kernel_stats_${R}_tree_$1_$2.txt 2>&1
+  PROBE_K=$3 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_tree_$1_$2_k$3 -o trace -- python $ROOT/tests/devtools/probe_tree.py time $1 $2 1 > $OUT/tree_trace_${R}_$1_$2_k$3.log 2>&1
+  python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_tree_$1_$2_k$3/trace_results.db > $OUT/kernel_stats_${R}_tree_$1_$2_k$3.txt 2>&1
+  rm -rf $OUT/prof_${R}_tree_$1_$2_k$3
 done
 # counters of the tree path's kernels on the 10M scene (separate passes; only the text summary travels back)
 TC="python $ROOT/tests/devtools/probe_tree.py time floaters 10000000 1"
@@ -42,7 +43,14 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_tree4 -o pmc -- $TC > /dev/nu
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_tree5 -o pmc -- $TC > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py --pmc $OUT/pmc_tree1/pmc_results.db $OUT/pmc_tree2/pmc_results.db $OUT/pmc_tree3/pmc_results.db $OUT/pmc_tree4/pmc_results.db $OUT/pmc_tree5/pmc_results.db 2>&1 | grep -E "^#|^kernel|knn_leaf|knn_tree|tree_" > $OUT/pmc_${R}_tree.txt
 rm -rf $OUT/pmc_tree1 $OUT/pmc_tree2 $OUT/pmc_tree3 $OUT/pmc_tree4 $OUT/pmc_tree5
+# counter calibration on known byte counts (tools/ubench/fetch_calib.hip) and the matrix / vector overlap probe
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/calib_fetch_${R} -o pmc -- $ROOT/tools/ubench/fetch_calib > $OUT/calib_${R}.txt 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/calib_write_${R} -o pmc -- $ROOT/tools/ubench/fetch_calib > /dev/null 2>&1
+python $ROOT/tools/rocpd_summary.py --pmc $OUT/calib_fetch_${R}/pmc_results.db $OUT/calib_write_${R}/pmc_results.db > $OUT/calib_pmc_${R}.txt 2>&1
+rm -rf $OUT/calib_fetch_${R} $OUT/calib_write_${R}
+timeout 120 $ROOT/tools/ubench/mfma_valu_overlap > $OUT/mfma_valu_overlap_${R}.txt 2>&1
 cd $ROOT
+timeout 600 python bench.py --gpus 8 --steps 5 --warmup 2 --n 1000000 --n3 4000000 --no-cpu-baseline > $OUT/bench_${R}_gpus8_hostwire.json 2>> $OUT/bench_${R}.err
 for T in "" _km _slab; do python tools/rocpd_summary.py $OUT/prof_${R}${T}/trace_results.db > $OUT/kernel_stats_${R}${T}.txt 2>&1; done
 python tools/rocpd_summary.py --pmc $OUT/pmc_fetch_${R}/pmc_results.db $OUT/pmc_write_${R}/pmc_results.db > $OUT/pmc_${R}_tcc.txt 2>&1
 python tools/rocpd_summary.py --pmc $OUT/pmc_sq1_${R}/pmc_results.db $OUT/pmc_sq2_${R}/pmc_results.db $OUT/pmc_sq3_${R}/pmc_results.db $OUT/pmc_sq4_${R}/pmc_results.db $OUT/pmc_grbm_${R}/pmc_results.db > $OUT/pmc_${R}_sq.txt 2>&1
