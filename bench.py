@@ -638,8 +638,34 @@ def main_single(args):
                                          "(read every row, write the survivors).  The reference does np.column_stack + vertices[mask] twice: "
                                          "~2.6 s at this size (profiles/r01_e2e_probe.log)"}}
 
+        def config3_one_gpu():
+            # BASELINE.json configs[3] (50M splats, k=32) on ONE GPU: the N = 1 point of its strong-scaling curve (the N > 1 runs
+            # of this file report configs[3] split over their ranks, with speedup_vs_one_gpu against ONE_GPU_CONFIG3_MS)
+            n3 = 50_000_000
+            x3 = synth_uniform(n3, 10.0, 0)
+            r = run_sor(L, ctx, x3, 32, args.sigma, 5, 2, groups=True)
+            r["workload"] = "BASELINE.json configs[3] on one GPU: %d uniform-random splats (L=10, seed 0), SOR k=32 sigma=%g, xyz resident in HBM" % (n3, args.sigma)
+            r["scaling"] = "strong"
+            r["n_gpus"] = 1
+            r["roofline"] = sor_roofline(n3, 32, r["knn_kernel_ms"], single=False)
+            r["roofline"]["algorithmic_bytes_per_splat"] = 12 * 16 + 16 + 4
+            r["roofline"]["note"] = ("k=32 runs 2x2x1-cell bricks at 13.5 points per cell: a brick streams 4x4x3 cells = 12x its own points; "
+                                     "priced with knn_brick's 148 B/splat for comparability; ") + r["roofline"]["note"]
+            if want_cpu:
+                from oracle import sor as osor
+                m = 4_000_000
+                workers = max(1, (os.cpu_count() or 2) - 1)
+                t0 = time.perf_counter()
+                osor.mean_dists_ckdtree(x3[:m], 32, workers=workers)
+                cdt = time.perf_counter() - t0
+                r["cpu_baseline"] = {"value": round(m / cdt / 1e6, 4), "unit": "Msplats/s", "cores": workers, "kind": "port",
+                                     "sample": "the first %d of the 50M splats, k=32, once (%.2f s): cKDTree build + query(k+1); a SUBSAMPLE -- the "
+                                               "full 50M reference run took 286 s on 8 cores of the build container (tests/golden/large_cases.json)" % (m, cdt)}
+            return r
+
         attempt("config1", config1)
         attempt("config1_brute", config1_brute)
+        attempt("config3_one_gpu", config3_one_gpu)
         attempt("host_to_host", lambda: run_host_to_host(L, ctx, xyz, args.k, args.sigma, head["ms_per_step"]))
         attempt("config2", lambda: run_chain(L, ctx, gsx, xyz, 0.5, args.k, args.sigma, small, 2, cpu=want_cpu))
         attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu, lanes=args.lanes))
