@@ -120,6 +120,11 @@ def sor_roofline(n, k, knn_ms, algo=0, n_total=None, single=True):
                             "profiles/r05_fetch_calib.txt; writes are counted exactly, one 32-byte sector per isolated 4-byte store)") if traffic else None,
            "note": "BASELINE.json's metric: algorithmic HBM bytes of one launch / its HIP-event duration vs 8 TB/s.  The kernel "
                    "is bound by VALU issue and latency, not by HBM (see valu_issue)"}
+    if pmc and pmc.get("valu_busy_frac"):
+        # name the resource that actually binds next to BASELINE.json's HBM fraction
+        hbm["binding_resource"] = {"name": "valu_issue", "busy_frac": pmc["valu_busy_frac"],
+                                   "note": "the kernel is bound by VALU issue, not HBM: 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) "
+                                           "of the committed rocprofv3 --pmc pass (static, %s); `frac` above stays BASELINE.json's metric" % pmc.get("source", "pmc_latest.json")}
     if pmc and pmc.get("valu_insts") and knn_ms > 0:
         # VALU issue cycles of one launch from the committed instruction counts (a property of build + cloud, labelled
         # static) weighted with the guide's per-instruction cycles, against SIMDs x clock x this run's kernel duration
