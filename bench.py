@@ -656,7 +656,7 @@ def main_single(args):
             r["roofline"]["algorithmic_bytes_per_splat"] = 12 * 16 + 16 + 4
             r["roofline"]["note"] = ("k=32 runs 2x2x1-cell bricks at 13.5 points per cell: a brick streams 4x4x3 cells = 12x its own points; "
                                      "priced with knn_brick's 148 B/splat for comparability; ") + r["roofline"]["note"]
-            if want_cpu:
+            if want_cpu:   # cpu_baseline leg: the reference's CPU path on a bounded subsample of the same cloud
                 from oracle import sor as osor
                 m = 4_000_000
                 workers = max(1, (os.cpu_count() or 2) - 1)
