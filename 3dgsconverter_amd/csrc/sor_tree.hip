@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
     TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
     const float4 *__restrict__ refs, const float4 *__restrict__ boxes, const unsigned *__restrict__ faillist,
     const double *__restrict__ failbound, int k, int q_begin, float *__restrict__ mean_out, double *__restrict__ kth_out,
-    unsigned *__restrict__ faillist2, double *__restrict__ failbound2)
+    unsigned *__restrict__ faillist2, double *__restrict__ failbound2, double cell_frac)
 {
     __shared__ double s_cand[TREE_THREADS / 64][TQ_CAND];
     __shared__ double s_out[TREE_THREADS / 64][64];
@@ -1096,8 +1096,8 @@ __global__ __launch_bounds__(TREE_THREADS, 6) void knn_tree_near_kernel(
         for (int attempt = 0;; ++attempt) {
             const double rin = fmax(r - 2.0 * slack, 0.0);
             const double T = bound >= 0.0 ? bound : rin * rin;
-            int Lg = 0;   // cells of 2^Lg fine cells: the smallest with an edge of at least r / 2
-            while (Lg < TB && s * (double)(1u << Lg) < 0.5 * r) ++Lg;
+            int Lg = 0;   // cells of 2^Lg fine cells: the smallest with an edge of at least cell_frac x r ("tree_near_cell", 0.5)
+            while (Lg < TB && s * (double)(1u << Lg) < cell_frac * r) ++Lg;
             const double g = s * (double)(1u << Lg);
             int c0[3], nc[3];
 #pragma unroll
@@ -1684,7 +1684,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
     hipLaunchKernelGGL(knn_tree_near_kernel, dim3(ctx->num_cu * 6), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
                        w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.blockboxes.as<float4>(), w.faillist.as<unsigned>(),
-                       w.failbound.as<double>(), k, (int)q_begin, mean_out, kth_out, w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n);
+                       w.failbound.as<double>(), k, (int)q_begin, mean_out, kth_out, w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n,
+                       ctx->tree_near_cell);
     hipLaunchKernelGGL(knn_tree_query_kernel, dim3(ctx->num_cu * 3), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
                        w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.blockboxes.as<float4>(),
                        w.faillist.as<unsigned>() + n, w.failbound.as<double>() + n, k, (int)q_begin, (int)q_count, mean_out, kth_out);
