@@ -869,6 +869,7 @@ class DeviceChain:
         self.empty = False                  # keep_none(): no survivor, whatever self.orig says
         self.mask = self.ctx.alloc(self.n0 + 16)
         self._md = self._st = None          # SOR work buffers (mean distances, statistics), allocated on first use
+        self._pristine_box = None           # box of the uploaded rows, when it was measured before any filter ran (restart() keeps it)
         self._box = None                    # box of the rows at the first density_filter() (a superset of every LATER state of the
                                             # chain; restart() drops it).  gsx_density_filter_dev re-derives the frame itself when
                                             # a row falls outside the box it was given (status word `oob` of the device result)
@@ -882,9 +883,10 @@ class DeviceChain:
             self._pool.append(self.orig)
         self.orig = None
         self.n, self.empty = self.n0, False
-        # the cached box is the box of the rows that were current at the first density_filter() -- after a restart
-        # the pristine rows may reach beyond it: drop it, the next density_filter() measures again
-        self._box = None
+        # the cached box is the box of the rows that were current at the first density_filter() -- after a restart the
+        # pristine rows may reach beyond it: back to the box of the PRISTINE rows if that is what was
+        # measured (no filter had run yet), else to "not measured"
+        self._box = self._pristine_box
 
     def _xyz(self):
         p = self.rows.ptr
@@ -916,9 +918,11 @@ class DeviceChain:
     def density_filter(self, voxel_size: float, min_points: int, keep_multicluster: bool):
         """the whole density filter on the device (gsx_density_filter_dev) -> dict(status, n_unique, kept_clusters, largest,
         left: rows after the compaction) ; status DENSITY_HOST: nothing was applied, take the host path"""
-        if self._box is None:     # box of the rows this chain started from: a superset of whatever survives later filters
+        if self._box is None:     # box of the rows as they are now: a superset of whatever survives later filters
             lo, hi = self.bbox()
             self._box = np.array(list(lo) + list(hi), dtype=np.float32)
+            if self.orig is None and not self.empty:     # nothing has been removed yet: this IS the box of the uploaded rows
+                self._pristine_box = self._box
         info = DensityInfo()
         x, y, z, st = self._xyz()
         check(self.ctx.lib.gsx_density_filter_dev(self.ctx.handle, x, y, z, st, self.n, float(voxel_size), int(min_points),
