@@ -99,6 +99,7 @@ SIGNATURES = {
     "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
+    "gsx_host_gather_columns_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
     "gsx_host_zero_columns": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I]),
     "gsx_host_append_columns": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64]),
@@ -252,6 +253,26 @@ def host_gather_xyz(vertices: np.ndarray, names=("x", "y", "z")) -> np.ndarray:
     offs = (_I64 * len(names))(*[int(fields[nm][1]) for nm in names])
     check(load().gsx_host_gather_f32(vertices.ctypes.data, vertices.dtype.itemsize, n, offs, len(names), out.ctypes.data),
           "gsx_host_gather_f32")
+    return out
+
+
+def host_gather_columns(vertices: np.ndarray, names) -> np.ndarray:
+    """(len(names), n) float32, row c = np.ascontiguousarray(vertices[names[c]]): every column a writer uploads, in ONE threaded
+    pass over the table (C ABI gsx_host_gather_columns_f32) instead of one strided numpy copy per column"""
+    names = list(names)
+    fields = vertices.dtype.fields or {}
+    n = len(vertices)
+    ok = (vertices.ndim == 1 and vertices.flags.c_contiguous and 1 <= len(names) <= 64 and
+          all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names))
+    if not ok or n == 0:
+        out = np.empty((len(names), n), dtype=np.float32)
+        for i, nm in enumerate(names):
+            out[i] = vertices[nm]
+        return out
+    out = np.empty((len(names), n), dtype=np.float32)
+    offs = (_I64 * len(names))(*[int(fields[nm][1]) for nm in names])
+    check(load().gsx_host_gather_columns_f32(vertices.ctypes.data, vertices.dtype.itemsize, n, offs, len(names), out.ctypes.data),
+          "gsx_host_gather_columns_f32")
     return out
 
 
@@ -722,6 +743,58 @@ def cply_pack(columns: dict, order: "np.ndarray | None", sh_columns=(), ctx: "Co
             check(ctx.lib.gsx_cply_sh_dev(ctx.handle, d_sh.ptr, m, n, d_order.ptr if d_order else None, n, d_out.ptr), "gsx_cply_sh_dev")
             sh = d_out.download(np.uint8, n * m).reshape(n, m)
         return chunks, verts, sh
+    finally:
+        for b in bufs:
+            b.free()
+        if own:
+            ctx.close()
+
+
+def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = None, ctx: "Context | None" = None):
+    """The compressed-PLY writer's numeric core on a whole splat table (formats/compressed_ply.py:200-297): ONE threaded gather
+    of the 13 + 1 + len(sh_names) columns (host_gather_columns), numpy's sigmoid of the opacity (the reference's expression, so
+    its bits), ONE upload, Morton order (unless `order` is given), chunk packers and SH bytes on the device.
+    -> (chunks (ceil(n/256), 18) f32, vertices (n, 4) u32, sh (n, m) u8 or None, order u32[n], recursion levels or None)"""
+    require_hip()
+    n = len(data)
+    sh_names = list(sh_names)
+    m = len(sh_names)
+    names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS] + sh_names
+    mat = host_gather_columns(data, names)                         # (14 + m, n), row 9 = opacity
+    with np.errstate(over="ignore"):
+        mat[9] = 1.0 / (1.0 + np.exp(-mat[9]))                     # :200-203 (float32 in, float32 out, as in the reference)
+    nchunks = (n + 255) // 256
+    own = ctx is None
+    ctx = ctx or Context(0)
+    bufs = []
+    try:
+        d_mat = ctx.alloc(max(mat.nbytes, 16)).upload(mat)
+        bufs.append(d_mat)
+        col = lambda i: d_mat.ptr + 4 * n * i
+        levels = None
+        d_order = ctx.alloc(max(4 * n, 16))
+        bufs.append(d_order)
+        if order is None:
+            lv = C.c_int()
+            check(ctx.lib.gsx_morton_order_dev(ctx.handle, col(0), col(1), col(2), 1, n, d_order.ptr, C.byref(lv)), "gsx_morton_order_dev")
+            levels = int(lv.value)
+            order = d_order.download(np.uint32, n) if n else np.zeros(0, np.uint32)
+        else:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            d_order.upload(order)
+        ptrs = (C.c_void_p * 14)(*[col(i) for i in range(14)])
+        d_chunk, d_vert = ctx.alloc(max(72 * nchunks, 16)), ctx.alloc(max(16 * n, 16))
+        bufs += [d_chunk, d_vert]
+        check(ctx.lib.gsx_cply_pack_dev(ctx.handle, ptrs, d_order.ptr, n, d_chunk.ptr, d_vert.ptr), "gsx_cply_pack_dev")
+        chunks = d_chunk.download(np.float32, 18 * nchunks).reshape(nchunks, 18)
+        verts = d_vert.download(np.uint32, 4 * n).reshape(n, 4)
+        sh = None
+        if m:
+            d_out = ctx.alloc(max(n * m, 16))
+            bufs.append(d_out)
+            check(ctx.lib.gsx_cply_sh_dev(ctx.handle, col(14), m, n, d_order.ptr, n, d_out.ptr), "gsx_cply_sh_dev")
+            sh = d_out.download(np.uint8, n * m).reshape(n, m)
+        return chunks, verts, sh, order, levels
     finally:
         for b in bufs:
             b.free()

@@ -60,19 +60,12 @@ def encode(data: np.ndarray, order=None):
     """-> (chunk_data, vertex_data, sh_data or None, order): the three structured arrays the reference hands to
     ``_write_ply_file``.  order: a precomputed splat order (e.g. the reference's own) instead of the Morton sort."""
     n = len(data)
-    ctx = _lib.Context(0)
-    try:
-        if order is None:
-            order, levels = _lib.morton_order(data["x"], data["y"], data["z"], ctx=ctx)
-            debug_print(f"[DEBUG] Morton order: {levels} recursion level(s)")
-        sh_names = active_sh_names(data)
-        with np.errstate(over="ignore"):
-            alpha = 1.0 / (1.0 + np.exp(-data["opacity"]))                                  # :200-203
-        cols = {name: data[name] for name in _lib.CPLY_COLUMNS if name != "alpha"}
-        cols["alpha"] = alpha
-        chunks, verts, sh = _lib.cply_pack(cols, order, [data[name] for name in sh_names], ctx=ctx)
-    finally:
-        ctx.close()
+    sh_names = active_sh_names(data)
+    # round 5: one threaded gather of every column the writer needs, one upload, Morton order + packers + SH bytes on the device
+    # (_lib.cply_pack_table; the per-column path below it -- _lib.morton_order + _lib.cply_pack -- is kept for callers with columns)
+    chunks, verts, sh, order, levels = _lib.cply_pack_table(data, sh_names, order)
+    if levels is not None:
+        debug_print(f"[DEBUG] Morton order: {levels} recursion level(s)")
     chunk_data = np.ascontiguousarray(chunks).view(CHUNK_DTYPE).reshape(-1)
     vertex_data = np.ascontiguousarray(verts).view(VERTEX_DTYPE).reshape(-1)
     sh_data = None

@@ -668,6 +668,90 @@ def main_single(args):
                                                "full 50M reference run took 286 s on 8 cores of the build container (tests/golden/large_cases.json)" % (m, cdt)}
             return r
 
+        def writers_2m():
+            # SURVEY.md 8(f) rows 2-4 with a clock on them: the SOG writer's numeric core (sog.py:264-386, 457-459), the
+            # compressed-PLY writer's Morton order + packers (compressed_ply.py:126-340) and the O(N) row filters
+            # (data_processor.py:184-224), on a synthetic 2M-splat degree-3 table (62 x f4), HOST arrays in, HOST arrays out --
+            # how the writers call them; K-Means, the rest of the SOG writer, is configs.config4
+            m = 2_000_000
+            r = np.random.default_rng(0)
+            names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(45)] + \
+                    ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+            tab = np.zeros(m, dtype=[(nm, "f4") for nm in names])
+            for nm in ("x", "y", "z"):
+                tab[nm] = r.standard_normal(m, dtype=np.float32) * np.float32(3.0)
+            for i in range(3):
+                tab["f_dc_%d" % i] = r.standard_normal(m, dtype=np.float32)
+                tab["scale_%d" % i] = r.standard_normal(m, dtype=np.float32) - np.float32(4.0)
+            for i in range(45):
+                tab["f_rest_%d" % i] = r.standard_normal(m, dtype=np.float32) * np.float32(0.1)
+            tab["opacity"] = r.standard_normal(m, dtype=np.float32) * np.float32(2.0)
+            for i in range(4):
+                tab["rot_%d" % i] = r.standard_normal(m, dtype=np.float32)
+            cply = importlib.import_module("3dgsconverter_amd.formats.compressed_ply_writer")
+
+            def best_of(fn, reps=2):
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    out = fn()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts) * 1e3, out
+
+            rot = np.ascontiguousarray(np.column_stack([tab["rot_%d" % i] for i in range(4)]))
+            xyz2 = np.ascontiguousarray(np.column_stack([tab["x"], tab["y"], tab["z"]]))
+            opa = np.ascontiguousarray(tab["opacity"])
+            t_order, order = best_of(lambda: L.lexsort3(tab["z"], tab["y"], tab["x"]))
+            t_pos, _ = best_of(lambda: [L.sog_positions(tab[a]) for a in "xyz"])
+            t_quat, _ = best_of(lambda: L.sog_quats(rot))
+            t_alpha, _ = best_of(lambda: L.sog_alpha(opa))
+            t_cply, enc = best_of(lambda: cply.encode(tab), reps=2)
+
+            def row_filters():
+                ch = L.DeviceChain(xyz2)
+                try:
+                    a = ch.bbox_keep([-6.0, -6.0, -6.0, 6.0, 6.0, 6.0])
+                    b = ch.ge_keep(opa, float(np.log(0.1 / 0.9)))
+                    return a, b, len(ch.survivors())
+                finally:
+                    ch.close()
+            t_rows, kept = best_of(row_filters)
+            out = {"workload": "%d-splat degree-3 table (62 x f4, synthetic), host arrays in and out: SOG numeric core, compressed-PLY encode, bbox + alpha "
+                               "row filters on the device chain (upload, two masks, two compactions, survivor list back)" % m,
+                   "unit": "ms", "ms": {"sog_lexsort3": round(t_order, 2), "sog_positions_xyz": round(t_pos, 2), "sog_quats": round(t_quat, 2),
+                                        "sog_alpha": round(t_alpha, 2), "compressed_ply_encode": round(t_cply, 2), "row_filters_bbox_alpha": round(t_rows, 2)},
+                   "value": round(m / ((t_order + t_pos + t_quat + t_alpha) * 1e-3) / 1e6, 2), "value_unit": "Msplats/s through the SOG numeric core (sum of its four stages)",
+                   "survivors_after_row_filters": kept[2],
+                   "roofline": {"bound": "pcie", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
+                                "note": "host-to-host calls: every stage uploads its columns and downloads its texels, so each is bound by PCIe "
+                                        "(4-28 B per splat each way at ~56 GB/s) and by numpy's part (extrema, flagged texels), not by HBM"}}
+            if want_cpu:   # cpu_baseline leg: the reference's own numpy expressions (restated in oracle/sog.py, oracle/cply.py) on the same table
+                from oracle import sog as osog, cply as ocply
+                t0 = time.perf_counter()
+                o = osog.order(tab)
+                c_order = (time.perf_counter() - t0) * 1e3
+                t0 = time.perf_counter()
+                osog.positions(tab)
+                c_pos = (time.perf_counter() - t0) * 1e3
+                t0 = time.perf_counter()
+                osog.quats(tab)
+                c_quat = (time.perf_counter() - t0) * 1e3
+                t0 = time.perf_counter()
+                osog.opacity_u8(tab)
+                c_alpha = (time.perf_counter() - t0) * 1e3
+                sub = tab[:200_000]
+                t0 = time.perf_counter()
+                oo, _ = ocply.morton_order(sub["x"], sub["y"], sub["z"])
+                ocply.encode(sub, oo, ["f_rest_%d" % i for i in range(45)])
+                c_cply = (time.perf_counter() - t0) * 1e3
+                out["cpu_baseline"] = {"value": round(m / ((c_order + c_pos + c_quat + c_alpha) * 1e-3) / 1e6, 3), "unit": "Msplats/s", "cores": 1, "kind": "port",
+                                       "ms": {"sog_lexsort3": round(c_order, 1), "sog_positions_xyz": round(c_pos, 1), "sog_quats": round(c_quat, 1),
+                                              "sog_alpha": round(c_alpha, 1), "compressed_ply_encode_200k_splats": round(c_cply, 1)},
+                                       "sample": "the same 2M-splat table, once, numpy single-threaded as the reference runs it; the compressed-PLY "
+                                                 "encode (a Python loop over 256-splat chunks in the reference) on the first 200 000 splats only",
+                                       "order_identical_to_gpu": bool(np.array_equal(o, order))}
+            return out
+
         attempt("config1", config1)
         attempt("config1_brute", config1_brute)
         attempt("config3_one_gpu", config3_one_gpu)
@@ -678,6 +762,7 @@ def main_single(args):
         attempt("floaters_10m", floaters)
         attempt("blobs_10m_k25", blobs_k25)
         attempt("dropin_e2e_10m", dropin_e2e)
+        attempt("writers_2m", writers_2m)
         out["configs"] = configs
         # SURVEY.md 8(d) names two numbers for the metric; both at the top level, unambiguously: `value` (= value_resident) is
         # the whole step with the rows already in HBM -- the harness's definition --, value_host_to_host the call a user of

@@ -132,6 +132,10 @@ int gsx_dev_memset(gsx_ctx *ctx, void *dst_dev, int value, size_t bytes);       
  */
 int gsx_host_gather_f32(const void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets,
                         int ncols, float *out);
+/* the same gather with a COLUMN-major result, out[c*n + r]: one contiguous float32 column per field, as the writers upload them
+ * (formats/compressed_ply.py:200-241 reads `data[name]` per column; formats/sog.py likewise) */
+int gsx_host_gather_columns_f32(const void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets,
+                                int ncols, float *out);
 /*
  * Stable compaction of the rows with mask[r] != 0 -- replaces data_processor.py:114,149
  * (self.data = vertices[mask]).  out must hold out_rows rows; *n_out = number of survivors
