@@ -710,6 +710,9 @@ __global__ __launch_bounds__(256) void big_bucket_scan_kernel(const GridParams *
 #ifndef GSX_NET_WAVES17
 #define GSX_NET_WAVES17 5
 #endif
+#ifndef GSX_BRICK_UNROLL3   // phase 1's word pipeline with rotating names (round 5, A/B)
+#define GSX_BRICK_UNROLL3 0
+#endif
 #ifndef GSX_NET_WAVES33
 #define GSX_NET_WAVES33 4
 #endif
@@ -1145,12 +1148,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                     const int t = min(my_cand, c - 1);  // slots past the end repeat the last candidate (masked out below)
                     return refs[t < w.c1 ? w.b1 + t : w.b2 + (t - w.c1)];
                 };
-                Word w_cur = next_word(0, 0);
-                Word w_n1 = next_word(w_cur.r, w_cur.off);
-                float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
-                while (w_cur.c1 > 0) {
-                    const Word w_n2 = next_word(w_n1.r, w_n1.off);
-                    const float4 p_n2 = fetch(w_n2);
+                auto process = [&](const Word &w_cur, const float4 &p_cur) __attribute__((always_inline)) {
                     const bf16x8 cand = mf_candidate_operand((p_cur.x - ccx) * g_inv_h, (p_cur.y - ccy) * g_inv_h,
                                                              (p_cur.z - ccz) * g_inv_h, upper);
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1169,11 +1167,41 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
                     }
                     nzw |= (m != 0 ? 1u : 0u) << widx;
                     ++widx;
+                };
+#if GSX_BRICK_UNROLL3
+                // the three-deep word pipeline with ROTATING names instead of register moves (the ISA of the rolled loop spends
+                // ~10 of its 105 VALU instructions per word on v_mov rotations of the two prefetched points and words)
+                Word w0 = next_word(0, 0);
+                Word w1 = next_word(w0.r, w0.off), w2;
+                float4 p0 = fetch(w0), p1 = fetch(w1), p2;
+                for (;;) {
+                    if (!(w0.c1 > 0)) break;
+                    w2 = next_word(w1.r, w1.off);
+                    p2 = fetch(w2);
+                    process(w0, p0);
+                    if (!(w1.c1 > 0)) break;
+                    w0 = next_word(w2.r, w2.off);
+                    p0 = fetch(w0);
+                    process(w1, p1);
+                    if (!(w2.c1 > 0)) break;
+                    w1 = next_word(w0.r, w0.off);
+                    p1 = fetch(w1);
+                    process(w2, p2);
+                }
+#else
+                Word w_cur = next_word(0, 0);
+                Word w_n1 = next_word(w_cur.r, w_cur.off);
+                float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
+                while (w_cur.c1 > 0) {
+                    const Word w_n2 = next_word(w_n1.r, w_n1.off);
+                    const float4 p_n2 = fetch(w_n2);
+                    process(w_cur, p_cur);
                     w_cur = w_n1;
                     p_cur = p_n1;
                     w_n1 = w_n2;
                     p_n1 = p_n2;
                 }
+#endif
                 lst.init();
                 }
             }
