@@ -101,6 +101,7 @@ SIGNATURES = {
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_gather_columns_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
+    "gsx_host_take_rows": (_I, [_P, _I64, _I64, _P, _I64, _P]),
     "gsx_host_zero_columns": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I]),
     "gsx_host_append_columns": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64]),
     "gsx_rgb_from_sh": (_I, [_P, _I64, _P, _P]),
@@ -291,6 +292,20 @@ def host_compact_rows(rows: np.ndarray, mask: np.ndarray) -> np.ndarray:
         check(load().gsx_host_compact_rows(src.ctypes.data, src.dtype.itemsize, len(src), m8.ctypes.data, out.ctypes.data,
                                            keep, C.byref(n_out)), "gsx_host_compact_rows")
         assert n_out.value == keep
+    return out
+
+
+def host_take_rows(rows: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """rows[idx] for a strictly ascending uint32 index list (the device chain's survivor list) == rows[mask], threaded
+    (C ABI gsx_host_take_rows): a new array, order kept, no boolean mask in between"""
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    if rows.ndim != 1 or rows.dtype.hasobject:
+        return rows[idx]
+    src = np.ascontiguousarray(rows)
+    out = np.empty(len(idx), dtype=rows.dtype)
+    if len(idx):
+        check(load().gsx_host_take_rows(src.ctypes.data, src.dtype.itemsize, len(src), idx.ctypes.data, len(idx), out.ctypes.data),
+              "gsx_host_take_rows")
     return out
 
 

@@ -147,6 +147,43 @@ extern "C" int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_
     return 0;
 }
 
+// rows[idx] for an ASCENDING list of distinct row indices -- what `vertices[mask]` (data_processor.py:114,149) is once the
+// device chain has handed back its survivor list: no boolean mask has to be built from the list first (numpy's
+// `mask[survivors] = True` on 8M indices cost more than the compaction itself).  Threaded; consecutive indices are copied as
+// one run.
+extern "C" int gsx_host_take_rows(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx, void *out)
+{
+    if (!rows || (!idx && n_idx > 0) || (!out && n_idx > 0)) GSX_FAIL("gsx_host_take_rows: null argument");
+    if (n < 0 || row_bytes <= 0 || n_idx < 0) GSX_FAIL("gsx_host_take_rows: bad shape");
+    if (n_idx == 0) return 0;
+    const int nt = worker_count(2 * n_idx * row_bytes);
+    const char *src = static_cast<const char *>(rows);
+    char *dst = static_cast<char *>(out);
+    {
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + (size_t)n_idx * (size_t)row_bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    std::vector<int> bad(nt, 0);
+    run_threads(nt, [&](int t) {
+        const int64_t i0 = n_idx * t / nt, i1 = n_idx * (t + 1) / nt;
+        int64_t i = i0;
+        while (i < i1) {
+            int64_t e = i + 1;
+            while (e < i1 && idx[e] == idx[e - 1] + 1u) ++e;   // a run of consecutive rows: one memcpy
+            if ((int64_t)idx[e - 1] >= n || (i > 0 && idx[i] <= idx[i - 1])) {
+                bad[t] = 1;
+                return;
+            }
+            memcpy(dst + i * row_bytes, src + (int64_t)idx[i] * row_bytes, (size_t)(e - i) * (size_t)row_bytes);
+            i = e;
+        }
+    });
+    for (int t = 0; t < nt; ++t)
+        if (bad[t]) GSX_FAIL("gsx_host_take_rows: the index list is not strictly ascending inside [0, n)");
+    return 0;
+}
+
 // data_processor.py:310-313 (cap_sh_degree): self.data[f_rest_i] = 0.0 for the columns above the kept degree -- up to 45
 // strided single-thread column fills in numpy; one threaded pass over the rows here.  offsets: byte offsets of the
 // 4-byte columns to zero.

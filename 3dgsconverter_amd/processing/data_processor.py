@@ -108,9 +108,9 @@ class DataProcessor:
             self._chain = None
             try:
                 if ch.n != ch.n0:
-                    mask = np.zeros(ch.n0, dtype=bool)
-                    mask[ch.survivors()] = True
-                    self._data = _lib.host_compact_rows(self._data, mask)
+                    # the chain's survivor list (ascending row indices) applied to the host table directly -- round 5: the
+                    # boolean mask numpy would index with (`mask[survivors] = True` on 8M indices) cost more than the compaction
+                    self._data = _lib.host_take_rows(self._data, ch.survivors())
             finally:
                 ch.close()
         if self._pending_zero:

@@ -143,6 +143,9 @@ int gsx_host_gather_columns_f32(const void *rows, int64_t row_bytes, int64_t n, 
  */
 int gsx_host_compact_rows(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *mask,
                           void *out, int64_t out_rows, int64_t *n_out);
+/* the same compaction from the survivor LIST the device chain returns (strictly ascending row indices): out[i] = rows[idx[i]] --
+ * `self.data = vertices[mask]` (data_processor.py:114,149) without building the boolean mask first.  Threaded. */
+int gsx_host_take_rows(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx, void *out);
 
 /*
  * Device-resident filter chain (device half): stable compaction of (n,3) float32 rows by a device

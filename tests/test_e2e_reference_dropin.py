@@ -198,6 +198,17 @@ def dropin(gsx, monkeypatch):
         verts[:, 3] = (verts[:, 3] & 0xffffff00) | na
         return chunks, verts, sh
 
+    def cply_pack_table(data, sh_names, order=None, ctx=None):
+        # round 5: the writer hands the whole table over (one gather, one upload); the stand-in is the oracle's own encode
+        from oracle import cply as ocply
+        levels = None
+        if order is None:
+            hits.append(("gsx_morton_order_dev", len(data)))
+            order, levels = ocply.morton_order(data["x"], data["y"], data["z"])
+        hits.append(("gsx_cply_pack_dev", len(order), len(sh_names)))
+        chunks, verts, sh = ocply.encode(data, order, list(sh_names))
+        return chunks, verts, sh, order, levels
+
     class FakeCtx:
         def __init__(self, device=0):
             pass
@@ -205,7 +216,7 @@ def dropin(gsx, monkeypatch):
         def close(self):
             pass
 
-    for name, fn in (("morton_order", morton_order), ("cply_pack", cply_pack), ("Context", FakeCtx), ("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
+    for name, fn in (("morton_order", morton_order), ("cply_pack", cply_pack), ("cply_pack_table", cply_pack_table), ("Context", FakeCtx), ("sor_filter", sor_filter), ("density_voxels", density_voxels), ("density_mask", density_mask),
                      ("kmeans_lloyd", kmeans_lloyd), ("kmeans_lloyd_many", kmeans_lloyd_many), ("quantize_sorted_codebook", quantize), ("DeviceChain", FakeChain),
                      ("lexsort3", lexsort3), ("sog_quats", sog_quats),
                      ("sog_positions", sog_positions), ("sog_alpha", sog_alpha), ("kmeans1d", kmeans1d),

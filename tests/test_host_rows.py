@@ -180,3 +180,25 @@ def test_lazy_cap_sh_degree_with_a_pending_compaction_leaves_the_callers_array_a
     proc.data = b
     assert ch.closed and float(a["f_rest_9"].sum()) == 50.0 and float(a["f_rest_44"].sum()) == 50.0
     assert proc.data is b and float(b["f_rest_9"].sum()) == 60.0
+
+
+def test_take_rows_by_the_survivor_list_is_boolean_indexing():
+    """round 5: gsx_host_take_rows (the device chain's ascending survivor list applied to the host table without a boolean
+    mask in between) == rows[mask] byte for byte; empty list, every row, a ragged structured dtype, and a list that is not
+    ascending is refused"""
+    import importlib
+    L = importlib.import_module("3dgsconverter_amd")._lib
+    rng = np.random.default_rng(9)
+    dt = np.dtype([("x", "f4"), ("k", "i8"), ("b", "u1", (3,)), ("y", "f4")])
+    t = np.zeros(123457, dtype=dt)
+    t["x"], t["k"], t["y"] = rng.random(len(t)), np.arange(len(t)), rng.random(len(t))
+    t["b"] = rng.integers(0, 255, (len(t), 3))
+    for frac in (0.0, 0.03, 0.8, 1.0):
+        mask = rng.random(len(t)) < frac
+        idx = np.flatnonzero(mask).astype(np.uint32)
+        got = L.host_take_rows(t, idx)
+        assert got.dtype == t.dtype and got.tobytes() == t[mask].tobytes()
+    with pytest.raises(L.GsxError):
+        L.host_take_rows(t, np.array([7, 7], dtype=np.uint32))
+    with pytest.raises(L.GsxError):
+        L.host_take_rows(t, np.array([1, len(t)], dtype=np.uint32))
