@@ -278,6 +278,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->adaptive = (int)value;
     } else if (!strcmp(name, "tree")) {
         c->tree = (int)value;
+    } else if (!strcmp(name, "tree_leaf_cap")) {
+        c->tree_leaf_cap = (int)value;
     } else if (!strcmp(name, "tree_near_cell")) {
         c->tree_near_cell = value > 0.05 ? value : 0.5;
     } else if (!strcmp(name, "tree_scale")) {

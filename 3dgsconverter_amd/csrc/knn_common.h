@@ -134,14 +134,18 @@ __device__ __forceinline__ void oe_sort(double *v)
     }
 }
 
+#ifndef GSX_CAP4   // list capacities 12, 20, 28, 36, 44, 52 in knn_brick and knn_leaf besides the multiples of 8 (round 5; 0 for A/B runs)
+#define GSX_CAP4 1
+#endif
 template <int L>
 struct TopNet {
-    static_assert(L % 8 == 0 && L >= 8 && L <= 64, "list length: a multiple of 8");
+    static_assert(L % 4 == 0 && L >= 8 && L <= 64, "list length: a multiple of 4");
     // Lengths that are not a power of two (24, 40, 48, 56: round 4 -- the reference's CLI asks for k = 18 ... 50, and a 64-entry list
     // for k = 36 is 2.2x the time of a 32-entry one) merge through the next power of two P with P - L entries of -inf
     // imagined IN FRONT of the list: [-inf ..., sorted head, bitonic tail] is still bitonic, and a compare-exchange whose
     // lower partner is -inf does nothing, so it is not emitted: 52 CE at L = 24 (80 at 32), 128 at L = 48 (192 at 64).
-    // Checked with the 0-1 principle for every multiple of 8 up to 64 (tests/test_ring_fast_logic.py::test_padded_bitonic_merge).
+    // Checked with the 0-1 principle for every multiple of 4 up to 64 (tests/test_ring_fast_logic.py::test_padded_bitonic_merge);
+    // round 5 instantiates 12, 20, 28 (64 CE: the reference's default k = 25 and --sor_intensity 5, k = 27), 36, 44 and 52 as well.
     static constexpr int P = L <= 8 ? 8 : (L <= 16 ? 16 : (L <= 32 ? 32 : 64)), OFF = P - L;
     // candidates per block.  8, not 16 (round 3): the same ~13 network ops per candidate, half the padding in a lane's
     // last block, 16 fewer live VGPRs -> two more waves per SIMD; 4 costs more network ops than it saves

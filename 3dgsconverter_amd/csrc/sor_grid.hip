@@ -2354,12 +2354,20 @@ static int dispatch_bricks(gsx_ctx *ctx, const BrickLaunch &a, bool mf, bool net
     const int kk = a.k + 1;
     if (net) {
 #define GSX_BRICKS(K) (mf ? launch_bricks<K, true, true>(ctx, a) : launch_bricks<K, false, true>(ctx, a))
+        // (round 5: the multiples of 4 in between as well -- --sor_intensity 1 ... 10 asks for k = 10, 14, 18, 23, 27, 32, 36, 41, 45, 50
+        //  and the default is 25: -5 % of the step at k = 25 with 28 entries instead of 32, profiles/r05_variants.txt)
         if (kk <= 9) return GSX_BRICKS(9);
+        if (GSX_CAP4 && kk <= 13) return GSX_BRICKS(13);
         if (kk <= 17) return GSX_BRICKS(17);
+        if (GSX_CAP4 && kk <= 21) return GSX_BRICKS(21);
         if (kk <= 25) return GSX_BRICKS(25);   // 24 and 48 entries: the reference CLI's k = 18 ... 24 and 33 ... 48
+        if (GSX_CAP4 && kk <= 29) return GSX_BRICKS(29);
         if (kk <= 33) return GSX_BRICKS(33);
+        if (GSX_CAP4 && kk <= 37) return GSX_BRICKS(37);
         if (kk <= 41) return GSX_BRICKS(41);   // (40 and 56 entries: -10 % at k = 36, -13 % at 40, -8 % at 56 against the next capacity)
+        if (GSX_CAP4 && kk <= 45) return GSX_BRICKS(45);
         if (kk <= 49) return GSX_BRICKS(49);
+        if (GSX_CAP4 && kk <= 53) return GSX_BRICKS(53);
         if (kk <= 57) return GSX_BRICKS(57);
         return GSX_BRICKS(65);
 #undef GSX_BRICKS

@@ -50,7 +50,8 @@
 namespace gsx {
 
 constexpr int TB = 21;                 // key bits per axis
-constexpr int LEAF_CAP = 64;           // points per leaf = lanes of a wave
+constexpr int LEAF_CAP = 64;           // points per leaf for k <= 16 = lanes of a wave; more for larger k (tree_leaf_cap_for)
+constexpr int LEAF_CAP_MAX = 256;
 constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 #ifndef GSX_TWCAP
 #define GSX_TWCAP 28
@@ -70,7 +71,7 @@ constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 static_assert(GSX_TWCAP <= 32, "the non-empty-word mask of a batch is one 32-bit register");
 constexpr int TWCAP = GSX_TWCAP;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
 constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag kernels
-constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points hands its queries to knn_tree_query
+constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points (x leaf capacity / 64) hands its queries to knn_tree_query
 constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small array (2.5 MB at 10M points: cache resident) that the
                                        // range look-ups search first; only the last 5 steps touch the 80 MB key array
 constexpr int TQ_STACK = 256;          // pending nodes of a descent (best-first: the frontier of the ball, typically a few dozen)
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void tree_probe_gather_kernel(const float *__r
 constexpr float PROBE_BIAS_T = 0.065f;
 __host__ __device__ constexpr float probe_target_t(int k) { return k <= 16 ? 0.12f : (k <= 32 ? 0.805f : 0.59f); }
 
-__device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int lane, const unsigned *hist, int k)   // one whole wave
+__device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int lane, const unsigned *hist, int k)   // one whole wave; k: per 64 points of leaf capacity
 {
     const int l = lane & (PROBE_BINS - 1);
     const float h_mine = (float)hist[l];
@@ -309,7 +310,7 @@ __device__ __forceinline__ void tree_pick_scale(TreeParams *__restrict__ tp, int
 // of its 64 candidates per sample, the wave pops the 8 nearest of those.  The last wave to finish turns the histogram into
 // the scale.  (One sample per wave straight from L2 was a chain of 64 dependent loads: 90 us.)
 constexpr int PROBE_PER_WAVE = 2;   // samples a wave takes at once (1: 37 us, 2: 28 us, 4: 31 us per launch)
-__global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restrict__ smp, int n, int k, TreeParams *__restrict__ tp,
+__global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restrict__ smp, int n, int k, float lg_cap, TreeParams *__restrict__ tp,
                                                          unsigned char *__restrict__ bins /* [PROBE_S]: histogram bin of every sample, 0xff = none */)
 {
     __shared__ unsigned s_hist[PROBE_BINS];
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void tree_probe_kernel(const float4 *__restric
             if (!bad && r2 > 0.0f && r2 < inf) {   // (duplicates: no finite density)
                 // rho = (m - 1) / (4/3 pi r^3) * n / S   (E[1/V_m] = rho / (m - 1));   the cube of edge s * 2^u holds 64 points:
                 // u = log2(cbrt(64 / rho) / s) = (6 - log2 rho) / 3 - log2 s      (f32 logarithms: +-1e-6 octave)
-                const float u = (6.0f - lg_c + 1.5f * __log2f(r2)) * (1.0f / 3.0f) - lg_s;
+                const float u = (lg_cap - lg_c + 1.5f * __log2f(r2)) * (1.0f / 3.0f) - lg_s;   // (lg_cap = 6: 64 points; a leaf holds 2^lg_cap)
                 if (u > -64.0f && u < 64.0f) bin = (unsigned char)min(PROBE_BINS - 1, (int)((u - floorf(u)) * PROBE_BINS));
             }
             // (a byte per sample, counted by the last workgroup: 4096 atomics on one cache line took 45 us -- the chip
@@ -449,32 +450,45 @@ __global__ __launch_bounds__(256) void tree_samples_kernel(const unsigned long l
 }
 
 // ---------------------------------------------------------------- leaves
-// flags[i] = bit level of the leaf of sorted point i | 0x80 if i is the leaf's first point; tilecnt[t] = leaves starting in tile t
-__global__ __launch_bounds__(256) void tree_leaf_flags_kernel(const unsigned long long *__restrict__ keys, int n,
+// flags[i] = bit level of the leaf of sorted point i | 0x80 if i is the leaf's first point; tilecnt[t] = leaves starting in tile t.
+// cap = points a leaf may hold (64 ... LEAF_CAP_MAX).  The window minimum over cap + 1 entries is taken in two steps: the minima
+// of all 64-entry windows by six doubling passes through LDS, then ceil((cap + 1) / 64) of those (overlapping where cap + 1 is
+// no multiple of 64) -- the plain loop was 65 LDS reads per point at cap = 64 and would be 257 at 256.
+__global__ __launch_bounds__(256) void tree_leaf_flags_kernel(const unsigned long long *__restrict__ keys, int n, int cap,
                                                               unsigned char *__restrict__ flags, unsigned *__restrict__ tilecnt)
 {
-    __shared__ unsigned char a[LEAF_TILE + LEAF_CAP];   // a[t] belongs to sorted index t0 - LEAF_CAP + t
+    constexpr int SPAN = LEAF_TILE + LEAF_CAP_MAX + 64;
+    __shared__ unsigned char buf[2][SPAN + 64];   // [t] belongs to sorted index t0 - cap + t
     __shared__ unsigned wsum[4];
     const int t0 = blockIdx.x * LEAF_TILE;
-    for (int t = threadIdx.x; t < LEAF_TILE + LEAF_CAP; t += 256) {
-        const long long j = (long long)t0 - LEAF_CAP + t;
-        int v = 64;   // no window of LEAF_CAP + 1 points starts here
-        if (j >= 0 && j + LEAF_CAP < n) {
-            const unsigned long long d = keys[j] ^ keys[j + LEAF_CAP];
-            v = d ? 64 - __builtin_clzll(d) : 0;   // smallest bit level at which j and j + LEAF_CAP share a node
+    const int span = LEAF_TILE + cap;   // entries that exist; the rest of the buffers reads as "no window"
+    for (int t = threadIdx.x; t < SPAN + 64; t += 256) {
+        const long long j = (long long)t0 - cap + t;
+        int v = 64;   // no window of cap + 1 points starts here
+        if (t < span && j >= 0 && j + cap < n) {
+            const unsigned long long d = keys[j] ^ keys[j + cap];
+            v = d ? 64 - __builtin_clzll(d) : 0;   // smallest bit level at which j and j + cap share a node
         }
-        a[t] = (unsigned char)v;
+        buf[0][t] = buf[1][t] = (unsigned char)v;
     }
     __syncthreads();
+    int cur = 0;
+#pragma unroll
+    for (int st = 1; st < 64; st *= 2) {   // buf[cur][t] = min of the 2*st entries from t on
+        for (int t = threadIdx.x; t < SPAN; t += 256) buf[cur ^ 1][t] = min(buf[cur][t], buf[cur][min(t + st, SPAN + 63)]);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const unsigned char *w64 = buf[cur];   // minimum over [t, t + 64)
     unsigned heads = 0;
 #pragma unroll
     for (int u = 0; u < LEAF_TILE / 256; ++u) {
         const int t = threadIdx.x + 256 * u;
         const int i = t0 + t;
         if (i < n) {
-            int split = 64;   // smallest bit level at which the node of i holds more than LEAF_CAP points
-            for (int d = 0; d <= LEAF_CAP; ++d) split = min(split, (int)a[t + d]);
-            const int bl = max(split - 1, 0);   // split == 0: more than LEAF_CAP points in one fine cell -- an over-full leaf
+            int split = (int)w64[t + cap + 1 - 64];   // smallest bit level at which the node of i holds more than cap points
+            for (int d = 0; d + 64 <= cap; d += 64) split = min(split, (int)w64[t + d]);
+            const int bl = max(split - 1, 0);   // split == 0: more than cap points in one fine cell -- an over-full leaf
             const bool head = i == 0 || (keys[i] >> bl) != (keys[i - 1] >> bl);
             flags[i] = (unsigned char)(bl | (head ? 0x80 : 0));
             heads += head ? 1u : 0u;
@@ -593,12 +607,12 @@ __device__ __forceinline__ double uniform_f64(double v)
 __device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 
 // points of the fullest over-full leaf (a leaf of more than 64 points is ONE fine cell): the host entry of adaptive mode reads it
-__global__ __launch_bounds__(256) void tree_leaf_max_kernel(TreeParams *__restrict__ tp, const unsigned *__restrict__ leafstart)
+__global__ __launch_bounds__(256) void tree_leaf_max_kernel(TreeParams *__restrict__ tp, const unsigned *__restrict__ leafstart, int cap)
 {
     const int nl = (int)tp->nleaves;
     unsigned mx = 0;
     for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < nl; l += gridDim.x * blockDim.x) mx = max(mx, leafstart[l + 1] - leafstart[l]);
-    if (mx > (unsigned)LEAF_CAP) atomicMax(&tp->max_leaf, mx);
+    if (mx > (unsigned)cap) atomicMax(&tp->max_leaf, mx);
 }
 
 // ---------------------------------------------------------------- knn_leaf
@@ -622,7 +636,7 @@ constexpr int leaf_min_waves(int kcap)
 template <int KCAP>
 __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_kernel(
     TreeParams *__restrict__ tp, const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ samples,
-    const float4 *__restrict__ refs, const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k,
+    const float4 *__restrict__ refs, const unsigned *__restrict__ leafstart, const unsigned char *__restrict__ leafbl, int k, int cand_limit,
     int q_begin, int q_count, float rf_scale, float *__restrict__ mean_out, double *__restrict__ kth_out, unsigned *__restrict__ faillist,
     double *__restrict__ failbound, int share, int nshares)
 {
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
             }
             wave_sync();
         }
-        const bool irregular = ncand > TREE_CAND_LIMIT;
+        const bool irregular = ncand > cand_limit;
 
         for (int qb = 0; qb < nq; qb += 64) {
             const int f = qb + lane;
@@ -888,12 +902,14 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 o.off = off;
                 return o;
             };
-            // The matrix-core filter is run on the assumption that the words of the box fit the park (28 words = 896 candidates:
-            // nearly always).  If they do not, its masks are dropped and the box is filtered again the slow way -- counting the
-            // words first cost 0.85 ms at 10M points (scalar loop over the ranges), the occasional wasted filter costs nothing.
-            bool parked = ncand <= TWCAP * 32;
-            if (parked) {
-                // ---- phase 1, matrix cores: cell-unit coordinates relative to the leaf centre (|u| <= 2); see knn_mfma.h
+            // ---- phase 1, matrix cores: cell-unit coordinates relative to the leaf centre (|u| <= 2); see knn_mfma.h.  One pass
+            // fills the park (28 words = 896 candidates) from position (cr, coff) of the flat sequence on and says whether words
+            // are left.  Nearly every 64-point leaf is ONE pass, and that pass runs with the list not yet alive (its registers
+            // are the filter's); the larger leaves of k > 16 (tree_leaf_cap_for) and the boxes of odd shapes take further passes
+            // -- drain, tighten the bound by the list's k-th distance, filter the next 896 candidates with the list alive.
+            // (Round 4 filtered such boxes from scratch on the float32 VALU, scalar loads: 3x the time per candidate.)
+            int cr = 0, coff = 0;
+            auto mfma_fill = [&]() __attribute__((always_inline)) {
                 const float ccx = uniform_f32(rec->ccx), ccy = uniform_f32(rec->ccy), ccz = uniform_f32(rec->ccz);
                 const float g_inv_h = uniform_f32(rec->inv_h);
                 const float uqx = (qx - ccx) * g_inv_h, uqy = (qy - ccy) * g_inv_h, uqz = (qz - ccz) * g_inv_h;
@@ -910,7 +926,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                     const int base = t < w.e[0] ? w.b[0] : (t < w.e[1] ? w.b[1] : (t < w.e[2] ? w.b[2] : w.b[3]));
                     return refs[base + t];
                 };
-                Word w_cur = next_word(0, 0);
+                Word w_cur = next_word(cr, coff);
                 Word w_n1 = next_word(w_cur.r, w_cur.off);
                 float4 p_cur = fetch(w_cur), p_n1 = fetch(w_n1);
                 while (w_cur.e[3] > 0 && widx < TWCAP && !(GSX_TREE_ABL & 2)) {
@@ -933,48 +949,23 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                     }
                     nzw |= (m != 0 ? 1u : 0u) << widx;
                     ++widx;
+                    cr = w_cur.r;      // the sequence continues behind the word just parked
+                    coff = w_cur.off;
                     w_cur = w_n1;
                     p_cur = p_n1;
                     w_n1 = w_n2;
                     p_n1 = p_n2;
                 }
-                if (w_cur.e[3] > 0 && !(GSX_TREE_ABL & 2)) {   // wave-uniform: words left over
-                    parked = false;
-                    widx = 0;
-                    nzw = 0;
-                }
                 wave_sync();
-            }
+                return w_cur.e[3] > 0 && !(GSX_TREE_ABL & 2);   // wave-uniform: words left over
+            };
+            bool more = mfma_fill();
             lst.init();
-            if (!parked) {
-                // ---- phase 1, float32 VALU on scalar loads: a box with more words than the park holds is filtered range by
-                // range and drained whenever the park is full (the list then lives across the filter loop)
-                for (int r = 0; r < nr; ++r) {
-                    const int gs = __builtin_amdgcn_readlane(rs_start, r & 63);
-                    const int len = __builtin_amdgcn_readlane(rs_len, r & 63);
-                    for (int w0 = 0; w0 < len; w0 += 32) {
-                        if (widx == TWCAP) drain();
-                        const int c = min(32, len - w0);
-                        const float4 *__restrict__ p = refs + gs + w0;
-                        const float neg_tau = -tau;
-                        unsigned m = 0;
-                        for (int i = 0; i < c; ++i) {
-                            const float4 P = p[i];   // wave-uniform address
-                            m = shift_in_lt(m, qx, qy, qz, P.x, P.y, P.z, neg_tau);
-                        }
-                        m <<= (32 - c);
-                        mask[widx][lane] = m;
-                        if (lane == 0) {
-                            wb0[widx] = (unsigned)(gs + w0);
-                            wb1[widx] = wb2[widx] = wb3[widx] = (unsigned)(gs + w0);
-                            wcut[widx] = 0x202020u;
-                        }
-                        nzw |= (m != 0 ? 1u : 0u) << widx;
-                        ++widx;
-                    }
-                }
+            for (;;) {
+                drain();
+                if (!uniform((int)more)) break;
+                more = mfma_fill();
             }
-            drain();
 
             {
                 const double kth_d2 = lst.kth(k);
@@ -1572,8 +1563,18 @@ static int tree_blocks(const gsx_ctx *ctx, int64_t n, int per_thread)
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * 16));
 }
 
+// Points a leaf may hold.  knn_leaf certifies a query whose k-th neighbour is nearer than the faces of the leaf's box grown by
+// half its longest side, so a leaf must be large against the ball of k points: with 64-point leaves 1 % of the queries of the
+// six-blob cloud go to the per-query kernels at k = 16, 5 % at k = 25, 15 % at 36, 29 % at 50 (4-5 ns each against ~0.5 ns in
+// knn_leaf: 15 of 25 ms at k = 50).  A leaf of more than 64 points is taken in batches of 64 queries against the same candidate
+// set, whose size grows with the leaf -- knn_leaf's time grows by a third from 64 to 96 points.  Measured at 10M points, ms per
+// step, capacity 64 / 96 / 128 / 192 (profiles/r05_variants.txt): blobs k = 25: 8.10 / 8.16 / 8.47 / 9.92, k = 36: 13.30 /
+// 11.00 / 10.51 / 12.39, k = 50: 24.60 / 19.40 / 16.56 / 16.93; scene + floaters (one density, the probe picks the shape):
+// k = 25: 6.05 / 6.68 / 6.98, k = 36: 8.76 / 9.01 / 8.93, k = 50: 12.28 / 13.11 / 12.39.
+static int tree_leaf_cap_for(int k) { return k <= 28 ? LEAF_CAP : (k <= 34 ? 96 : 128); }
+
 template <int KCAP>
-static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_t q_count, float *mean_out, double *kth_out, int share,
+static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int leaf_cap, int64_t q_begin, int64_t q_count, float *mean_out, double *kth_out, int share,
                          int nshares)
 {
     static int occ = 0;
@@ -1584,7 +1585,7 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int64_t q_begin, int64_
     static const float rf_scale = getenv("GSX_TREE_RF") ? (float)atof(getenv("GSX_TREE_RF")) : 1.1f;   // (tuning: DESIGN.md 5.8)
     hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
                        w.keys[1].as<unsigned long long>(), w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
-                       w.leafbl.as<unsigned char>(), k, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
+                       w.leafbl.as<unsigned char>(), k, TREE_CAND_LIMIT / LEAF_CAP * leaf_cap, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
                        w.faillist.as<unsigned>(), w.failbound.as<double>(), share, nshares);
     GSX_HIP(hipGetLastError());
     return 0;
@@ -1599,6 +1600,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     if (n_ref <= k) GSX_FAIL("sor (tree): k=%d needs more than %lld points", k, (long long)n_ref);
     TreeWs &w = ctx->tree_ws;
     ctx->last_knn_algo = GSX_KNN_TREE;
+    const int leaf_cap = ctx->tree_leaf_cap > 0 ? std::min(std::max(ctx->tree_leaf_cap, LEAF_CAP), LEAF_CAP_MAX) : tree_leaf_cap_for(k);
     const size_t n = (size_t)n_ref;
     const int ntiles = div_up(n_ref, LEAF_TILE);
     const int bbox_blocks = std::min(tree_blocks(ctx, n_ref, 8), ctx->num_cu * 4);
@@ -1636,7 +1638,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
     if (ctx->tree_scale == 0.0 && n_ref >= PROBE_MIN_N) {   // the shape of the leaves: see "density probe" above
         float4 *smp = w.keys[1].as<float4>();              // (free until the sort)
         hipLaunchKernelGGL(tree_probe_gather_kernel, dim3(PROBE_S / 256), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, smp);
-        hipLaunchKernelGGL(tree_probe_kernel, dim3(PROBE_S / (4 * PROBE_PER_WAVE)), dim3(256), 0, ctx->stream, smp, (int)n_ref, k, tp,
+        hipLaunchKernelGGL(tree_probe_kernel, dim3(PROBE_S / (4 * PROBE_PER_WAVE)), dim3(256), 0, ctx->stream, smp, (int)n_ref,
+                           std::max(1, k * LEAF_CAP / leaf_cap), log2f((float)leaf_cap), tp,
                            reinterpret_cast<unsigned char *>(smp + PROBE_S));
     }
     hipLaunchKernelGGL(tree_keys_kernel, dim3(tree_blocks(ctx, n_ref, 4)), dim3(256), 0, ctx->stream, x, y, z, stride, (int)n_ref, tp,
@@ -1647,8 +1650,8 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
                        v1, w.refs.as<float4>(), w.blockboxes.as<float4>(), (int)std::min<int64_t>(ref_only_from, INT32_MAX));
     hipLaunchKernelGGL(tree_samples_kernel, dim3(tree_blocks(ctx, n_ref / KEY_BLOCK + 1, 1)), dim3(256), 0, ctx->stream, k1, (int)n_ref,
                        w.samples.as<unsigned long long>());
-    hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, w.flags.as<unsigned char>(),
-                       tilecnt);
+    hipLaunchKernelGGL(tree_leaf_flags_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, k1, (int)n_ref, leaf_cap,
+                       w.flags.as<unsigned char>(), tilecnt);
     GSX_HIP(hipGetLastError());
     GSX_HIP(rocprim::exclusive_scan(w.temp.p, t_scan, tilecnt, tileoff, 0u, (size_t)ntiles, rocprim::plus<unsigned>(), ctx->stream));
     hipLaunchKernelGGL(tree_leaf_compact_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, w.flags.as<unsigned char>(), (int)n_ref,
@@ -1658,7 +1661,7 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
         // adaptive mode (the caller synchronises anyway): a cloud with tens of thousands of points inside ONE fine cell -- two
         // scales more than 2^21 apart -- would be searched quadratically there; the caller's grid refinement re-scales instead
         hipLaunchKernelGGL(tree_leaf_max_kernel, dim3(tree_blocks(ctx, n_ref / 32 + 1, 1)), dim3(256), 0, ctx->stream, tp,
-                           w.leafstart.as<unsigned>());
+                           w.leafstart.as<unsigned>(), leaf_cap);
         unsigned max_leaf = 0;
         GSX_HIP(hipMemcpyAsync(&max_leaf, &tp->max_leaf, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         GSX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1672,14 +1675,16 @@ int launch_knn_tree(gsx_ctx *ctx, const float *x, const float *y, const float *z
 
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_KNN));
     const int kk = k + 1;
-    if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 17) GSX_CHECK(launch_leaves<17>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 25) GSX_CHECK(launch_leaves<25>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 33) GSX_CHECK(launch_leaves<33>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 41) GSX_CHECK(launch_leaves<41>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 49) GSX_CHECK(launch_leaves<49>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else if (kk <= 57) GSX_CHECK(launch_leaves<57>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
-    else GSX_CHECK(launch_leaves<65>(ctx, w, k, q_begin, q_count, mean_out, kth_out, share, nshares));
+    if (kk <= 9) GSX_CHECK(launch_leaves<9>(ctx, w, k, leaf_cap, q_begin, q_count, mean_out, kth_out, share, nshares));
+#define GSX_LEAVES(K) else if (kk <= K) GSX_CHECK(launch_leaves<K>(ctx, w, k, leaf_cap, q_begin, q_count, mean_out, kth_out, share, nshares));
+#if GSX_CAP4   // (list capacities 12, 20, 28, ...: round 5, see dispatch_bricks)
+    GSX_LEAVES(13) GSX_LEAVES(17) GSX_LEAVES(21) GSX_LEAVES(25) GSX_LEAVES(29) GSX_LEAVES(33) GSX_LEAVES(37) GSX_LEAVES(41) GSX_LEAVES(45)
+    GSX_LEAVES(49) GSX_LEAVES(53) GSX_LEAVES(57)
+#else
+    GSX_LEAVES(17) GSX_LEAVES(25) GSX_LEAVES(33) GSX_LEAVES(41) GSX_LEAVES(49) GSX_LEAVES(57)
+#endif
+#undef GSX_LEAVES
+    else GSX_CHECK(launch_leaves<65>(ctx, w, k, leaf_cap, q_begin, q_count, mean_out, kth_out, share, nshares));
     GSX_CHECK(timing_end(ctx, GSX_T_SOR_KNN));
     GSX_CHECK(timing_begin(ctx, GSX_T_SOR_FALLBACK));
     hipLaunchKernelGGL(knn_tree_near_kernel, dim3(ctx->num_cu * 6), dim3(TREE_THREADS), 0, ctx->stream, tp, k1,
