@@ -280,6 +280,8 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->tree = (int)value;
     } else if (!strcmp(name, "tree_leaf_cap")) {
         c->tree_leaf_cap = (int)value;
+    } else if (!strcmp(name, "tree_cand_limit")) {
+        c->tree_cand_limit = (int)value;
     } else if (!strcmp(name, "tree_near_cell")) {
         c->tree_near_cell = value > 0.05 ? value : 0.5;
     } else if (!strcmp(name, "tree_scale")) {

@@ -167,6 +167,7 @@ struct gsx_ctx {
     int tree = 1;        // adaptive mode: 1 = the Morton-tree path (sor_tree.hip, no host round trips), 0 = level-by-level grid refinement
     int kmeans_mfma = 1;  // K-Means assign for D in {9,24,45}, K >= 64: 1 = matrix-core filter + exact certificate, 0 = packed-f32 VALU scan
     int tree_leaf_cap = 0;         // points per leaf of the Morton-tree path: 0 = by k (sor_tree.hip: tree_leaf_cap_for), else 64 ... 256 (A/B)
+    int tree_cand_limit = 0;       // candidates per 64 points of leaf capacity above which a leaf's queries go to the per-query kernels (0 = 4096; A/B)
     double tree_near_cell = 0.5;   // knn_tree_near: edge of the cover's cells as a fraction of the ball's radius (A/B)
     double tree_scale = 0.0;   // > 0: the Morton tree's fine cell edge is (extent / 2^21) x this (A/B of the leaf-shape rule); 0 = chosen by the density probe
     int km_exact_blocks = 4;   // workgroups per CU of kmeans_assign_exact_list (one uncertified point per workgroup and round: A/B)

@@ -71,7 +71,8 @@ constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 static_assert(GSX_TWCAP <= 32, "the non-empty-word mask of a batch is one 32-bit register");
 constexpr int TWCAP = GSX_TWCAP;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
 constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag kernels
-constexpr int TREE_CAND_LIMIT = 2048;   // a leaf whose searched box holds more points (x leaf capacity / 64) hands its queries to knn_tree_query
+constexpr int TREE_CAND_LIMIT = 4096;   // a leaf whose searched box holds more points (x leaf capacity / 64) hands its queries to knn_tree_near
+                                        // (2048 until the filter ran in passes: blobs 10M k = 25 8.08 -> 7.85 ms, k = 50 16.5 -> 16.0; 8192: no better)
 constexpr int KEY_BLOCK = 32;          // one key in 32 is copied to a small array (2.5 MB at 10M points: cache resident) that the
                                        // range look-ups search first; only the last 5 steps touch the 80 MB key array
 constexpr int TQ_STACK = 256;          // pending nodes of a descent (best-first: the frontier of the ball, typically a few dozen)
@@ -80,6 +81,11 @@ constexpr unsigned TREE_OVERFULL_LIMIT = 32768;   // points in one fine cell abo
                                                    // search is quadratic in that number: the key resolution, extent / 2^21, is exhausted)
 constexpr int TQ_DENSE = 4096;         // points of one cover cell knn_tree_near takes itself, block boxes first (more: the pruned descent;
                                        // 2^18 measured: 5x slower on blobs -- the ball fills the buffer and the query is handed on anyway)
+#ifndef GSX_TQ_FLIGHT
+#define GSX_TQ_FLIGHT 4
+#endif
+constexpr int TQ_FLIGHT = GSX_TQ_FLIGHT;   // 64-point blocks a descent has in flight while it scans a node (8 and 16 measured in round 5: no change --
+                                           // the launch lasts as long as its slowest query, and that query's time is its ~70 splits, not its scans)
 constexpr int TQ_CAND = 256;           // candidates inside the search ball a wave collects before it ranks them
 
 struct TreeParams {
@@ -1394,12 +1400,12 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                             need = !(m2b > T0) && (!insert_mode || m2b < kv);
                         }
                         unsigned long long todo = __ballot(need);
-                        // ---- scan: up to 4 blocks of 64 points in flight; the nearest candidate below the running k-th distance first
+                        // ---- scan: up to TQ_FLIGHT blocks of 64 points in flight; the nearest candidate below the running k-th distance first
                         while (todo) {
-                            float4 p4[4];
-                            unsigned base4[4];
+                            float4 p4[TQ_FLIGHT];
+                            unsigned base4[TQ_FLIGHT];
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
+                            for (int v = 0; v < TQ_FLIGHT; ++v) {
                                 base4[v] = 0xffffffffu;
                                 if (todo) {
                                     base4[v] = (bb + (unsigned)__builtin_ctzll(todo)) << 6;
@@ -1409,7 +1415,7 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                                 p4[v] = refs[(base4[v] != 0xffffffffu && j >= nlo && j < nhi) ? j : nlo];
                             }
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
+                            for (int v = 0; v < TQ_FLIGHT; ++v) {
                                 if (base4[v] == 0xffffffffu) break;   // wave-uniform
                                 const unsigned j = base4[v] + (unsigned)lane;
                                 const float4 p = p4[v];
@@ -1531,7 +1537,7 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                     wave_sync();
                     break;
                 }
-                R *= 2.0;   // fewer than k points inside the ball (a whole-cloud pass always has them: n > k)
+                R *= M == 0 ? 8.0 : (4 * M < k ? 4.0 : 2.0);   // fewer than k points inside the ball (a whole-cloud pass always has them: n > k); see below
                 continue;
             }
             // INSERT mode: certified iff k neighbours were found inside the radius the pass covered
@@ -1551,7 +1557,14 @@ __global__ __launch_bounds__(TREE_THREADS, 3) void knn_tree_query_kernel(
                 wave_sync();
                 break;
             }
-            R *= 2.0;
+            // Fewer than k points inside the ball: the next one is wider by what the count says.  (Plain doubling took a flyer
+            // whose leaf holds nothing else -- a radius to try of half a fine cell -- through 17 passes, 2^-10 to 2^6: 0.3-0.7 ms
+            // for ONE query, the duration of the whole launch.  A ball that is too wide costs little here: the descent is
+            // nearest-first and pruned by the running k-th distance, the radius only certifies.)
+            {
+                const int found = (int)__popcll(__ballot(best < 1e300));
+                R *= found == 0 ? 8.0 : (4 * found < k ? 4.0 : 2.0);
+            }
         }
     }
 }
@@ -1585,7 +1598,7 @@ static int launch_leaves(gsx_ctx *ctx, TreeWs &w, int k, int leaf_cap, int64_t q
     static const float rf_scale = getenv("GSX_TREE_RF") ? (float)atof(getenv("GSX_TREE_RF")) : 1.1f;   // (tuning: DESIGN.md 5.8)
     hipLaunchKernelGGL((knn_leaf_kernel<KCAP>), dim3(ctx->num_cu * occ), dim3(TREE_THREADS), 0, ctx->stream, w.params.as<TreeParams>(),
                        w.keys[1].as<unsigned long long>(), w.samples.as<unsigned long long>(), w.refs.as<float4>(), w.leafstart.as<unsigned>(),
-                       w.leafbl.as<unsigned char>(), k, TREE_CAND_LIMIT / LEAF_CAP * leaf_cap, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
+                       w.leafbl.as<unsigned char>(), k, (ctx->tree_cand_limit > 0 ? ctx->tree_cand_limit : TREE_CAND_LIMIT) / LEAF_CAP * leaf_cap, (int)q_begin, (int)q_count, rf_scale, mean_out, kth_out,
                        w.faillist.as<unsigned>(), w.failbound.as<double>(), share, nshares);
     GSX_HIP(hipGetLastError());
     return 0;
