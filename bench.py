@@ -605,7 +605,7 @@ def main_single(args):
             r["workload"] = ("%d splats in six Gaussian blobs (sigma 0.05...1.5) + 2 %% far flyers, SOR k=25 sigma=10.5 (the reference CLI's "
                              "defaults), adaptive mode (Morton-tree path, csrc/sor_tree.hip)" % args.n)
             r["roofline"] = sor_roofline(args.n, 25, r["knn_kernel_ms"], single=False)
-            r["roofline"]["kernel"] = "knn_leaf_kernel<25> + the rim kernels (knn_tree_near, knn_tree_query) in the same interval"
+            r["roofline"]["kernel"] = "knn_leaf_kernel<29> + the rim kernels (knn_tree_near, knn_tree_query) in the same interval"
             r["roofline"]["algorithmic_bytes_per_splat"] = 8 * 16 + 16 + 4
             r["roofline"]["note"] = "knn_leaf (one wave per Morton leaf), priced like knn_brick; " + r["roofline"]["note"]
             return r
