@@ -757,7 +757,7 @@ def main_single(args):
         attempt("config3_one_gpu", config3_one_gpu)
         attempt("host_to_host", lambda: run_host_to_host(L, ctx, xyz, args.k, args.sigma, head["ms_per_step"]))
         attempt("config2", lambda: run_chain(L, ctx, gsx, xyz, 0.5, args.k, args.sigma, small, 2, cpu=want_cpu))
-        attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 3, 1, cpu=want_cpu, lanes=args.lanes))
+        attempt("config4", lambda: run_kmeans(L, ctx, gsx, args.n, 6, 2, cpu=want_cpu, lanes=args.lanes))
         attempt("clustered_1m", clustered)
         attempt("floaters_10m", floaters)
         attempt("blobs_10m_k25", blobs_k25)

@@ -28,7 +28,7 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MU
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 -d $OUT/pmc_sq4_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 # the clouds a uniform grid is bad at: adaptive mode -> Morton-tree path (csrc/sor_tree.hip)
-for C in "clustered 1000000 16" "floaters 10000000 16" "clustered 10000000 16" "clustered 10000000 25"; do
+for C in "clustered 1000000 16" "floaters 10000000 16" "clustered 10000000 16" "clustered 10000000 25" "clustered 10000000 50"; do
   set -- $C
   PROBE_K=$3 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_tree_$1_$2_k$3 -o trace -- python $ROOT/tests/devtools/probe_tree.py time $1 $2 1 > $OUT/tree_trace_${R}_$1_$2_k$3.log 2>&1
   python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_tree_$1_$2_k$3/trace_results.db > $OUT/kernel_stats_${R}_tree_$1_$2_k$3.txt 2>&1
