@@ -61,6 +61,9 @@ constexpr int BRICK_THREADS = 256;  // 4 independent waves per workgroup
 constexpr int HEAVY_RING_CANDIDATES = 1 << 16;
 constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of knn_heavy_scan covers (512 per lane: the
                                     // per-lane top list stops changing after the first few dozen, and the wave merge amortises)
+#ifndef GSX_WCAP_BIG   // mask words parked per wave for the lists of more than 32 entries (round 5: 32 -- these kernels run two or three
+#define GSX_WCAP_BIG 32   // waves per SIMD, LDS is not what limits them; a brick of more words is filtered by the float32 loop: k = 57 11.2 -> 7.8 ms)
+#endif
 constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
 
 // ---------------------------------------------------------------- bbox + grid params
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra,
     unsigned *__restrict__ deferred, double *__restrict__ kth_out)
 {
-    constexpr int WCAP = gsx::WCAP;
+    constexpr int WCAP = KCAP > 33 ? GSX_WCAP_BIG : gsx::WCAP;
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
     // per mask word: first candidate (index into refs); (c1, b2 - c1): candidates of the first row segment and the
     // offset of the second (MFMA words may span two rows).  Two narrow arrays: one 16-byte entry per word read
@@ -2486,7 +2489,12 @@ static int knn_grid_level(gsx_ctx *ctx, int level, const float *x, const float *
         // k = 36 6.28 -> 4.52, k = 41 6.10 -> 5.02, k = 45 7.26 -> 5.73, k = 48 7.50 -> 6.3, k = 50 10.3 -> 8.3; k >= 56: the ring
         // queries win -- profiles/r04_variants.txt)
         if (k >= 26 && k <= 31) pts_per_cell = std::min(pts_per_cell, 12.0 * fill / 54.0);   // (k = 27: 3.49 -> 3.36, k = 30: 3.58 -> 3.42)
-        if (k >= 35 && k <= 52) pts_per_cell = std::min(pts_per_cell, (k <= 38 ? 13.5 : (k <= 46 ? 14.5 : 15.0)) * fill / 54.0);
+        if (k >= 35 && k <= 43) pts_per_cell = std::min(pts_per_cell, (k <= 38 ? 13.5 : 14.5) * fill / 54.0);
+        // Round 5: with 32 parked words (1024 candidates) for the lists of more than 32 entries the cells of k >= 44 can be larger
+        // again -- fewer ring queries (k = 50 at 15 points per cell: 595 k of them, 2.5 of 7.6 ms).  10M uniform, step ms, best of
+        // a sweep 15 ... 26 (profiles/r05_variants.txt): k = 45 5.67 -> 5.41 (16), 47 6.01 -> 5.58 (16), 50 7.60 -> 6.37 (22), 52 8.86 ->
+        // 6.14 (22), 55 7.17 -> 6.81 (22), 57 7.87 -> 7.22 (22), 60 7.87 -> 7.34 (24); k >= 63: 0.47 (k + 1) as before
+        if (k >= 44 && k <= 62) pts_per_cell = std::min(pts_per_cell, k <= 49 ? 16.0 : (k <= 58 ? 22.0 : 24.0));
     }
     GSX_CHECK(w.packed.reserve(sizeof(float4) * (size_t)n_ref));
     GSX_CHECK(w.bucketpts.reserve(sizeof(float4) * (size_t)n_ref));
