@@ -64,6 +64,9 @@ constexpr int HEAVY_CHUNK = 32768;  // points of the sorted array one wave of kn
 #ifndef GSX_WCAP_BIG   // mask words parked per wave for the lists of more than 32 entries (round 5: 32 -- these kernels run two or three
 #define GSX_WCAP_BIG 32   // waves per SIMD, LDS is not what limits them; a brick of more words is filtered by the float32 loop: k = 57 11.2 -> 7.8 ms)
 #endif
+#ifndef GSX_WCAP_MID   // ... and for 17 ... 32 entries (four waves per SIMD)
+#define GSX_WCAP_MID 24
+#endif
 constexpr int WCAP = 24;            // mask words parked in LDS per wave between drains (6 KiB/wave)
 
 // ---------------------------------------------------------------- bbox + grid params
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(BRICK_THREADS, brick_min_waves(KCAP, MF, NET)) void
     float *__restrict__ mean_out, unsigned *__restrict__ faillist, uint2 *__restrict__ extra,
     unsigned *__restrict__ deferred, double *__restrict__ kth_out)
 {
-    constexpr int WCAP = KCAP > 33 ? GSX_WCAP_BIG : gsx::WCAP;
+    constexpr int WCAP = KCAP > 33 ? GSX_WCAP_BIG : (KCAP > 17 ? GSX_WCAP_MID : gsx::WCAP);
     __shared__ unsigned s_mask[BRICK_THREADS / 64][WCAP][64];
     // per mask word: first candidate (index into refs); (c1, b2 - c1): candidates of the first row segment and the
     // offset of the second (MFMA words may span two rows).  Two narrow arrays: one 16-byte entry per word read
