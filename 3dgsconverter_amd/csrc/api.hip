@@ -268,6 +268,10 @@ int gsx_ctx_set_param(gsx_ctx *c, const char *name, double value)
         c->km_group_mb = value < 0 ? 0 : (int)value;
     } else if (!strcmp(name, "kmeans_cs")) {
         c->kmeans_cs = value != 0.0;
+    } else if (!strcmp(name, "km_small_wgs")) {
+        c->km_small_wgs = (int)value;
+    } else if (!strcmp(name, "kmeans_cs_small")) {
+        c->kmeans_cs_small = value != 0.0;
     } else if (!strcmp(name, "ring_fast")) {
         c->ring_fast = value != 0.0;
     } else if (!strcmp(name, "phase2_net")) {

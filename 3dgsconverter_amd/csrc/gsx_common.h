@@ -174,6 +174,8 @@ struct gsx_ctx {
     int km_seg_rows = 32;   // rows of the label-sorted permutation one wave of kmeans_segment_sum takes (64 / 32 / 16: A/B)
     int km_group_mb = 0;   // gsx_kmeans_lloyd_batch_dev: problems are run in groups whose rows fit this many MB (0: all at once) -- a group's
                            // rows then stay in the 256 MB Infinity Cache across its iterations (round 5, A/B)
+    int km_small_wgs = 0;      // workgroups per CU of those shapes (0: 3 resp. 5; A/B)
+    int kmeans_cs_small = 1;   // ... with 4-wave / 2-wave workgroups for K <= 256 / K <= 64 (0: the 16-wave shape for every K; A/B)
     int kmeans_cs = 1;   // centroid-stationary matrix-core assign for K <= 1024 (0: the streaming kernel; A/B)
     int ring_fast = 1;   // knn_ring_fast before knn_ring (0: A/B only)
     int phase2_net = 1;  // knn_brick phase 2: 1 = sorting-network block selection (TopNet), 0 = per-candidate bubble insert (A/B only)

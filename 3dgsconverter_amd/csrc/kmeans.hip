@@ -965,10 +965,22 @@ static int launch_assign_mfma_t(gsx_ctx *c, const float *data, int64_t n, float 
     }
     if (c->kmeans_cs && ktiles <= KM_CS_WAVES * KM_CS_CT) {
         // centroid-stationary: one 16-wave workgroup per CU keeps every centroid operand in registers (kmeans_cs.h); in a
-        // batch a workgroup stays with ONE problem's centroids for all of its share of that problem's rows
-        const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)per);
-        hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks, P), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
-                           ktiles, reinterpret_cast<const float *>(meta), labels, list, meta + 1, kb);
+        // batch a workgroup stays with ONE problem's centroids for all of its share of that problem's rows.  Smaller K
+        // (the palette's 256 and 64 per chunk at --compression_level 4-9): fewer waves per workgroup, more workgroups.
+        const float *metaf = reinterpret_cast<const float *>(meta);
+        if (ktiles <= 2 && c->kmeans_cs_small) {
+            const int blocks = (int)std::min<int64_t>(div_up(n, 64), (int64_t)per * (c->km_small_wgs > 0 ? c->km_small_wgs : 3));
+            hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D, 2, 1, 2>), dim3(blocks, P), dim3(128), 0, c->stream, data, n, opnd, ktiles, metaf,
+                               labels, list, meta + 1, kb);
+        } else if (ktiles <= 8 && c->kmeans_cs_small) {
+            const int blocks = (int)std::min<int64_t>(div_up(n, 64), (int64_t)per * (c->km_small_wgs > 0 ? c->km_small_wgs : 3));   // (141 VGPRs: three waves per SIMD)
+            hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D, 4, 2, 2>), dim3(blocks, P), dim3(256), 0, c->stream, data, n, opnd, ktiles, metaf,
+                               labels, list, meta + 1, kb);
+        } else {
+            const int blocks = (int)std::min<int64_t>(div_up(n, KM_CS_BLOCK), (int64_t)per);
+            hipLaunchKernelGGL((kmeans_assign_mfma_cs_kernel<D>), dim3(blocks, P), dim3(64 * KM_CS_WAVES), 0, c->stream, data, n, opnd,
+                               ktiles, metaf, labels, list, meta + 1, kb);
+        }
     } else {
         const int64_t tiles = div_up(n, KM_MF_TILE);
         const int blocks = (int)std::min<int64_t>(tiles, (int64_t)per * 8);

@@ -23,8 +23,13 @@ constexpr int KM_CS_PTILES = 4;              // 32-point tiles per block
 constexpr int KM_CS_BLOCK = 32 * KM_CS_PTILES;
 constexpr int KM_CS_ML = GSX_KM_ML;
 
-template <int D>
-__global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel(const float *__restrict__ data, int64_t n,
+// Round 5: the shape is a template argument.  WAVES x CT centroid tiles = K / 32; the palette's K per chunk is 1024 for
+// --compression_level 0-3, 256 for 4-6, 64 for 7-9 (sog.py:513-529), and the 16-wave workgroup ran the smaller two with 12 resp.
+// 15 of its waves idle at every barrier: 1.35 / 1.24 ms per iteration of the 10M-splat palette against 2.72 at K = 1024.
+// K <= 256: 4 waves x 2 tiles, K <= 64: 2 waves x 1 tile, both on 64-point blocks (half the LDS: four resp. five workgroups
+// per CU keep the row stream going).
+template <int D, int WAVES = KM_CS_WAVES, int CT = KM_CS_CT, int PTILES = KM_CS_PTILES>
+__global__ __launch_bounds__(64 * WAVES) void kmeans_assign_mfma_cs_kernel(const float *__restrict__ data, int64_t n,
                                                                                 const ku32x4 *__restrict__ opnd, int ktiles,
                                                                                 const float *__restrict__ cmax2,
                                                                                 int32_t *__restrict__ labels,
@@ -33,6 +38,7 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
 {
     constexpr int DP = km_dp(D), NS = DP / 16;
     constexpr int AW = NS * 2 * 64;
+    constexpr int BLOCK = 32 * PTILES;
     {
         const int64_t r0 = km_problem_rows(kb, n);             // problem blockIdx.y: its rows, its centroid operands
         data += r0 * D;
@@ -44,65 +50,82 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     }
     // double buffered: block b+1 is fetched and split while block b runs through the matrix cores, and block b's
     // per-wave results are merged while block b+1 runs
-    __shared__ ku32x4 s_x[2][KM_CS_PTILES][NS][2][64];   // point operand words: (tile, slice, hi/lo, lane)
-    __shared__ float s_part[2][KM_CS_BLOCK][NS * 2];     // |x|^2 by operand word (summed in a fixed order by the merge)
+    __shared__ ku32x4 s_x[2][PTILES][NS][2][64];   // point operand words: (tile, slice, hi/lo, lane)
+    __shared__ float s_part[2][BLOCK][NS * 2];     // |x|^2 by operand word (summed in a fixed order by the merge)
     // (rows padded by two words: the merge reads view 2 sub + u of point p with 8 lanes per point -- bank 4 sub + 2 u + p)
-    __shared__ float s_best[2][KM_CS_WAVES][KM_CS_BLOCK + 2], s_second[2][KM_CS_WAVES][KM_CS_BLOCK + 2];
-    __shared__ int s_idx[2][KM_CS_WAVES][KM_CS_BLOCK + 2];
+    __shared__ float s_best[2][WAVES][BLOCK + 2], s_second[2][WAVES][BLOCK + 2];
+    __shared__ int s_idx[2][WAVES][BLOCK + 2];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float nc2 = *cmax2, nc = __builtin_sqrtf(nc2);
     // this wave's centroid operands, resident for the whole launch
-    ku32x4 a[KM_CS_CT][NS][2];
+    ku32x4 a[CT][NS][2];
 #pragma unroll
-    for (int ct = 0; ct < KM_CS_CT; ++ct) {
-        const int t = min(wv * KM_CS_CT + ct, ktiles - 1);
+    for (int ct = 0; ct < CT; ++ct) {
+        const int t = min(wv * CT + ct, ktiles - 1);
 #pragma unroll
         for (int j = 0; j < NS; ++j)
 #pragma unroll
             for (int v = 0; v < 2; ++v) a[ct][j][v] = opnd[(size_t)t * AW + (size_t)(j * 2 + v) * 64 + lane];
     }
-    const int64_t nblocks = (n + KM_CS_BLOCK - 1) / KM_CS_BLOCK;
-    // one item = 8 dimensions of one point = one operand word pair; 768 items per block, IPT per thread
-    constexpr int NITEMS = KM_CS_PTILES * NS * 64, NT = 64 * KM_CS_WAVES, IPT = (NITEMS + NT - 1) / NT;
-    float v[IPT][8];
+    const int64_t nblocks = (n + BLOCK - 1) / BLOCK;
+    // Round 5: a block's rows are ONE contiguous span of memory (row-major n x D), so every wave fetches ITS rows (BLOCK / WAVES
+    // of them) as consecutive dwords -- two cache lines per wave instruction -- parks them in its own strip of LDS and cuts its
+    // items (8 dimensions of one point = one operand word pair) out of that: only the wave itself reads the strip, no workgroup
+    // barrier.  (Before, lane l loaded 8 dwords of row l: every wave instruction touched 64 different cache lines, 1.9 M cycles
+    // of address processing per CU and iteration of the 10M-splat palette -- hidden behind the matrix cores at K = 1024, the
+    // whole time at K <= 256.)  Strip reads are conflict-free: consecutive lanes read consecutive rows, D = 45 dwords apart.
+    constexpr int RPW = BLOCK / WAVES, FPW = RPW * D, LPL = (FPW + 63) / 64;   // rows / dwords per wave, dwords per lane
+    constexpr int NITEMS = RPW * NS * 2, IPT = (NITEMS + 63) / 64;
+    static_assert(BLOCK % WAVES == 0, "rows per wave");
+    __shared__ float s_raw[WAVES][FPW];
+    float raw[LPL];
     auto fetch = [&](int64_t blk) __attribute__((always_inline)) {   // global loads only (consumed after the compute phase)
-        const int64_t base = blk * KM_CS_BLOCK;
-        const int rows = (int)(n - base < KM_CS_BLOCK ? n - base : KM_CS_BLOCK);
+        const int64_t base = blk * BLOCK;
+        const int rows = (int)(n - base < BLOCK ? n - base : BLOCK);
+        const int mine = min(max(rows - wv * RPW, 0), RPW) * D;   // dwords of this wave's rows that exist
+        const float *__restrict__ src = data + (base + (int64_t)wv * RPW) * D;
 #pragma unroll
-        for (int q = 0; q < IPT; ++q) {
-            const int item = (int)threadIdx.x + q * NT;
-            if (item >= NITEMS) continue;
-            const int il = item & 63, ij = (item >> 6) % NS, ipt = item / (64 * NS);
-            const int r = ipt * 32 + (il & 31);
-            const int rr = r < rows ? r : rows - 1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int d = 16 * ij + 8 * (il >> 5) + i;
-                v[q][i] = d < D ? data[(base + rr) * D + d] : 0.0f;
-            }
+        for (int q = 0; q < LPL; ++q) {
+            const int idx = lane + 64 * q;
+            raw[q] = idx < mine ? src[idx] : 0.0f;
         }
     };
     auto split_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
+        for (int q = 0; q < LPL; ++q) {
+            const int idx = lane + 64 * q;
+            if (idx < FPW) s_raw[wv][idx] = raw[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
         for (int q = 0; q < IPT; ++q) {
-            const int item = (int)threadIdx.x + q * NT;
+            const int item = lane + 64 * q;
             if (item >= NITEMS) continue;
-            const int il = item & 63, ij = (item >> 6) % NS, ipt = item / (64 * NS);
+            const int rl = item % RPW, rest = item / RPW, ij = rest % NS, half = rest / NS;
+            const int r = wv * RPW + rl, ipt = r >> 5, il = (half << 5) | (r & 31);
+            float v[8];
             float acc2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc2 = __builtin_fmaf(v[q][i], v[q][i], acc2);
+            for (int i = 0; i < 8; ++i) {
+                const int d = 16 * ij + 8 * half + i;
+                v[i] = d < D ? s_raw[wv][rl * D + d] : 0.0f;
+                acc2 = __builtin_fmaf(v[i], v[i], acc2);
+            }
             ku32x4 hi, lo;
-            km_split8(v[q], hi, lo);
+            km_split8(v, hi, lo);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {   // 1.0 against the three |c|^2 pieces, in the high operand only
-                const int d = 16 * ij + 8 * (il >> 5) + i;
+                const int d = 16 * ij + 8 * half + i;
                 if (d >= D && d < D + 3) hi[i >> 1] |= 0x3f80u << ((i & 1) * 16);
             }
             s_x[buf][ipt][ij][0][il] = hi;
             s_x[buf][ipt][ij][1][il] = lo;
-            s_part[buf][ipt * 32 + (il & 31)][ij * 2 + (il >> 5)] = acc2;
+            s_part[buf][r][ij * 2 + half] = acc2;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the strip is rewritten for the next block only after these reads)
+        __builtin_amdgcn_wave_barrier();
     };
     if ((int64_t)blockIdx.x < nblocks) {
         fetch(blockIdx.x);
@@ -114,13 +137,13 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
     __syncthreads();
     int cur = 0;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x, cur ^= 1) {
-        const int64_t base = blk * KM_CS_BLOCK;
-        const int rows = (int)(n - base < KM_CS_BLOCK ? n - base : KM_CS_BLOCK);
+        const int64_t base = blk * BLOCK;
+        const int rows = (int)(n - base < BLOCK ? n - base : BLOCK);
         const bool has_next = blk + gridDim.x < nblocks && !(GSX_KM_ABL & 2);
         if (has_next) fetch(blk + gridDim.x);
         // ---- every point tile of the block against this wave's centroid tiles
 #pragma unroll 1
-        for (int pt = 0; pt < KM_CS_PTILES; ++pt) {
+        for (int pt = 0; pt < PTILES; ++pt) {
             if (pt * 32 >= rows) break;   // (a ragged last block)
             ku32x4 xh[NS], xl[NS];
 #pragma unroll
@@ -131,8 +154,8 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
             float best = __builtin_inff(), second = __builtin_inff();
             int btile = 0;
 #pragma unroll
-            for (int ct = 0; ct < KM_CS_CT; ++ct) {
-                const int t = wv * KM_CS_CT + ct;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int t = wv * CT + ct;
                 if (t >= ktiles) break;   // wave-uniform
                 kf32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -176,10 +199,10 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
         // others wait for them at its barrier -- but spreading it over all 16 waves (KM_CS_ML = 8) is slower still (41.4 against
         // 39.5 ms per palette): every wave then pays the LDS round trips.  profiles/r05_variants.txt.
         {
-            constexpr int ML = KM_CS_ML, VPL = KM_CS_WAVES / ML;
-            if ((int)threadIdx.x >= KM_CS_BLOCK * ML) continue;   // (whole waves: KM_CS_BLOCK * ML is a multiple of 64)
+            constexpr int ML = KM_CS_ML, VPL = WAVES / ML;
+            if ((int)threadIdx.x >= BLOCK * ML) continue;   // (whole waves: BLOCK * ML is a multiple of 64)
             const int p = (int)threadIdx.x / ML, sub = (int)threadIdx.x % ML;
-            const int nw = min(KM_CS_WAVES, (ktiles + KM_CS_CT - 1) / KM_CS_CT);
+            const int nw = min(WAVES, (ktiles + CT - 1) / CT);
             float mb = __builtin_inff(), ms = __builtin_inff();
             int mi = 0;
             if (p < rows) {
@@ -219,3 +242,4 @@ __global__ __launch_bounds__(64 * KM_CS_WAVES) void kmeans_assign_mfma_cs_kernel
         }
     }
 }
+

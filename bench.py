@@ -363,12 +363,12 @@ def run_chain(L, ctx_unused, gsx, xyz_host, sensitivity, k, sigma, steps, warmup
         ch.close()
 
 
-def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=0):
+def run_kmeans(L, ctx, gsx, n_scene, steps, warmup, cpu=False, params=(), lanes=0, level=2):
     """BASELINE.json configs[4] with SURVEY.md 8(d) config-5 data: f_rest ~ N(0, 0.1^2) f32 from numpy's seed-0 generator,
     initial centroids = random rows drawn like the reference's front door (np.random.seed(0); one np.random.choice per chunk,
     gpu_ops.py:182).  One step = all chunks of the scene, SH rows resident in HBM."""
     pal = importlib.import_module("3dgsconverter_amd.dist_palette")
-    d, iters, level = 45, 10, 2
+    d, iters = 45, 10
     plan = pal.palette_plan(n_scene, level)
     nch, cs, k = plan["num_chunks"], plan["chunk_size"], plan["k_per_chunk"]
     rng = np.random.default_rng(0)
