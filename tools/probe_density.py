@@ -1,5 +1,6 @@
 """GPU box: the density stage of BASELINE configs[2] alone (10M uniform splats, L=5, sensitivity 0.5 -> voxel 1.1, 0.55 %), on the
-device chain, for `rocprofv3 --kernel-trace --stats` and A/B runs:   python tools/probe_density.py [n] [L] [sensitivity]"""
+device chain, for `rocprofv3 --kernel-trace --stats` and A/B runs:   python tools/probe_density.py [n] [L] [sensitivity] [cloud]
+(cloud: uniform (default) | floaters | blobs -- bench.py's generators; L is ignored for the last two)"""
 import importlib
 import os
 import sys
@@ -15,7 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 ext = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 sens = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
 voxel, thr = max(0.1, 2.0 - 1.8 * sens), 0.1 + 0.9 * sens
-xyz = bench.synth_uniform(n, ext, 0)
+cloud = sys.argv[4] if len(sys.argv) > 4 else "uniform"
+xyz = bench.synth_uniform(n, ext, 0) if cloud == "uniform" else (bench.synth_scene_with_floaters(n, 0) if cloud == "floaters" else bench.synth_clustered(n, 0))
 ch = L.DeviceChain(xyz, keep_pristine=True)
 minpts = int(n * (thr / 100.0))
 res = ch.density_filter(voxel, minpts, False)
