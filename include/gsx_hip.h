@@ -112,7 +112,10 @@ int  gsx_ctx_get_timing(gsx_ctx *ctx, int slot, uint64_t *launches, double *tota
  * a cloud with one dominant density are cubes of ~50 points; f > 0: that factor, no probe -- A/B; results are
  * bit-identical for every value), "filter_mfma" (1 = matrix-core phase-1 filter, default), "timing_mask" (bit s set = slot
  * GSX_T_s records events while timing is enabled; default all -- every event pair costs stream time),
- * "debug_skip" (profiling only) */
+ * "tree_leaf_cap" (0, default: points per leaf of the tree path by k -- 64 up to k = 28, 96 up to 34, 128 above; 64 ... 256: that
+ * capacity; results are bit-identical for every value), "tree_cand_limit" (candidates per 64 points of leaf capacity above which
+ * a leaf hands its queries to the per-query kernels; 0 = 4096), "kmeans_cs_small" (1, default: the K-Means assign kernel uses
+ * 4-wave / 2-wave workgroups for K <= 256 / K <= 64), "km_small_wgs" (their workgroups per CU; 0 = 3), "debug_skip" (profiling only) */
 int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
 
 /* raw device memory for hosts that have no other allocator (bench without torch) */
