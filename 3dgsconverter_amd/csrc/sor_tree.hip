@@ -792,7 +792,12 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
                 const double e3[3] = {(double)hi3[0] - (double)lo3[0], (double)hi3[1] - (double)lo3[1], (double)hi3[2] - (double)lo3[2]};
                 const double emx = fmax(fmax(e3[0], e3[1]), e3[2]);
                 const double vt = fmax(e3[0], 1e-3 * emx) * fmax(e3[1], 1e-3 * emx) * fmax(e3[2], 1e-3 * emx);
-                const double rt = 1.3 * cbrt(0.397 * (double)(k + 1) * vt / (double)min(nq - qb, 64));
+                double rt = 1.3 * cbrt(0.397 * (double)(k + 1) * vt / (double)min(nq - qb, 64));
+                // ... which says nothing when the leaf holds a handful of points (a flyer alone in a node the size of the space
+                // between it and the scene: tight box 0, radius to try half a fine cell, and the descent widened it pass by pass,
+                // 2^-10 -> 2^6): the node was split down to THIS size because its parent held more than a leaf's worth of points,
+                // so the neighbours are about a cell away
+                if (min(nq - qb, 64) <= 4) rt = fmax(rt, 0.5 * rec->cell);
                 {   // one run of list entries per leaf (knn_tree_near takes neighbouring entries together)
                     const unsigned long long fb = __ballot(is_query);
                     unsigned base = 0;
