@@ -68,7 +68,10 @@ constexpr int TREE_THREADS = 256;      // 4 independent waves per workgroup
 #ifndef GSX_TREE_ABL   // profiling builds only (results become wrong): 1 = no phase 2, 2 = no phase 1, 4 = no range look-ups, 16 = no word count, 32 = no cbrt
 #define GSX_TREE_ABL 0
 #endif
-static_assert(GSX_TWCAP <= 32, "the non-empty-word mask of a batch is one 32-bit register");
+#ifndef GSX_TWCAP_BIG   // ... for lists of more than 32 entries (round 5: 32 -- fewer filter passes over the 96 / 128-point leaves, -2 ... -4 % at k = 36 ... 64)
+#define GSX_TWCAP_BIG 32
+#endif
+static_assert(GSX_TWCAP <= 32 && GSX_TWCAP_BIG <= 32, "the non-empty-word mask of a batch is one 32-bit register");
 constexpr int TWCAP = GSX_TWCAP;              // mask words parked in LDS per wave (7 KiB): 896 candidates per single-drain batch
 constexpr int LEAF_TILE = 1024;        // points per workgroup of the leaf-flag kernels
 constexpr int TREE_CAND_LIMIT = 4096;   // a leaf whose searched box holds more points (x leaf capacity / 64) hands its queries to knn_tree_near
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(TREE_THREADS, leaf_min_waves(KCAP)) void knn_leaf_k
     constexpr int L = KCAP - 1;
     using Net = TopNet<L>;
     constexpr int BS = Net::BS, HB = GSX_LEAF_HB < BS ? GSX_LEAF_HB : BS;
+    constexpr int TWCAP = KCAP > 33 ? GSX_TWCAP_BIG : gsx::TWCAP;   // (the kernels of the longer lists run two or three waves per SIMD)
     __shared__ unsigned s_mask[TREE_THREADS / 64][TWCAP][64];
     // per mask word: the (pre-adjusted) first index of up to four key ranges and where in the word each one ends
     __shared__ unsigned s_wb[TREE_THREADS / 64][4][TWCAP];
