@@ -139,3 +139,28 @@ def test_padded_bitonic_merge():
             assert _padded_bitonic_merge(L, 8, a, b)[0] == sorted(a + b)[:L]
     assert {L: counts[L] for L in range(8, 65, 8)} == {8: 12, 16: 32, 24: 52, 32: 80, 40: 100, 48: 128, 56: 156, 64: 192}
     assert counts[28] == 64   # (the default k = 25: a fifth fewer compare-exchanges than the 32-entry list)
+
+
+def test_leaf_window_minimum_by_doubling():
+    """csrc/sor_tree.hip: tree_leaf_flags_kernel restated -- the minimum over the cap + 1 window levels that contain a sorted point is
+    taken from the minima of all 64-entry windows (six doubling passes) at offsets 0, 64, ... and cap + 1 - 64 (overlapping where
+    cap + 1 is no multiple of 64); for every capacity the kernel accepts, against the plain loop round 4 ran"""
+    rng = np.random.default_rng(11)
+    tile = 256
+    for cap in (64, 65, 96, 100, 127, 128, 129, 192, 200, 255, 256):
+        span = tile + cap
+        a = rng.integers(0, 65, size=span + 400).astype(np.int64)
+        a[span:] = 64                       # "no window starts here": what the kernel writes beyond the entries that exist
+        w = a.copy()
+        st = 1
+        while st < 64:                      # w[t] = min a[t .. t + 2 st)
+            w = np.minimum(w, np.concatenate([w[st:], np.full(st, 64)]))
+            st *= 2
+        for t in range(tile):
+            want = a[t:t + cap + 1].min()
+            got = w[t + cap + 1 - 64]
+            d = 0
+            while d + 64 <= cap:
+                got = min(got, w[t + d])
+                d += 64
+            assert got == want, (cap, t)
