@@ -164,3 +164,56 @@ def test_leaf_window_minimum_by_doubling():
                 got = min(got, w[t + d])
                 d += 64
             assert got == want, (cap, t)
+
+
+def _next_word(lens, starts, r, off):
+    """csrc/sor_tree.hip: knn_leaf's next_word restated -- the candidate ranges are ONE flat sequence cut into words of 32 candidates,
+    a word taking pieces of up to four ranges; returns the word's (base, end) pieces and where the next word starts"""
+    nr, fill, pieces = len(lens), 0, []
+    for _ in range(4):
+        ln = lens[r] if r < nr else 0
+        while r < nr and off >= ln:
+            r, off = r + 1, 0
+            ln = lens[r] if r < nr else 0
+        take, st = 0, 0
+        if r < nr and fill < 32:
+            take = min(ln - off, 32 - fill)
+            st = starts[r] + off
+        pieces.append((st - fill, fill + take))   # candidate t of the word, t in [previous end, this end), is index base + t
+        fill += take
+        off += take
+    return pieces, r, off
+
+
+def test_filter_passes_cover_every_candidate_once():
+    """... and the filter takes them in passes of `park` words, each pass resuming at (cr, coff) = the position behind the last word
+    it parked (round 5: boxes of more than 896 candidates).  Every candidate index must come out exactly once, in order."""
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        nr = int(rng.integers(1, 64))
+        lens = [int(x) for x in rng.choice([0, 1, 2, 5, 31, 32, 33, 70, 200], size=nr)]
+        starts, at = [], 1000
+        for ln in lens:
+            starts.append(at)
+            at += ln + int(rng.integers(0, 50))
+        want = [s + i for s, ln in zip(starts, lens) for i in range(ln)]
+        park = int(rng.choice([1, 2, 28, 32]))
+        got, cr, coff, passes, nwords = [], 0, 0, 0, 0
+        while True:
+            widx, more = 0, False
+            pieces, r, off = _next_word(lens, starts, cr, coff)
+            while pieces[3][1] > 0 and widx < park:
+                prev_end = 0
+                for base, end in pieces:
+                    got.extend(base + t for t in range(prev_end, end))
+                    prev_end = end
+                widx += 1
+                nwords += 1
+                cr, coff = r, off
+                pieces, r, off = _next_word(lens, starts, cr, coff)
+            more = pieces[3][1] > 0
+            passes += 1
+            if not more:
+                break
+        assert got == want, (trial, lens, park)
+        assert passes == max(1, -(-nwords // park))
