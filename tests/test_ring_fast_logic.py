@@ -217,3 +217,26 @@ def test_filter_passes_cover_every_candidate_once():
                 break
         assert got == want, (trial, lens, park)
         assert passes == max(1, -(-nwords // park))
+
+
+def test_kmeans_strip_items_cover_every_operand_word_once():
+    """csrc/kmeans_cs.h: every wave of the centroid-stationary assign kernel cuts the operand words of ITS rows out of its LDS strip;
+    item -> (row, 16-dimension slice, half) must hit every (point tile, slice, hi/lo lane) slot of the block exactly once, for the three
+    shapes the launcher uses (waves, points per block) and D = 45 (three slices), 24 (two), 9 (one)"""
+    for waves, block in ((16, 128), (4, 64), (2, 64)):
+        for d in (45, 24, 9):
+            ns = -(-(d + 3) // 16)          # km_dp(D) / 16: the dimensions + three |c|^2 pieces, padded to 16
+            rpw = block // waves
+            seen = set()
+            for wv in range(waves):
+                nitems = rpw * ns * 2
+                for item in range(nitems):
+                    rl, rest = item % rpw, item // rpw
+                    ij, half = rest % ns, rest // ns
+                    r = wv * rpw + rl
+                    slot = (r >> 5, ij, (half << 5) | (r & 31))
+                    assert half < 2 and slot not in seen
+                    seen.add(slot)
+                    # the 8 dimensions this item reads from the strip: row rl of the wave, dimensions 16 ij + 8 half ...
+                    assert rl * d + min(16 * ij + 8 * half, d - 1) < rpw * d
+            assert len(seen) == (block // 32) * ns * 64
