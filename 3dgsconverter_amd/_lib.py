@@ -69,6 +69,22 @@ class DensityInfo(C.Structure):
                 ("kept_clusters", C.c_int64), ("largest", C.c_int64)]
 
 
+SOG_FIELDS = 59   # GSX_SOG_FIELDS: x y z | rot_0..3 | scale_0..2 | f_dc_0..2 | opacity | f_rest_0..44
+SOG_FIELD_NAMES = (["x", "y", "z", "rot_0", "rot_1", "rot_2", "rot_3", "scale_0", "scale_1", "scale_2", "f_dc_0", "f_dc_1", "f_dc_2", "opacity"]
+                   + ["f_rest_%d" % i for i in range(45)])
+
+
+class SogLayout(C.Structure):
+    """gsx_sog_layout (include/gsx_hip.h): where the writer's float32 fields sit inside a row of the structured table"""
+    _fields_ = [("row_bytes", C.c_int64), ("n_rest", C.c_int32), ("offset", C.c_int32 * SOG_FIELDS)]
+
+
+class SogScan(C.Structure):
+    """gsx_sog_scan (include/gsx_hip.h)"""
+    _fields_ = [("vmin", C.c_float * 3), ("vmax", C.c_float * 3), ("nonfinite", C.c_uint32), ("reserved", C.c_uint32),
+                ("rest_nonzero", C.c_uint64)]
+
+
 DENSITY_OK, DENSITY_EMPTY, DENSITY_HOST = range(3)
 SLAB_OK, SLAB_EMPTY, SLAB_NONFINITE, SLAB_SMALL_SHARD, SLAB_NO_STRUCTURE = range(5)
 COMM_F32_MAX, COMM_F32_SUM, COMM_I64_SUM, COMM_F64_MAX, COMM_I64_MIN = range(5)
@@ -151,6 +167,15 @@ SIGNATURES = {
     "gsx_sog_alpha": (_I, [_P, _I64, _P, _P]),
     "gsx_sog_alpha_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_sog_quats_dev": (_I, [_P, _P, _I64, _P]),
+    "gsx_sog_scan_dev": (_I, [_P, _P, C.POINTER(SogLayout), _I64, _P, C.POINTER(SogScan)]),
+    "gsx_sog_extremes_dev": (_I, [_P, _P, _I64, _P, _P, _I, _P, _P]),
+    "gsx_sog_order_dev": (_I, [_P, _P, _I64, _P]),
+    "gsx_sog_gather_dev": (_I, [_P, _P, C.POINTER(SogLayout), _P, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    "gsx_sog_means_texels_dev": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "gsx_sog_quats_texels_dev": (_I, [_P, _P, _I64, _I64, _P]),
+    "gsx_sog_codes_texels_dev": (_I, [_P, _P, _I64, _I64, _P, _I, _P, _P, _P, _I64, _P]),
+    "gsx_sog_labels_texels_dev": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "gsx_gather_rows_dev": (_I, [_P, _P, _I, _P, _I64, _P]),
     "gsx_morton_order_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, C.POINTER(_I)]),
     "gsx_cply_pack_dev": (_I, [_P, _P, _P, _I64, _P, _P]),
     "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
@@ -530,9 +555,12 @@ def kmeans_lloyd_many(problems, max_iter: int, lanes: int = PALETTE_LANES, devic
     if not problems:
         return []
     shapes = {(p[0].shape[1], p[1].shape[0], p[1].shape[1]) for p in problems}
-    if len(shapes) == 1 and len(problems) > 1 and all(len(p[0]) > 0 for p in problems):
+    batched = len(shapes) == 1 and next(iter(shapes))[0] in (9, 24, 45) and next(iter(shapes))[1] >= 64
+    if batched and len(problems) > 1 and all(len(p[0]) > 0 for p in problems):
         # the palette's usual case: every chunk the same d and k -> one batched call, the problem is a grid dimension
-        # (round 5: gsx_kmeans_lloyd_batch_dev; per problem the same kernels, launch order and arithmetic)
+        # (round 5: gsx_kmeans_lloyd_batch_dev; per problem the same kernels, launch order and arithmetic).  Only the shapes
+        # of the matrix-core path batch on the device (d in 9/24/45, k >= 64: the C side's `batched` condition); for the
+        # others the batch entry point would loop the problems on ONE stream, so they keep the concurrent lanes below.
         return kmeans_lloyd_batch(problems, max_iter, device)
     lanes = max(1, min(int(lanes), len(problems)))
     ctxs = [Context(device, own_stream=True) for _ in range(lanes)]

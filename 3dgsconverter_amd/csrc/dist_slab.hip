@@ -560,17 +560,19 @@ int gsx_sor_slab_step_dev(gsx_ctx *c, const float *rows_dev, int64_t n_local, in
     // A rank that fails BETWEEN collectives (a reservation, the planner's row-count check, a launch) would leave its peers
     // blocked in the next one: every error exit tells them (hostwire: their barriers fail at once; RCCL: ncclCommAbort of
     // this rank's communicator, the peers' watchdog -- launch.comm_watchdog -- ends them).  ADVICE round 4.
+    // Argument validation fails identically on every rank BEFORE any collective -- no peer can be left blocked, so it must
+    // not cost the communicator: checked here, outside the abort-on-error wrapper.
+    if (!c || !out || n_local < 0 || (n_local > 0 && !rows_dev)) GSX_FAIL("gsx_sor_slab_step_dev: bad arguments");
+    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_slab_step_dev: k=%d not supported (1 <= k <= 64)", k);
+    if (n_local >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_slab_step_dev: shard too large");
     const int rc = slab_step_body(c, rows_dev, n_local, k, threshold_factor, halo_cells, mask_out_dev, out);
-    if (rc != 0 && c && c->comm) gsx_comm_abort(c);
+    if (rc != 0 && c->comm) gsx_comm_abort(c);
     return rc;
 }
 
 static int slab_step_body(gsx_ctx *c, const float *rows_dev, int64_t n_local, int k, double threshold_factor, double halo_cells,
                           uint8_t *mask_out_dev, gsx_slab_step_t *out)
 {
-    if (!c || !out || n_local < 0 || (n_local > 0 && !rows_dev)) GSX_FAIL("gsx_sor_slab_step_dev: bad arguments");
-    if (k < 1 || k > 64) GSX_FAIL("gsx_sor_slab_step_dev: k=%d not supported (1 <= k <= 64)", k);
-    if (n_local >= (1LL << 31) - 1024) GSX_FAIL("gsx_sor_slab_step_dev: shard too large");
     GSX_HIP(hipSetDevice(c->device));
     memset(out, 0, sizeof(*out));
     int G = 1, r = 0;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "gsx_common.h"
+#include "sog_math.h"
 
 namespace gsx {
 
@@ -895,17 +896,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float *__restrict__
     for (int i = threadIdx.x; i < kcb; i += 256) lcb[i] = cb[i];
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = vals[i];
-        int lo = 0, hi = kcb;  // np.searchsorted(cb, v, 'left'): first index with cb[idx] >= v
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (lcb[mid] < v) lo = mid + 1; else hi = mid;
-        }
-        int idx = min(lo, kcb - 1);
-        int left = max(idx - 1, 0);
-        float d_idx = fabsf(v - lcb[idx]);
-        float d_left = fabsf(v - lcb[left]);
-        if (d_left < d_idx) idx = left;  // strict: ties go to the right neighbour
+        const int idx = sog_codebook_index(lcb, kcb, vals[i]);   // sog_math.h
         out[i] = (uint8_t)idx;
     }
 }

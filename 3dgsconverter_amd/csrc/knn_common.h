@@ -226,7 +226,8 @@ __device__ __forceinline__ float mean_from_net(const TopNet<L> &lst, int k)
 #pragma unroll
     for (int j = 0; j < L; ++j) b[j] = sqrt_rn_dist2(lst.a[j]);
     double res;
-    if (k == L) {  // wave-uniform; the headline k = 16 / 32: numpy's 8 accumulators over a multiple of 8, no scalar branches
+    if (L % 8 == 0 && k == L) {  // wave-uniform; the headline k = 16 / 32: numpy's 8 accumulators over a MULTIPLE of 8, no scalar
+                                 // branches (L = 12, 20, 28 ...: numpy adds the last 4 sequentially -> the general branch)
         double r[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) r[t] = b[t];

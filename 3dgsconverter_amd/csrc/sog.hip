@@ -19,17 +19,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "gsx_common.h"
+#include "sog_math.h"
 
 namespace gsx {
-
-// float32 -> uint32 whose unsigned order is numpy's sort order: -0.0 == +0.0, every NaN last
-__device__ __forceinline__ unsigned sort_key(float v)
-{
-    if (v != v) return 0xffffffffu;
-    if (v == 0.0f) v = 0.0f;  // -0.0 -> +0.0
-    const unsigned b = __float_as_uint(v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 
 __global__ __launch_bounds__(256) void lexsort_keys_kernel(const float *__restrict__ col, int64_t stride,
                                                            const unsigned *__restrict__ perm /* null: identity */, int64_t n,
@@ -45,108 +37,29 @@ __global__ __launch_bounds__(256) void lexsort_keys_kernel(const float *__restri
 // sog.py:315-386.  rot: (n,4) float32 rows (rot_0..rot_3); out: 4 bytes per splat (c0, c1, c2, 252 + max_idx)
 __global__ __launch_bounds__(256) void sog_quats_kernel(const float *__restrict__ rot, int64_t n, uchar4 *__restrict__ out)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float4 q4 = reinterpret_cast<const float4 *>(rot)[i];
-        float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        // np.linalg.norm(q, axis=1): sqrt(add.reduce(q*q)) in float32, four elements summed left to right
-        float s = __fmul_rn(q[0], q[0]);
-        s = __fadd_rn(s, __fmul_rn(q[1], q[1]));
-        s = __fadd_rn(s, __fmul_rn(q[2], q[2]));
-        s = __fadd_rn(s, __fmul_rn(q[3], q[3]));
-        const float nrm = __fsqrt_rn(s);
-        int mi = 0;
-        float ma = -1.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            q[c] = __fdiv_rn(q[c], nrm);                // qn = q / norm
-            const float a = fabsf(q[c]);
-            if (a > ma) {                               // np.abs(qn).argmax(axis=1): first maximum
-                ma = a;
-                mi = c;
-            }
-        }
-        const float mv = q[mi];
-        const float sg = mv > 0.0f ? 1.0f : (mv < 0.0f ? -1.0f : 0.0f);   // np.sign(max_val)
-        unsigned char b[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = __fmul_rn(q[c], sg);                                  // qn *= sign_flip
-            v = (float)((double)v * 1.4142135623730951);                    // qn *= np.sqrt(2.0): float64 scalar, cast back
-            float t = __fadd_rn(__fmul_rn(v, 0.5f), 0.5f);                  // quantize_vec: (v*0.5 + 0.5) * 255.0, float32
-            t = __fmul_rn(t, 255.0f);
-            t = fminf(fmaxf(t, 0.0f), 255.0f);                              // np.clip
-            b[c] = (unsigned char)t;                                        // astype(uint8): truncation
-        }
-        // the three components that are not the maximum, in index order
-        const int i0 = mi == 0 ? 1 : 0, i1 = mi <= 1 ? 2 : 1, i2 = mi == 3 ? 2 : 3;
-        out[i] = make_uchar4(b[i0], b[i1], b[i2], (unsigned char)(252 + mi));
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = sog_quat_pack(reinterpret_cast<const float4 *>(rot)[i]);
 }
 
-// float32 value `steps` ulps above (steps > 0) or below a finite float, crossing zero correctly
-__device__ __forceinline__ float ulp_step(float a, int steps)
-{
-    int b = (int)__float_as_uint(a);
-    b = b < 0 ? (int)0x80000000u - b : b;   // ordered integer: monotone in the float value
-    b += steps;
-    b = b < 0 ? (int)0x80000000u - b : b;
-    return __uint_as_float((unsigned)b);
-}
-
-// numpy's float32 SIMD routines: log max error 3.83 ulp, exp 2.52 ulp (their documented bounds; measured here on 28M values
-// each: 3.01 and 2.52).  The brackets add the half ulp of rounding the float64 value to float32 and a margin.
-constexpr int SOG_ULPS_LOG = 5, SOG_ULPS_EXP = 4;
-// (no absolute slack near 0: for |v| + 1 within a few ulp of 1 numpy's log keeps its RELATIVE accuracy -- measured 1.2 ulp
-//  at |v| ~ 1e-6 -- and an absolute term would flag every texel of a scene a few micro-units across)
-
-// sog.py:279-309 for one axis: v -> sign(v) log(|v| + 1) -> (l - mn) / (mx - mn) * 65535 -> clip -> u16
+// sog.py:279-309 for one axis (sog_math.h: sog_position_texel)
 __global__ __launch_bounds__(256) void sog_positions_kernel(const float *__restrict__ v, int64_t n, float mn, float mx,
                                                             uint16_t *__restrict__ out, uint8_t *__restrict__ uncertain)
 {
     const float range = __fsub_rn(mx, mn);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float x = v[i];
-        const float t = __fadd_rn(fabsf(x), 1.0f);                       // np.abs(v) + 1.0 in float32
-        const float sg = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);    // np.sign
-        const double lt = (double)sg * ::log((double)t);
-        const float a = (float)lt;
-        float lo = ulp_step(a, -SOG_ULPS_LOG), hi = ulp_step(a, SOG_ULPS_LOG);
-        if (sg == 0.0f) lo = hi = 0.0f;                                   // 0 * log(1) is exactly 0 whatever log returns
-        unsigned q[2];
-        const float e[2] = {lo, hi};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float r = __fdiv_rn(__fsub_rn(e[s], mn), range);
-            r = __fmul_rn(r, 65535.0f);
-            r = fminf(fmaxf(r, 0.0f), 65535.0f);
-            q[s] = (unsigned)r;
-        }
-        const bool ok = q[0] == q[1] && (x == x) && fabsf(x) <= 3.0e38f && range > 0.0f;
-        out[i] = (uint16_t)q[0];
+        bool ok;
+        out[i] = (uint16_t)sog_position_texel(v[i], mn, range, &ok);
         uncertain[i] = ok ? 0 : 1;
     }
 }
 
-// sog.py:457-459: 1 / (1 + exp(-o)) * 255 -> clip -> u8
+// sog.py:457-459: 1 / (1 + exp(-o)) * 255 -> clip -> u8 (sog_math.h: sog_alpha_texel)
 __global__ __launch_bounds__(256) void sog_alpha_kernel(const float *__restrict__ o, int64_t n, uint8_t *__restrict__ out,
                                                         uint8_t *__restrict__ uncertain)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float x = o[i];
-        const double et = ::exp(-(double)x);
-        bool ok = (x == x) && fabsf(x) < 80.0f;                          // outside: exp over/underflows in float32 -> host
-        const float a = ok ? (float)et : 1.0f;
-        const float e[2] = {ulp_step(a, -SOG_ULPS_EXP), ulp_step(a, SOG_ULPS_EXP)};
-        unsigned q[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float r = __fdiv_rn(1.0f, __fadd_rn(1.0f, e[s]));
-            r = __fmul_rn(r, 255.0f);
-            r = fminf(fmaxf(r, 0.0f), 255.0f);
-            q[s] = (unsigned)r;
-        }
-        ok = ok && q[0] == q[1];
-        out[i] = (uint8_t)q[0];
+        bool ok;
+        out[i] = (uint8_t)sog_alpha_texel(o[i], &ok);
         uncertain[i] = ok ? 0 : 1;
     }
 }

@@ -21,6 +21,11 @@ Same bundle layout and the same bytes wherever the reference is deterministic; w
   |                                               | on the GPU                                                   |
   | :269-276, 566-639 WebP textures, meta, zip     | pillow / zipfile, as the reference (out of scope: packaging) |
 
+Round 6: the table is DEVICE-RESIDENT for the whole core (formats/sog_device.py, csrc/sog_table.hip): the raw rows are uploaded
+once, lexsort / ``data[indices]`` / texels / codebooks / palette run in HBM, texels come back.  The host-staged core below (one
+upload / download per stage) remains for the tables that path does not take (non-float32 fields, fewer than 1024 rows,
+non-finite coordinates) and for a palette dealt out across GPUs.
+
 ``install(sog_writer=True)`` rebinds ``gsconverter.formats.sog.SogFormat.write`` to this function, which also makes the
 GPU quantiser reachable from the reference's CLI (in the reference it is a closure inside ``write``).
 """
@@ -36,6 +41,7 @@ from .. import _lib
 from ..processing import gpu_ops
 from ..utils import debug_print, status_print
 from .. import dist_palette
+from . import sog_device
 
 
 def _texture_size(n):
@@ -97,16 +103,16 @@ def _sh_bands(data, ds):
     return bands
 
 
-def write_sog(data: np.ndarray, path: str, comm=None, be=None, **kwargs):
-    """data: the reference's structured splat table.  comm / be: optional communicator + buffer backend of dist_slab for
-    the SH palette across GPUs (every rank passes the same table; rank 0's file is the result)."""
+def _encode_host(data: np.ndarray, level: int, comm=None, be=None) -> dict:
+    """The numeric core with the table on the HOST: one upload / download per stage (round 3's writer).  Takes every table the
+    reference takes (any dtype, tiny tables with their k >= N shortcuts, a palette dealt out across GPUs through comm / be);
+    returns what sog_device.encode returns."""
     n = len(data)
-    debug_print(f"[DEBUG] Writing .sog file to {path}")
     width, height = _texture_size(n)
     texels = width * height
     order = _lib.lexsort3(data["z"], data["y"], data["x"])                    # :264
     ds = data[order]
-    zf = zipfile.ZipFile(path, "w", zipfile.ZIP_STORED)
+    out = {"n": n, "width": width, "height": height, "textures": {}, "stats": {}}
 
     # positions: low / high byte textures (:300-312)
     u16, mins, maxs = _positions(ds)
@@ -115,64 +121,104 @@ def write_sog(data: np.ndarray, path: str, comm=None, be=None, **kwargs):
     for c in range(3):
         lo[:n, c] = u16[c] & 0xff
         hi[:n, c] = u16[c] >> 8
-    _webp(zf, "means_l.webp", lo, width, height)
-    _webp(zf, "means_u.webp", hi, width, height)
+    out["textures"]["means_l"], out["textures"]["means_u"] = lo, hi
+    out["mins"], out["maxs"] = mins, maxs
 
     # rotations (:315-386)
     quats = np.full((texels, 4), 255, np.uint8)
     quats[:n] = _lib.sog_quats(np.column_stack((ds["rot_0"], ds["rot_1"], ds["rot_2"], ds["rot_3"])))
-    _webp(zf, "quats.webp", quats, width, height)
+    out["textures"]["quats"] = quats
 
     # scales (:388-431) and colours + opacity (:433-459)
     scale_cb, (s0, s1, s2) = _scalar_codebook(("scale_0", "scale_1", "scale_2"), ds, "Clustering Scales...")
     scales = np.zeros((texels, 4), np.uint8)
     scales[:n, 0], scales[:n, 1], scales[:n, 2], scales[:n, 3] = s0, s1, s2, 255
-    _webp(zf, "scales.webp", scales, width, height)
+    out["textures"]["scales"], out["scale_codebook"] = scales, scale_cb
     color_cb, (d0, d1, d2) = _scalar_codebook(("f_dc_0", "f_dc_1", "f_dc_2"), ds, "Clustering Colors...")
     sh0 = np.zeros((texels, 4), np.uint8)
     sh0[:n, 0], sh0[:n, 1], sh0[:n, 2] = d0, d1, d2
     sh0[:n, 3] = _lib.sog_alpha(ds["opacity"])                                                 # :457-459
-    _webp(zf, "sh0.webp", sh0, width, height)
+    out["textures"]["sh0"], out["color_codebook"] = sh0, color_cb
 
     # SH-N palette (:496-600)
-    shn_meta = None
-    bands = _sh_bands(data, ds)
+    bands = out["bands"] = _sh_bands(data, ds)
     if bands > 0:
         coeffs = [0, 9, 24, 45][bands]
         sh = np.column_stack([ds["f_rest_%d" % i] for i in range(coeffs)]).astype(np.float32)
-        try:
-            level = int(kwargs.get("compression_level", 0))
-        except Exception:
-            level = 0
         status_print(f"SOG Write Quality Level: {level} (0=Max, 9=Min)")
-        plan = dist_palette.palette_plan(n, level)
-        status_print(f"SH Clustering: K={plan['target_k']}, Points={n}. Strategy: GPU (HIP gfx950)")
+        status_print(f"SH Clustering: K={dist_palette.palette_plan(n, level)['target_k']}, Points={n}. Strategy: GPU (HIP gfx950)")
         centroids, labels = dist_palette.palette_kmeans(sh, level, 10, comm=comm, be=be)
-        palette = len(centroids)
+        palette = out["palette"] = len(centroids)
         status_print("Clustering SH Centroids into Codebook...")
         flat = np.ascontiguousarray(centroids, dtype=np.float32).reshape(-1)
         if len(flat) > 256:                                                                               # :561
             codebook = _lib.kmeans1d(flat, 256, iters=100).astype(np.float64)
         else:   # fewer scalars than codebook entries (sklearn would raise): every scalar is its own entry
             codebook = np.array(sorted(flat.tolist()))
-        cidx = gpu_ops.quantize_to_codebook(centroids.flatten(), codebook)
+        out["shn_codebook"] = codebook
+        out["shn_centroid_index"] = gpu_ops.quantize_to_codebook(centroids.flatten(), codebook)
+        limg = np.zeros((texels, 4), np.uint8)
+        l16 = labels.astype(np.uint16)
+        limg[:n, 0], limg[:n, 1], limg[:n, 2], limg[:n, 3] = l16 & 0xff, l16 >> 8, 0, 255
+        out["textures"]["shN_labels"] = limg
+        assert palette * coeffs == len(out["shn_centroid_index"])
+    return out
+
+
+DEVICE_RESIDENT = None   # default of encode(device_resident=...): None = whenever eligible (the CPU-only call-sequence test of the
+                         # host-staged stages, tests/test_e2e_reference_dropin.py, sets False)
+
+
+def encode(data: np.ndarray, level: int = 0, comm=None, be=None, device_resident=None, profile: bool = False) -> dict:
+    """every array SogFormat.write hands to write_webp + the numbers of its meta.json (sog.py:249-600 without the packaging).
+    device_resident: None = the device-resident core (formats/sog_device.py) whenever the table and the request allow it,
+    True = insist (NotEligible propagates), False = the host-staged core."""
+    if device_resident is None:
+        device_resident = DEVICE_RESIDENT
+    if device_resident is not False and comm is None:
+        try:
+            return sog_device.encode(data, level, profile=profile)
+        except sog_device.NotEligible as e:
+            if device_resident:
+                raise
+            debug_print(f"[DEBUG] SOG Write: host-staged core ({e})")
+    return _encode_host(data, level, comm=comm, be=be)
+
+
+def write_sog(data: np.ndarray, path: str, comm=None, be=None, **kwargs):
+    """data: the reference's structured splat table.  comm / be: optional communicator + buffer backend of dist_slab for
+    the SH palette across GPUs (every rank passes the same table; rank 0's file is the result)."""
+    n = len(data)
+    debug_print(f"[DEBUG] Writing .sog file to {path}")
+    try:
+        level = int(kwargs.get("compression_level", 0))
+    except Exception:
+        level = 0
+    core = encode(data, level, comm=comm, be=be, device_resident=kwargs.get("device_resident"))
+    width, height, tex = core["width"], core["height"], core["textures"]
+    zf = zipfile.ZipFile(path, "w", zipfile.ZIP_STORED)
+    for name in ("means_l", "means_u", "quats", "scales", "sh0"):
+        _webp(zf, name + ".webp", tex[name], width, height)
+
+    shn_meta = None
+    bands = core["bands"]
+    if bands > 0:
+        coeffs = [0, 9, 24, 45][bands]
+        palette, codebook, cidx = core["palette"], core["shn_codebook"], core["shn_centroid_index"]
         w_c, h_c = 64 * coeffs, int(np.ceil(palette / 64))
         cimg = np.full((w_c * h_c, 4), 255, np.uint8)
         per = cidx.reshape(palette, 3, coeffs // 3).transpose(0, 2, 1).reshape(-1, 3)                 # (P, 3, C) -> (P*C, 3), :580-590
         cimg[:len(per), :3] = per
         _webp(zf, "shN_centroids.webp", cimg, w_c, h_c)
-        limg = np.zeros((texels, 4), np.uint8)
-        l16 = labels.astype(np.uint16)
-        limg[:n, 0], limg[:n, 1], limg[:n, 2], limg[:n, 3] = l16 & 0xff, l16 >> 8, 0, 255
-        _webp(zf, "shN_labels.webp", limg, width, height)
+        _webp(zf, "shN_labels.webp", tex["shN_labels"], width, height)
         shn_meta = {"count": int(palette), "bands": int(bands), "codebook": [float(c) for c in codebook],
                     "files": ["shN_centroids.webp", "shN_labels.webp"]}
 
     meta = {"version": 2, "asset": {"generator": "gsconverter-sog"}, "count": n,
-            "means": {"mins": [float(m) for m in mins], "maxs": [float(m) for m in maxs], "files": ["means_l.webp", "means_u.webp"]},
-            "scales": {"codebook": [float(c) for c in scale_cb], "files": ["scales.webp"]},
+            "means": {"mins": [float(m) for m in core["mins"]], "maxs": [float(m) for m in core["maxs"]], "files": ["means_l.webp", "means_u.webp"]},
+            "scales": {"codebook": [float(c) for c in core["scale_codebook"]], "files": ["scales.webp"]},
             "quats": {"files": ["quats.webp"]},
-            "sh0": {"codebook": [float(c) for c in color_cb], "files": ["sh0.webp"]}}
+            "sh0": {"codebook": [float(c) for c in core["color_codebook"]], "files": ["sh0.webp"]}}
     if shn_meta:
         meta["shN"] = shn_meta
     zf.writestr("meta.json", json.dumps(meta))

@@ -465,6 +465,66 @@ int gsx_sog_alpha_dev(gsx_ctx *ctx, const float *opacity_dev, int64_t n, uint8_t
 int gsx_sog_quats(const float *rot_rows, int64_t n, uint8_t *out4);
 int gsx_sog_quats_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, uint8_t *out4_dev);
 
+/* ---- the SOG writer on a DEVICE-RESIDENT splat table (csrc/sog_table.hip) ----
+ * formats/sog.py:249-600 between the structured table and the RGBA texel arrays of its WebP images, without the host copies
+ * the reference makes (`data_s = data[indices]` :265, the quaternion / SH `column_stack`s :315,:499-503, `np.concatenate` of
+ * the 3N scalars :391,:434): the raw rows are uploaded once (gsx_dev_upload), every stage reads and writes HBM, only texels
+ * (4 bytes per splat and image) and short lists of texels for the host's numpy come back.  Call order:
+ * scan -> extremes -> order -> gather -> *_texels (+ gsx_kmeans1d_dev / gsx_kmeans_lloyd_batch_dev for the codebooks). */
+#define GSX_SOG_FIELDS 59
+typedef struct gsx_sog_layout {
+    int64_t row_bytes;                 /* itemsize of the structured dtype: a multiple of 4, at most 512 */
+    int32_t n_rest;                    /* f_rest columns present (0, 9, 24 or 45: sog.py:468-474) */
+    int32_t offset[GSX_SOG_FIELDS];    /* byte offset of the float32 fields x y z | rot_0..3 | scale_0..2 | f_dc_0..2 | opacity |
+                                          f_rest_0..44 inside a row (multiples of 4; entries beyond 14 + n_rest are ignored) */
+} gsx_sog_layout;
+typedef struct gsx_sog_scan {
+    float    vmin[3], vmax[3];         /* np.min / np.max of x, y, z (a -0.0 is reported as +0.0) */
+    uint32_t nonfinite;                /* bit a: axis a holds a NaN or an infinity */
+    uint32_t reserved;
+    uint64_t rest_nonzero;             /* bit i: np.any(data['f_rest_i'] != 0) -- the band detection of sog.py:476-486 */
+} gsx_sog_scan;
+/* one pass over the n rows in table order: keys3_dev[a * n + i] = the uint32 whose unsigned order is numpy's sort order of
+ * axis a's float32 value (-0.0 == +0.0, NaN last); *out (HOST) after one small synchronisation */
+int gsx_sog_scan_dev(gsx_ctx *ctx, const void *rows_dev, const gsx_sog_layout *layout, int64_t n, uint32_t *keys3_dev,
+                     gsx_sog_scan *out);
+/* the values v <= lo3[a] (list 2a) and v >= hi3[a] (list 2a + 1) of every axis, from the key columns: the candidates for
+ * np.min / np.max of the log-transformed axis (sog.py:287-288; numpy's float32 log is monotone only up to a few ulp, so the
+ * host evaluates its own expression on the values within a small window of the extremes).  vals_out: HOST float[6][cap],
+ * counts6_out: HOST, the true list lengths (entries beyond cap are dropped).  Synchronises. */
+int gsx_sog_extremes_dev(gsx_ctx *ctx, const uint32_t *keys3_dev, int64_t n, const float *lo3, const float *hi3, int cap,
+                         float *vals_out, int64_t *counts6_out);
+/* perm = np.lexsort((z, y, x)) (sog.py:264) from the key columns: three stable radix passes */
+int gsx_sog_order_dev(gsx_ctx *ctx, const uint32_t *keys3_dev, int64_t n, uint32_t *perm_out_dev);
+/* `data_s = data[indices]` (sog.py:265) for the columns the writer reads, one pass: pos_dev f32[3][n] (x, y, z columns),
+ * rot_dev f32[n][4] (the column_stack of :315), scale_dev / dc_dev f32[3][n] (= the np.concatenate of :391 / :434),
+ * opacity_dev f32[n], sh_dev f32[n][d_sh] (the column_stack of :499-503; d_sh = 0, 9, 24 or 45; nullable for 0) */
+int gsx_sog_gather_dev(gsx_ctx *ctx, const void *rows_dev, const gsx_sog_layout *layout, const uint32_t *perm_dev, int64_t n,
+                       int d_sh, float *pos_dev, float *rot_dev, float *scale_dev, float *dc_dev, float *opacity_dev,
+                       float *sh_dev);
+/* Texel writers: out = `texels` x 4 bytes, the flat RGBA array the reference hands to write_webp (texels = width * height
+ * >= n; the padding texels get the reference's fill value).  Lists: `cap` entries of two uint32 (texel index * 4 + channel,
+ * the bits of the float32 input value) for the values whose float32 log / exp bracket straddles a rounding boundary -- the
+ * caller evaluates numpy's own expression for those (see gsx_sog_positions) and patches the texel; *count_dev (uint32,
+ * zeroed by the call) keeps counting past cap.
+ *   means:  sog.py:279-312 -> means_l (low bytes of the u16 x, y, z, 255) and means_u (high bytes, 255); padding 255
+ *   quats:  sog.py:315-386 -> (c0, c1, c2, 252 + argmax); padding 255
+ *   codes:  sog.py:408-431 / :446-459 -> (codebook index of the three columns, 255 or -- opacity_dev given -- the sigmoid of
+ *           the opacity as a byte); padding 0.  cols3_dev = f32[3][n], codebook_dev = kcb <= 256 ascending float32
+ *   labels: sog.py:546-552,:600-606 -> palette label = labels_dev[i] + (i / chunk_rows) * k as (low byte, high byte, 0, 255) */
+int gsx_sog_means_texels_dev(gsx_ctx *ctx, const float *pos_dev, int64_t n, int64_t texels, const float *log_min3,
+                             const float *log_max3, uint8_t *means_l_dev, uint8_t *means_u_dev, uint32_t *list_dev,
+                             int64_t cap, uint32_t *count_dev);
+int gsx_sog_quats_texels_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, int64_t texels, uint8_t *out_dev);
+int gsx_sog_codes_texels_dev(gsx_ctx *ctx, const float *cols3_dev, int64_t n, int64_t texels, const float *codebook_dev, int kcb,
+                             const float *opacity_dev /* nullable */, uint8_t *out_dev, uint32_t *list_dev, int64_t cap,
+                             uint32_t *count_dev);
+int gsx_sog_labels_texels_dev(gsx_ctx *ctx, const int32_t *labels_dev, int64_t n, int64_t texels, int64_t chunk_rows, int k,
+                              uint8_t *out_dev);
+/* dst row i = src row idx_dev[i] (rows of row_floats float32): `s_data[idx]` of the codebooks' 50 000-sample (sog.py:397-400,
+ * row_floats = 1) and the palette's initial centroids `data[np.random.choice(N, k)]` (gpu_ops.py:182) */
+int gsx_gather_rows_dev(gsx_ctx *ctx, const float *src_dev, int row_floats, const int64_t *idx_dev, int64_t m, float *dst_dev);
+
 /* ---- compressed-PLY writer numeric core ---- */
 /*
  * formats/compressed_ply.py:245-291 _sort_morton_order: 10-bit-per-axis Morton codes inside the bounding box, groups of

@@ -224,6 +224,12 @@ def dropin(gsx, monkeypatch):
         monkeypatch.setattr(lib, name, fn)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_HIP", True)
     monkeypatch.setattr(gsx.gpu_ops, "HAS_TAICHI", True)
+    # the SOG writer's device-resident core (formats/sog_device.py) is one sequence of _dev calls on a resident table: it has no
+    # per-stage host entry points for the oracle to stand in for, so this GPU-less test drives the host-staged core (the same
+    # kernels' arithmetic, one call per stage); the resident core is tested on the GPU against the reference's own bundle
+    # (tests/test_sog_gpu.py)
+    import importlib
+    monkeypatch.setattr(importlib.import_module("3dgsconverter_amd.formats.sog_writer"), "DEVICE_RESIDENT", False)
     gsx.install()
     try:
         yield hits

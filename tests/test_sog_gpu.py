@@ -65,7 +65,8 @@ def test_quats_random_and_axis_aligned(gsx):
     np.testing.assert_array_equal(lib.sog_quats(q), want)
 
 
-def test_write_sog_on_the_device_reproduces_the_reference_bundle(gsx, kref, tmp_path):
+@pytest.mark.parametrize("name,resident", [("sog_20k_l2", True), ("sog_20k_l2", False), ("sog_3k_l8", True)])
+def test_write_sog_on_the_device_reproduces_the_reference_bundle(gsx, kref, tmp_path, name, resident):
     """formats/sog_writer.py:write_sog with the real library: the textures that do not depend on the random K-Means init
     are byte-identical to the bundle the reference wrote from the same table (committed fixture); the clustered ones are
     consistent with the codebooks stored next to them"""
@@ -75,14 +76,14 @@ def test_write_sog_on_the_device_reproduces_the_reference_bundle(gsx, kref, tmp_
     from PIL import Image
     from oracle import kmeans as okm
     cases, arr = kref
-    name = "sog_20k_l2"
     case = cases["sog"][name]
     n = case["n"]
     data = datasets.sog_scene(n, case["scene_seed"])
     w = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
     path = str(tmp_path / "out.sog")
     np.random.seed(case["np_seed"])
-    w.write_sog(data, path, compression_level=case["compression_level"])
+    # resident: the table stays in HBM for the whole core (round 6, formats/sog_device.py); else one upload / download per stage
+    w.write_sog(data, path, compression_level=case["compression_level"], device_resident=resident)
     with zipfile.ZipFile(path) as zf:
         meta = json.loads(zf.read("meta.json"))
         tex = {f[:-5]: np.asarray(Image.open(io.BytesIO(zf.read(f))).convert("RGBA"), dtype=np.uint8).reshape(-1, 4)
@@ -162,3 +163,164 @@ def test_sigmoid_alpha_device_path_is_numpys_bytes(gsx):
         want = np.clip(1.0 / (1.0 + np.exp(-o)) * 255, 0, 255).astype(np.uint8)
     np.testing.assert_array_equal(got, want)
     assert stats["uncertain"] <= 0.005 * n, stats
+
+
+# ---- round 6: the writer's core on a device-resident table (formats/sog_device.py, csrc/sog_table.hip) -------------------
+
+def _sog_writer():
+    import importlib
+    return importlib.import_module("3dgsconverter_amd.formats.sog_writer")
+
+
+def _check_core_against_numpy(core, data, level):
+    """every texture of a device-resident encode against the reference's numpy expressions (oracle/sog.py restates
+    formats/sog.py:264-386,457-459 line by line) on the lexsorted table; the clustered textures against their own codebooks"""
+    from oracle import kmeans as okm
+    n = len(data)
+    tex = core["textures"]
+    texels = core["width"] * core["height"]
+    ds = data[osog.order(data)]
+    with np.errstate(all="ignore"):
+        lo, hi, mins, maxs = osog.positions(ds)
+        want_q, want_a = osog.quats(ds), osog.opacity_u8(ds)
+    for c in range(3):
+        assert np.float32(core["mins"][c]).tobytes() == np.float32(mins[c]).tobytes()
+        assert np.float32(core["maxs"][c]).tobytes() == np.float32(maxs[c]).tobytes()
+    np.testing.assert_array_equal(tex["means_l"][:n, :3], lo)
+    np.testing.assert_array_equal(tex["means_u"][:n, :3], hi)
+    np.testing.assert_array_equal(tex["quats"][:n], want_q)
+    np.testing.assert_array_equal(tex["sh0"][:n, 3], want_a)
+    # fill values of the reference's np.full / np.zeros images (:300-301, :340, :425, :451, :598-606)
+    for name, fill, alpha in (("means_l", 255, 255), ("means_u", 255, 255), ("quats", 255, None), ("scales", 0, 255), ("sh0", 0, None)):
+        assert tex[name].shape == (texels, 4) and np.all(tex[name][n:] == fill), name
+        if alpha is not None:
+            assert np.all(tex[name][:n, 3] == alpha), name
+    for name, cols, cbk in (("scales", ["scale_0", "scale_1", "scale_2"], "scale_codebook"), ("sh0", ["f_dc_0", "f_dc_1", "f_dc_2"], "color_codebook")):
+        cb = np.asarray(core[cbk], dtype=np.float32)
+        assert len(cb) == 256 and np.all(np.diff(cb) >= 0)
+        for ch, col in enumerate(cols):
+            np.testing.assert_array_equal(okm.quantize_to_codebook(ds[col], cb), tex[name][:n, ch])
+    if core["bands"] > 0:
+        coeffs = [0, 9, 24, 45][core["bands"]]
+        plan = okm.sog_sh_plan(n, level)
+        lab = tex["shN_labels"][:n, 0].astype(np.int64) + 256 * tex["shN_labels"][:n, 1].astype(np.int64)
+        assert np.all(tex["shN_labels"][:n, 2] == 0) and np.all(tex["shN_labels"][:n, 3] == 255) and np.all(tex["shN_labels"][n:] == 0)
+        chunk = np.arange(n) // plan["chunk_size"]
+        assert np.all(lab // plan["k_per_chunk"] == chunk)          # labels of a chunk stay inside the chunk's slice of the palette
+        assert core["palette"] == plan["k_per_chunk"] * (-(-n // plan["chunk_size"]))
+        assert len(core["shn_centroid_index"]) == core["palette"] * coeffs and len(core["shn_codebook"]) == 256
+    return ds
+
+
+@pytest.mark.parametrize("n,level,seed", [(20000, 2, 11), (3000, 8, 12), (1024, 0, 13), (300001, 5, 14)])
+def test_device_resident_core_is_numpys_bytes(gsx, n, level, seed):
+    w = _sog_writer()
+    data = datasets.sog_scene(n, seed)
+    np.random.seed(seed)
+    core = w.encode(data, level, device_resident=True)
+    _check_core_against_numpy(core, data, level)
+    assert core["bands"] == 3
+
+
+def test_device_resident_core_ties_duplicates_and_signed_zeros(gsx):
+    """the lexsort must be numpy's: long runs of ties on the primary and secondary keys, +-0.0 tie, duplicate points keep
+    their table order (stable) -- visible in the quaternion texture, whose rows differ between the duplicates"""
+    w = _sog_writer()
+    rng = np.random.default_rng(21)
+    n = 150001
+    data = datasets.sog_scene(n, 21)
+    for a, s in zip("xyz", (3, 2, 1.5)):
+        c = np.round(rng.standard_normal(n) * s).astype(np.float32) * np.float32(0.5)
+        c[rng.random(n) < 0.05] = np.float32(-0.0)
+        data[a] = c
+    core = w.encode(data, 2, device_resident=True)
+    _check_core_against_numpy(core, data, 2)
+
+
+def test_device_resident_core_equals_the_host_staged_core(gsx):
+    """3 000 splats: 9 000 scalars per codebook fit, no sub-sample drawn -> both cores fit the same data with the same
+    deterministic solver: every texture but the palette's (random initial centroids) must agree byte for byte"""
+    w = _sog_writer()
+    data = datasets.sog_scene(3000, 31)
+    np.random.seed(5)
+    a = w.encode(data, 8, device_resident=True)
+    np.random.seed(5)
+    b = w.encode(data, 8, device_resident=False)
+    for name in ("means_l", "means_u", "quats", "scales", "sh0"):
+        np.testing.assert_array_equal(a["textures"][name], b["textures"][name], err_msg=name)
+    np.testing.assert_array_equal(np.asarray(a["scale_codebook"], np.float32), np.asarray(b["scale_codebook"], np.float32))
+    np.testing.assert_array_equal(np.asarray(a["color_codebook"], np.float32), np.asarray(b["color_codebook"], np.float32))
+    assert a["bands"] == b["bands"] == 3 and a["palette"] == b["palette"]
+    assert [np.float32(v).tobytes() for v in a["mins"] + a["maxs"]] == [np.float32(v).tobytes() for v in b["mins"] + b["maxs"]]
+
+
+def test_device_resident_core_band_detection_and_odd_rows(gsx):
+    """sog.py:461-493: trailing all-zero coefficients downgrade the bands (a -0.0 counts as zero); a table widened by u1 colour
+    fields (251-byte rows: data_processor.py:262-274) is packed by one host pass and takes the same path"""
+    w = _sog_writer()
+    from oracle import kmeans as okm
+    n = 5000
+    data = datasets.sog_scene(n, 41)
+    for i in range(24, 45):
+        data["f_rest_%d" % i] = 0.0
+    data["f_rest_30"][::7] = np.float32(-0.0)
+    core = w.encode(data, 9, device_resident=True)
+    assert core["bands"] == 2 and len(core["shn_centroid_index"]) == core["palette"] * 24
+    _check_core_against_numpy(core, data, 9)
+    for i in range(9, 24):
+        data["f_rest_%d" % i] = 0.0
+    assert w.encode(data, 9, device_resident=True)["bands"] == 1
+    for i in range(9):
+        data["f_rest_%d" % i] = 0.0
+    core0 = w.encode(data, 9, device_resident=True)
+    assert core0["bands"] == 0 and "shN_labels" not in core0["textures"]
+    # no f_rest fields at all
+    d0 = datasets.sog_scene(n, 42, sh_degree=0)
+    c0 = w.encode(d0, 0, device_resident=True)
+    assert c0["bands"] == 0
+    _check_core_against_numpy(c0, d0, 0)
+    # odd row size
+    wide = np.zeros(n, dtype=np.dtype(datasets.sog_scene(8, 1).dtype.descr + [("red", "u1"), ("green", "u1"), ("blue", "u1")]))
+    src = datasets.sog_scene(n, 43)
+    for nm in src.dtype.names:
+        wide[nm] = src[nm]
+    assert wide.dtype.itemsize % 4 != 0
+    np.random.seed(3)
+    cw = w.encode(wide, 2, device_resident=True)
+    np.random.seed(3)
+    cs = w.encode(src, 2, device_resident=True)
+    for name in cs["textures"]:
+        np.testing.assert_array_equal(cw["textures"][name], cs["textures"][name], err_msg=name)
+
+
+def test_device_resident_core_declines_what_it_does_not_take(gsx):
+    w = _sog_writer()
+    sd = __import__("importlib").import_module("3dgsconverter_amd.formats.sog_device")
+    small = datasets.sog_scene(500, 1)
+    with pytest.raises(sd.NotEligible):
+        w.encode(small, 0, device_resident=True)
+    assert w.encode(small, 0)["n"] == 500                        # ... and the default falls back to the host-staged core
+    bad = datasets.sog_scene(4000, 2)
+    bad["y"][17] = np.nan
+    with pytest.raises(sd.NotEligible):
+        w.encode(bad, 0, device_resident=True)
+    f8 = datasets.sog_scene(4000, 3).astype([(nm, "f8" if nm == "opacity" else "f4") for nm in datasets.sog_scene(8, 1).dtype.names])
+    with pytest.raises(sd.NotEligible):
+        w.encode(f8, 0, device_resident=True)
+
+
+def test_device_resident_core_degenerate_axes_and_wide_ranges(gsx):
+    """a two-valued axis (every value is an extreme: more candidates than the list holds -> the reference's expression on the
+    host column), values spanning 24 orders of magnitude, a one-sided axis"""
+    w = _sog_writer()
+    rng = np.random.default_rng(51)
+    n = 120000
+    data = datasets.sog_scene(n, 51)
+    data["x"] = np.where(rng.random(n) < 0.5, np.float32(1.25), np.float32(-0.75)).astype(np.float32)
+    data["y"] = (rng.standard_normal(n) * np.exp(rng.uniform(-12, 12, n))).astype(np.float32)
+    data["z"] = (np.abs(rng.standard_normal(n)) + 2.0).astype(np.float32)
+    with np.errstate(all="ignore"):
+        core = w.encode(data, 4, device_resident=True)
+        _check_core_against_numpy(core, data, 4)
+    st = core["stats"]
+    assert st["uncertain_alpha"] <= 0.005 * n and st["uncertain_positions"] <= 0.2 * 3 * n, st

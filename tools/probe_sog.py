@@ -1,0 +1,61 @@
+"""GPU box: the SOG writer's numeric core on a device-resident table -- per-stage clock (PROBE_N splats, degree-3 table).
+    python tools/probe_sog.py            # PROBE_N=10000000 PROBE_LEVEL=2 PROBE_REPS=3"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def table(n, seed=0):
+    """62 x f4 rows like oracle.datasets.sog_scene, generated column by column in float32 (no float64 temporaries of n rows x 45)"""
+    names = (["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(45)]
+             + ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"])
+    a = np.zeros(n, dtype=[(nm, "f4") for nm in names])
+    rng = np.random.default_rng(seed)
+    for nm in names:
+        if nm in ("nx", "ny", "nz"):
+            continue
+        v = rng.standard_normal(n, dtype=np.float32)
+        if nm in "xyz":
+            v *= np.float32(3.0)
+        elif nm.startswith("f_rest"):
+            v *= np.float32(0.1)
+        elif nm.startswith("scale"):
+            v -= np.float32(4.0)
+        elif nm == "opacity":
+            v *= np.float32(2.0)
+        a[nm] = v
+    return a
+
+
+def main():
+    n = int(os.environ.get("PROBE_N", 10_000_000))
+    level = int(os.environ.get("PROBE_LEVEL", 2))
+    reps = int(os.environ.get("PROBE_REPS", 3))
+    w = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
+    t0 = time.perf_counter()
+    data = table(n)
+    print("table: %d rows x %d B in %.1f s" % (n, data.dtype.itemsize, time.perf_counter() - t0), flush=True)
+    out = {"n": n, "level": level, "row_bytes": data.dtype.itemsize, "runs_ms": [], "stage_ms": None}
+    np.random.seed(0)
+    core = w.encode(data, level, device_resident=True, profile=True)      # warm-up (first touches, code objects) + stage clock
+    core = w.encode(data, level, device_resident=True, profile=True)
+    out["stage_ms"] = core["stage_ms"]
+    out["stats"] = core["stats"]
+    for _ in range(reps):
+        t = time.perf_counter()
+        core = w.encode(data, level, device_resident=True)
+        out["runs_ms"].append(round((time.perf_counter() - t) * 1e3, 2))
+    out["best_ms"] = min(out["runs_ms"])
+    out["texels_bytes"] = int(sum(v.nbytes for v in core["textures"].values()))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
