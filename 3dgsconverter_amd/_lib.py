@@ -114,6 +114,8 @@ SIGNATURES = {
     "gsx_dev_copy": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
+    "gsx_dev_upload_staged": (_I, [_P, _P, _P, C.c_size_t]),
+    "gsx_dev_download_staged": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_gather_columns_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
     "gsx_host_compact_rows": (_I, [_P, _I64, _I64, _P, _P, _I64, C.POINTER(_I64)]),
@@ -171,7 +173,7 @@ SIGNATURES = {
     "gsx_sog_extremes_dev": (_I, [_P, _P, _I64, _P, _P, _I, _P, _P]),
     "gsx_sog_order_dev": (_I, [_P, _P, _I64, _P]),
     "gsx_sog_gather_dev": (_I, [_P, _P, C.POINTER(SogLayout), _P, _I64, _I, _P, _P, _P, _P, _P, _P]),
-    "gsx_sog_means_texels_dev": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "gsx_sog_means_texels_dev": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "gsx_sog_quats_texels_dev": (_I, [_P, _P, _I64, _I64, _P]),
     "gsx_sog_codes_texels_dev": (_I, [_P, _P, _I64, _I64, _P, _I, _P, _P, _P, _I64, _P]),
     "gsx_sog_labels_texels_dev": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),

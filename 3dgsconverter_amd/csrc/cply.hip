@@ -285,7 +285,7 @@ __device__ __forceinline__ unsigned pack_quat(float q0, float q1, float q2, floa
     float q[4] = {q0, q1, q2, q3};
     // np.linalg.norm(axis=-1): sqrt(add.reduce(q*q)) -- numpy adds the four squares left to right
     const float ss = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(q0, q0), __fmul_rn(q1, q1)), __fmul_rn(q2, q2)), __fmul_rn(q3, q3));
-    const float d = __fadd_rn(__fsqrt_rn(ss), 1e-10f);
+    const float d = __fadd_rn(__builtin_sqrtf(ss) /* correctly rounded; __fsqrt_rn is the native approximation */, 1e-10f);
     int largest = 0;
     float best = -1.0f;
 #pragma unroll

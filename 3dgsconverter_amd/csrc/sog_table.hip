@@ -217,6 +217,7 @@ __device__ __forceinline__ void list_append(bool flag, unsigned tag, float value
 
 struct SogMeansArgs {
     float mn[3], mx[3];
+    float v_mn[3], v_mx[3];   // the coordinate values whose transform IS mn / mx (numpy evaluated them): texels 0 and 65535, certain
 };
 // :279-312: texel i of means_l / means_u = (low / high byte of the u16 x, y, z, 255); padding texels 255
 __global__ __launch_bounds__(256) void sog_means_texels_kernel(const float *__restrict__ pos, int64_t n, int64_t texels, SogMeansArgs a,
@@ -234,6 +235,15 @@ __global__ __launch_bounds__(256) void sog_means_texels_kernel(const float *__re
             for (int c = 0; c < 3; ++c) {
                 v[c] = pos[(int64_t)c * n + i];
                 q[c] = sog_position_texel(v[c], a.mn[c], range[c], &ok[c]);
+                // (l - mn) / range is exactly 0 / exactly 1 for the values numpy's min / max came from; their bracket straddles
+                // the clip at 65535, which would put every copy of a repeated maximum on the list
+                if (range[c] > 0.0f && v[c] == a.v_mn[c]) {
+                    q[c] = 0u;
+                    ok[c] = true;
+                } else if (range[c] > 0.0f && v[c] == a.v_mx[c]) {
+                    q[c] = 65535u;
+                    ok[c] = true;
+                }
             }
         }
         if (i < texels) {
@@ -459,7 +469,7 @@ static int texel_args(gsx_ctx *c, int64_t n, int64_t texels, const char *who)
 }
 
 int gsx_sog_means_texels_dev(gsx_ctx *c, const float *pos_dev, int64_t n, int64_t texels, const float *log_min3, const float *log_max3,
-                             uint8_t *means_l_dev, uint8_t *means_u_dev, uint32_t *list_dev, int64_t cap, uint32_t *count_dev)
+                             const float *arg_min3, const float *arg_max3, uint8_t *means_l_dev, uint8_t *means_u_dev, uint32_t *list_dev, int64_t cap, uint32_t *count_dev)
 {
     if (!c || !pos_dev || !log_min3 || !log_max3 || !means_l_dev || !means_u_dev || !list_dev || !count_dev) GSX_FAIL("gsx_sog_means_texels_dev: null argument");
     if (cap < 0 || cap > 0xffffffffLL) GSX_FAIL("gsx_sog_means_texels_dev: bad list capacity");
@@ -469,6 +479,8 @@ int gsx_sog_means_texels_dev(gsx_ctx *c, const float *pos_dev, int64_t n, int64_
     for (int k = 0; k < 3; ++k) {
         a.mn[k] = log_min3[k];
         a.mx[k] = log_max3[k];
+        a.v_mn[k] = arg_min3 ? arg_min3[k] : __builtin_nanf("");   // a NaN equals nothing: no shortcut
+        a.v_mx[k] = arg_max3 ? arg_max3[k] : __builtin_nanf("");
     }
     GSX_HIP(hipMemsetAsync(count_dev, 0, 4, c->stream));
     hipLaunchKernelGGL(sog_means_texels_kernel, dim3(stream_blocks(c, texels)), dim3(256), 0, c->stream, pos_dev, n, texels, a,

@@ -29,6 +29,7 @@ statistics do not.  The host-staged writer (``sog_writer._encode_host``) keeps t
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import time
 
 import numpy as np
@@ -117,7 +118,8 @@ class _Stages:
 
     def mark(self, name):
         if self.on:
-            self.ctx.synchronize()
+            if self.on != "host":      # "host": the host thread's own clock, no extra synchronisation
+                self.ctx.synchronize()
             now = time.perf_counter()
             self.ms[name] = self.ms.get(name, 0.0) + (now - self.t) * 1e3
             self.t = now
@@ -142,8 +144,10 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         raise NotEligible("a palette chunk with k >= rows")
     width, height = texture_size(n)
     texels = width * height
+    t_enter = time.perf_counter()
     ctx = _lib.Context(device)
     st = _Stages(ctx, profile)
+    st.t = t_enter
     bufs = []
 
     def alloc(nbytes):
@@ -160,7 +164,8 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
     try:
         # ---- the table crosses PCIe once
         d_rows = alloc(rows.nbytes)
-        _lib.check(lib.gsx_dev_upload(ctx.handle, d_rows.ptr, rows.ctypes.data, rows.nbytes), "gsx_dev_upload")
+        st.mark("alloc_rows")
+        _lib.check(lib.gsx_dev_upload_staged(ctx.handle, d_rows.ptr, rows.ctypes.data, rows.nbytes), "gsx_dev_upload_staged")
         st.mark("upload")
         d_keys = alloc(12 * n)
         scan = _lib.SogScan()
@@ -182,15 +187,18 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         counts = np.zeros(6, np.int64)
         _lib.check(lib.gsx_sog_extremes_dev(ctx.handle, d_keys.ptr, n, lo_t.ctypes.data, hi_t.ctypes.data, EXTREME_CAP,
                                             cand.ctypes.data, counts.ctypes.data), "gsx_sog_extremes_dev")
-        mins, maxs = [], []
+        mins, maxs, arg_mn, arg_mx = [], [], [], []
         for a, name in enumerate("xyz"):
             if counts[2 * a] > EXTREME_CAP or counts[2 * a + 1] > EXTREME_CAP:
-                t = _log_transform(np.ascontiguousarray(data[name]))      # a degenerate axis: the reference's expression as is
-                mins.append(np.min(t))
-                maxs.append(np.max(t))
+                lo_c = hi_c = np.ascontiguousarray(data[name])       # a degenerate axis: the reference's expression on the column
             else:
-                mins.append(np.min(_log_transform(cand[2 * a, :counts[2 * a]])))
-                maxs.append(np.max(_log_transform(cand[2 * a + 1, :counts[2 * a + 1]])))
+                lo_c, hi_c = cand[2 * a, :counts[2 * a]], cand[2 * a + 1, :counts[2 * a + 1]]
+            t_lo, t_hi = _log_transform(lo_c), _log_transform(hi_c)
+            i_lo, i_hi = int(np.argmin(t_lo)), int(np.argmax(t_hi))
+            mins.append(t_lo[i_lo])                                  # == np.min / np.max of the whole transformed axis (:287-288)
+            maxs.append(t_hi[i_hi])
+            arg_mn.append(lo_c[i_lo])
+            arg_mx.append(hi_c[i_hi])
         out["mins"], out["maxs"] = mins, maxs
         st.mark("extremes")
 
@@ -209,9 +217,18 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         # ---- positions, rotations
         cap = n // 8 + 4096
         d_list, d_cnt = alloc(8 * cap), alloc(16)
-        tex = {nm: alloc(4 * texels) for nm in ("means_l", "means_u", "quats", "scales", "sh0")}
+        # the texel images are slices of ONE device buffer and come back as slices of ONE host array: a single bulk copy
+        tex_names = ["means_l", "means_u", "quats", "scales", "sh0"] + (["shN_labels"] if coeffs else [])
+        d_tex = alloc(4 * texels * len(tex_names))
+
+        class _Slice:
+            def __init__(self, i):
+                self.ptr = d_tex.ptr + 4 * texels * i
+        tex = {nm: _Slice(i) for i, nm in enumerate(tex_names)}
         mn3, mx3 = np.array(mins, np.float32), np.array(maxs, np.float32)
-        _lib.check(lib.gsx_sog_means_texels_dev(ctx.handle, d_pos.ptr, n, texels, mn3.ctypes.data, mx3.ctypes.data, tex["means_l"].ptr,
+        amn3, amx3 = np.array(arg_mn, np.float32), np.array(arg_mx, np.float32)
+        _lib.check(lib.gsx_sog_means_texels_dev(ctx.handle, d_pos.ptr, n, texels, mn3.ctypes.data, mx3.ctypes.data, amn3.ctypes.data,
+                                                amx3.ctypes.data, tex["means_l"].ptr,
                                                 tex["means_u"].ptr, d_list.ptr, cap, d_cnt.ptr), "gsx_sog_means_texels_dev")
         m_pos = int(d_cnt.download(np.uint32, 1)[0])
         if m_pos > cap:
@@ -250,6 +267,13 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         st.mark("codebooks_codes")
 
         # ---- SH palette (:496-552) as ONE batched Lloyd call, then the centroid codebook (:561) and its indices
+        # ---- SH palette (:496-552) as ONE batched Lloyd call on a worker thread (the C call releases the GIL): while its ~40 ms of
+        # kernels run, this thread brings the five finished images back through a second context (its own stream, the staging
+        # lanes' DMA engines) and evaluates numpy's log / exp for the listed texels
+        host_tex = np.empty((len(tex_names), texels, 4), np.uint8)
+        for i, nm in enumerate(tex_names):
+            out["textures"][nm] = host_tex[i]
+        worker, werr = None, []
         if coeffs:
             status_print(f"SOG Write Quality Level: {int(compression_level)} (0=Max, 9=Min)")
             status_print(f"SH Clustering: K={plan['target_k']}, Points={n}. Strategy: GPU (HIP gfx950)")
@@ -260,12 +284,46 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             d_init.upload(init_rows)
             _lib.check(lib.gsx_gather_rows_dev(ctx.handle, d_sh.ptr, coeffs, d_init.ptr, len(init_rows), d_cent.ptr), "gsx_gather_rows_dev")
             _lib.check(lib.gsx_dev_memset(ctx.handle, d_lab.ptr, 0, 4 * n), "gsx_dev_memset")
-            _lib.check(lib.gsx_kmeans_lloyd_batch_dev(ctx.handle, d_sh.ptr, off.ctypes.data, nprob, coeffs, k, int(max_iter), d_cent.ptr, d_lab.ptr),
-                       "gsx_kmeans_lloyd_batch_dev")
-            st.mark("palette")
+            ctx.synchronize()          # the five images are complete in HBM
+
+            def run_palette():
+                try:
+                    _lib.check(lib.gsx_kmeans_lloyd_batch_dev(ctx.handle, d_sh.ptr, off.ctypes.data, nprob, coeffs, k, int(max_iter), d_cent.ptr,
+                                                              d_lab.ptr), "gsx_kmeans_lloyd_batch_dev")
+                except BaseException as e:     # re-raised on the calling thread
+                    werr.append(e)
+            worker = threading.Thread(target=run_palette, name="gsx-sog-palette")
+            worker.start()
+        try:
+            ctx2 = _lib.Context(device, own_stream=True) if worker else ctx
+            try:
+                _lib.check(lib.gsx_dev_download_staged(ctx2.handle, host_tex.ctypes.data, d_tex.ptr, 5 * 4 * texels), "gsx_dev_download_staged")
+            finally:
+                if ctx2 is not ctx:
+                    ctx2.close()
+            with np.errstate(all="ignore"):
+                if len(pos_list):
+                    # one fancy assignment for the three channels: the tag (texel * 4 + channel) IS the flat index into the RGBA array
+                    tag, ch = pos_list[:, 0].astype(np.int64), (pos_list[:, 0] & 3).astype(np.int64)
+                    v = pos_list[:, 1].copy().view(np.float32)
+                    mn_c, mx_c = np.array(mins, np.float32)[ch], np.array(maxs, np.float32)[ch]
+                    t = (_log_transform(v) - mn_c) / (mx_c - mn_c)                                  # :293 per element, float32
+                    u = np.clip(t * 65535, 0, 65535).astype(np.uint16)                              # :294-295
+                    out["textures"]["means_l"].reshape(-1)[tag] = (u & 0xff).astype(np.uint8)
+                    out["textures"]["means_u"].reshape(-1)[tag] = (u >> 8).astype(np.uint8)
+                if len(al_list):
+                    ti = (al_list[:, 0] >> 2).astype(np.int64)
+                    o = al_list[:, 1].copy().view(np.float32)
+                    out["textures"]["sh0"][ti, 3] = np.clip(1.0 / (1.0 + np.exp(-o)) * 255, 0, 255).astype(np.uint8)   # :457-459
+        finally:
+            if worker:
+                worker.join()
+        if werr:
+            raise werr[0]
+        st.mark("palette+download+host_patch" if coeffs else "download+host_patch")
+        if coeffs:
             palette = nprob * k
             flat_n = palette * coeffs
-            tex["shN_labels"] = alloc(4 * texels)
             _lib.check(lib.gsx_sog_labels_texels_dev(ctx.handle, d_lab.ptr, n, texels, plan["chunk_size"], k, tex["shN_labels"].ptr),
                        "gsx_sog_labels_texels_dev")
             status_print("Clustering SH Centroids into Codebook...")
@@ -275,32 +333,15 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             out["palette"] = palette
             out["shn_codebook"] = d_cb2.download(np.float32, 256).astype(np.float64)
             out["shn_centroid_index"] = d_cidx.download(np.uint8, flat_n)
-            st.mark("centroid_codebook")
-
-        # ---- texels back; numpy's own log / exp for the listed ones
-        for nm, b in tex.items():
-            arr = np.empty((texels, 4), np.uint8)
-            _lib.check(lib.gsx_dev_download(ctx.handle, arr.ctypes.data, b.ptr, arr.nbytes), "gsx_dev_download")
-            out["textures"][nm] = arr
-        st.mark("download")
-        with np.errstate(all="ignore"):
-            if len(pos_list):
-                ti, ch = (pos_list[:, 0] >> 2).astype(np.int64), (pos_list[:, 0] & 3).astype(np.int64)
-                v = pos_list[:, 1].copy().view(np.float32)
-                lo, hi = out["textures"]["means_l"], out["textures"]["means_u"]
-                for c in range(3):
-                    sel = ch == c
-                    if np.any(sel):
-                        t = (_log_transform(v[sel]) - mins[c]) / (maxs[c] - mins[c])
-                        u = np.clip(t * 65535, 0, 65535).astype(np.uint16)                      # :293-295
-                        lo[ti[sel], c] = (u & 0xff).astype(np.uint8)
-                        hi[ti[sel], c] = (u >> 8).astype(np.uint8)
-            if len(al_list):
-                ti = (al_list[:, 0] >> 2).astype(np.int64)
-                o = al_list[:, 1].copy().view(np.float32)
-                out["textures"]["sh0"][ti, 3] = np.clip(1.0 / (1.0 + np.exp(-o)) * 255, 0, 255).astype(np.uint8)   # :457-459
+            _lib.check(lib.gsx_dev_download_staged(ctx.handle, host_tex[5].ctypes.data, tex["shN_labels"].ptr, 4 * texels), "gsx_dev_download_staged")
+            st.mark("centroid_codebook+labels")
+        if profile:
+            out["_lists"] = (pos_list, al_list)
         out["stats"] = {"uncertain_positions": int(len(pos_list)), "uncertain_alpha": int(len(al_list)), "n": n}
-        st.mark("host_patch")
+        for b_ in list(bufs):
+            b_.free()
+        bufs.clear()
+        st.mark("free")
         if profile:
             out["stage_ms"] = {k_: round(v_, 3) for k_, v_ in st.ms.items()}
         return out

@@ -701,7 +701,13 @@ def main_single(args):
             rot = np.ascontiguousarray(np.column_stack([tab["rot_%d" % i] for i in range(4)]))
             xyz2 = np.ascontiguousarray(np.column_stack([tab["x"], tab["y"], tab["z"]]))
             opa = np.ascontiguousarray(tab["opacity"])
-            t_order, order = best_of(lambda: L.lexsort3(tab["z"], tab["y"], tab["x"]))
+            def host_lexsort():   # as formats/sog_writer.py:_encode_host calls it (round 6: the keys gathered in one threaded pass)
+                zyx = L.host_gather_columns(tab, ["z", "y", "x"])
+                return L.lexsort3(zyx[0], zyx[1], zyx[2])
+            t_order, order = best_of(host_lexsort)
+            sogw = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
+            sogw.encode(tab, 2, device_resident=True)
+            resident = sogw.encode(tab, 2, device_resident=True, profile=True)["stage_ms"]
             t_pos, _ = best_of(lambda: [L.sog_positions(tab[a]) for a in "xyz"])
             t_quat, _ = best_of(lambda: L.sog_quats(rot))
             t_alpha, _ = best_of(lambda: L.sog_alpha(opa))
@@ -722,6 +728,9 @@ def main_single(args):
                                         "sog_alpha": round(t_alpha, 2), "compressed_ply_encode": round(t_cply, 2), "row_filters_bbox_alpha": round(t_rows, 2)},
                    "value": round(m / ((t_order + t_pos + t_quat + t_alpha) * 1e-3) / 1e6, 2), "value_unit": "Msplats/s through the SOG numeric core (sum of its four stages)",
                    "survivors_after_row_filters": kept[2],
+                   "sog_core_resident_stage_ms": resident,
+                   "sog_core_resident_note": "the same table through the device-resident core (formats/sog_device.py; configs.sog_write_core_10m at full "
+                                             "size): `order` is the lexsort, `means_quats` the positions (all three axes) + quaternions, no per-stage PCIe",
                    "roofline": {"bound": "pcie", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
                                 "note": "host-to-host calls: every stage uploads its columns and downloads its texels, so each is bound by PCIe "
                                         "(4-28 B per splat each way at ~56 GB/s) and by numpy's part (extrema, flagged texels), not by HBM"}}
@@ -752,6 +761,71 @@ def main_single(args):
                                        "order_identical_to_gpu": bool(np.array_equal(o, order))}
             return out
 
+        def sog_write_core():
+            # the SOG writer's numeric core on a DEVICE-RESIDENT table (formats/sog_device.py, csrc/sog_table.hip):
+            # 10M x 62-field host table in -> every texel array of SogFormat.write out (sog.py:249-600; WebP / zip excluded).  The
+            # table crosses PCIe once, texels come back; K-Means = configs.config4's batched palette, inside the clock here.
+            sogw = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
+            m = args.n
+            r = np.random.default_rng(0)
+            names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + ["f_rest_%d" % i for i in range(45)] + \
+                    ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+            tab = np.zeros(m, dtype=[(nm, "f4") for nm in names])
+            for nm in names:
+                if nm[0] == "n":
+                    continue
+                v = r.standard_normal(m, dtype=np.float32)
+                if nm in "xyz":
+                    v *= np.float32(3.0)
+                elif nm.startswith("f_rest"):
+                    v *= np.float32(0.1)
+                elif nm.startswith("scale"):
+                    v -= np.float32(4.0)
+                elif nm == "opacity":
+                    v *= np.float32(2.0)
+                tab[nm] = v
+            level = 2
+            np.random.seed(0)
+            sogw.encode(tab, level, device_resident=True)                       # warm-up: code objects, pinned staging pool
+            prof = sogw.encode(tab, level, device_resident=True, profile=True)   # stage clock (a synchronisation after every stage)
+            runs = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                core = sogw.encode(tab, level, device_resident=True)
+                runs.append((time.perf_counter() - t0) * 1e3)
+            runs.sort()
+            med = runs[len(runs) // 2]
+            tex_bytes = int(sum(v.nbytes for v in core["textures"].values()))
+            pcie = tab.nbytes + tex_bytes
+            res = {"workload": "%d x %d-byte host rows (62 f4 fields, degree-3 SH) -> all texel arrays of the SOG bundle (means_l/u, quats, scales, "
+                               "sh0, shN labels + centroid indices + 3 codebooks), compression_level %d (64 x K=1024 palette, 10 Lloyd iterations); "
+                               "WebP / zip excluded" % (m, tab.dtype.itemsize, level),
+                   "value": round(m / (med * 1e-3) / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(med, 2), "ms_min": round(runs[0], 2),
+                   "all_runs_ms": [round(v, 2) for v in runs], "steps": len(runs), "stage_ms": prof["stage_ms"],
+                   "uncertain_texels": core["stats"],
+                   "roofline": {"bound": "pcie", "achieved": round(pcie / (med * 1e-3) / 1e9, 2), "unit": "GB/s", "peak": 56.0,
+                                "frac": round(pcie / (med * 1e-3) / 1e9 / 56.0, 4), "traffic": None, "algorithmic_bytes": int(pcie),
+                                "note": "bytes over PCIe (the table up once, texels down) / the call; peak = the pageable-copy rate measured on these "
+                                        "boxes when the host pages sit on the GPU's NUMA node (configs.host_to_host); the upload alone is %.0f %% of the "
+                                        "call, the palette K-Means (configs.config4) most of the rest" % (100.0 * prof["stage_ms"].get("upload", 0.0) / max(sum(prof["stage_ms"].values()), 1e-9))}}
+            if want_cpu:   # cpu_baseline leg: the reference's own statements minus its K-Means calls, on a bounded subsample
+                from oracle import sog as osog
+                sub_n = 2_000_000
+                sub = tab[:sub_n].copy()
+                np.random.seed(1)
+                gsub = sogw.encode(sub, level, device_resident=True)
+                t0 = time.perf_counter()
+                ref = osog.write_core_without_kmeans(sub, gsub["scale_codebook"], gsub["color_codebook"])
+                cdt = time.perf_counter() - t0
+                same = all(np.array_equal(ref[k_], gsub["textures"][k_]) for k_ in ("means_l", "means_u", "quats", "scales", "sh0"))
+                res["cpu_baseline"] = {"value": round(sub_n / cdt / 1e6, 3), "unit": "Msplats/s", "cores": 1, "kind": "port",
+                                       "sample": "the first %d rows of the same table, once (%.1f s): every numpy statement of SogFormat.write between the "
+                                                 "table and its texel arrays (sog.py:264-265,279-386,391,408-459,499-503) as the reference runs them, single-threaded, "
+                                                 "with the two scalar codebooks handed over -- its K-Means fits (sklearn: ~2.6 s per palette chunk, "
+                                                 "configs.config4) are NOT in this number" % (sub_n, cdt),
+                                       "textures_identical_to_gpu": bool(same)}
+            return res
+
         attempt("config1", config1)
         attempt("config1_brute", config1_brute)
         attempt("config3_one_gpu", config3_one_gpu)
@@ -763,6 +837,7 @@ def main_single(args):
         attempt("blobs_10m_k25", blobs_k25)
         attempt("dropin_e2e_10m", dropin_e2e)
         attempt("writers_2m", writers_2m)
+        attempt("sog_write_core_10m", sog_write_core)
         out["configs"] = configs
         # SURVEY.md 8(d) names two numbers for the metric; both at the top level, unambiguously: `value` (= value_resident) is
         # the whole step with the rows already in HBM -- the harness's definition --, value_host_to_host the call a user of

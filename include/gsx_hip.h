@@ -126,6 +126,11 @@ int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 int gsx_dev_copy(gsx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* device to device, asynchronous */
 int gsx_dev_upload_async(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);  /* enqueue only */
 int gsx_dev_memset(gsx_ctx *ctx, void *dst_dev, int value, size_t bytes);                    /* enqueue only */
+/* bulk copies of PAGEABLE host memory (a numpy array) through pinned staging buffers, threaded: a few lanes split the transfer,
+ * each fills / drains one pinned 8 MiB buffer while the DMA of its other one is in flight (csrc/host_rows.hip).  Synchronous;
+ * wait for the context's stream first.  What the writers move: the 2.48 GB splat table up, 240 MB of texels down. */
+int gsx_dev_upload_staged(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gsx_dev_download_staged(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- Host-side row operations around every filter -- */
 /*
@@ -507,13 +512,17 @@ int gsx_sog_gather_dev(gsx_ctx *ctx, const void *rows_dev, const gsx_sog_layout 
  * the bits of the float32 input value) for the values whose float32 log / exp bracket straddles a rounding boundary -- the
  * caller evaluates numpy's own expression for those (see gsx_sog_positions) and patches the texel; *count_dev (uint32,
  * zeroed by the call) keeps counting past cap.
- *   means:  sog.py:279-312 -> means_l (low bytes of the u16 x, y, z, 255) and means_u (high bytes, 255); padding 255
+ *   means:  sog.py:279-312 -> means_l (low bytes of the u16 x, y, z, 255) and means_u (high bytes, 255); padding 255.
+ *           log_min3 / log_max3 = numpy's np.min / np.max of the transformed axes (gsx_sog_extremes_dev), arg_min3 / arg_max3
+ *           = a coordinate value per axis whose transform numpy evaluated to exactly that minimum / maximum (texels 0 / 65535
+ *           for every copy of it without consulting the bracket)
  *   quats:  sog.py:315-386 -> (c0, c1, c2, 252 + argmax); padding 255
  *   codes:  sog.py:408-431 / :446-459 -> (codebook index of the three columns, 255 or -- opacity_dev given -- the sigmoid of
  *           the opacity as a byte); padding 0.  cols3_dev = f32[3][n], codebook_dev = kcb <= 256 ascending float32
  *   labels: sog.py:546-552,:600-606 -> palette label = labels_dev[i] + (i / chunk_rows) * k as (low byte, high byte, 0, 255) */
 int gsx_sog_means_texels_dev(gsx_ctx *ctx, const float *pos_dev, int64_t n, int64_t texels, const float *log_min3,
-                             const float *log_max3, uint8_t *means_l_dev, uint8_t *means_u_dev, uint32_t *list_dev,
+                             const float *log_max3, const float *arg_min3 /* nullable */, const float *arg_max3 /* nullable */,
+                             uint8_t *means_l_dev, uint8_t *means_u_dev, uint32_t *list_dev,
                              int64_t cap, uint32_t *count_dev);
 int gsx_sog_quats_texels_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, int64_t texels, uint8_t *out_dev);
 int gsx_sog_codes_texels_dev(gsx_ctx *ctx, const float *cols3_dev, int64_t n, int64_t texels, const float *codebook_dev, int kcb,

@@ -55,3 +55,51 @@ def opacity_u8(data_s):
     """sog.py:457-459"""
     op_sig = 1.0 / (1.0 + np.exp(-data_s["opacity"]))
     return np.clip(op_sig * 255, 0, 255).astype(np.uint8)
+
+
+def write_core_without_kmeans(data, scale_codebook, color_codebook):
+    """Every statement of SogFormat.write between the table and its texel arrays EXCEPT the K-Means fits (sog.py:264-265,
+    279-312, 315-386, 391, 408-431, 434, 446-459, 499-503), with the two scalar codebooks given: what the reference's single
+    numpy thread does around its clustering calls.  -> dict of (texels, 4) uint8 images + the (N, 45) SH matrix + mins / maxs.
+    bench.py times it as the CPU baseline of configs.sog_write_core_10m and compares its images with the device's."""
+    N = len(data)
+    width = int(np.ceil(np.sqrt(N) / 4) * 4)
+    height = int(np.ceil(N / width / 4) * 4)
+    indices = np.lexsort((data["z"], data["y"], data["x"]))              # :264
+    data_s = data[indices]                                               # :265
+    lo, hi, mins, maxs = positions(data_s)                               # :279-298
+    means_l = np.full((height * width, 4), 255, dtype=np.uint8)          # :300-312
+    means_u = np.full((height * width, 4), 255, dtype=np.uint8)
+    means_l[:N, :3] = lo
+    means_u[:N, :3] = hi
+    quats_img = np.full((height * width, 4), 255, dtype=np.uint8)        # :340
+    quats_img[:N] = quats(data_s)                                        # :315-386
+
+    def quantize_to_codebook(vals, cb):                                  # :408-419
+        if len(cb) == 1:
+            return np.zeros_like(vals, dtype=np.uint8)
+        idx = np.searchsorted(cb, vals)
+        idx = np.clip(idx, 0, len(cb) - 1)
+        left = np.maximum(idx - 1, 0)
+        d_idx = np.abs(vals - cb[idx])
+        d_left = np.abs(vals - cb[left])
+        use_left = d_left < d_idx
+        idx[use_left] = left[use_left]
+        return idx.astype(np.uint8)
+    s_data = np.concatenate([data_s["scale_0"], data_s["scale_1"], data_s["scale_2"]])      # :391 (what the 50 000-sample is drawn from)
+    scb = np.array(scale_codebook)
+    scales_img = np.zeros((height * width, 4), dtype=np.uint8)           # :421-431
+    for c in range(3):
+        scales_img[:N, c] = quantize_to_codebook(data_s["scale_%d" % c], scb)
+    scales_img[:N, 3] = 255
+    dc_data = np.concatenate([data_s["f_dc_0"], data_s["f_dc_1"], data_s["f_dc_2"]])        # :434
+    ccb = np.array(color_codebook)
+    sh0_img = np.zeros((height * width, 4), dtype=np.uint8)              # :446-459
+    for c in range(3):
+        sh0_img[:N, c] = quantize_to_codebook(data_s["f_dc_%d" % c], ccb)
+    sh0_img[:N, 3] = opacity_u8(data_s)
+    sh = None
+    if "f_rest_44" in data.dtype.names:
+        sh = np.column_stack([data_s["f_rest_%d" % i] for i in range(45)]).astype(np.float32)   # :499-503
+    return {"means_l": means_l, "means_u": means_u, "quats": quats_img, "scales": scales_img, "sh0": sh0_img, "sh": sh,
+            "mins": mins, "maxs": maxs, "n_concat": len(s_data) + len(dc_data)}

@@ -212,7 +212,7 @@ def _check_core_against_numpy(core, data, level):
     return ds
 
 
-@pytest.mark.parametrize("n,level,seed", [(20000, 2, 11), (3000, 8, 12), (1024, 0, 13), (300001, 5, 14)])
+@pytest.mark.parametrize("n,level,seed", [(20000, 2, 11), (3000, 8, 12), (1100, 0, 13), (300001, 5, 14)])
 def test_device_resident_core_is_numpys_bytes(gsx, n, level, seed):
     w = _sog_writer()
     data = datasets.sog_scene(n, seed)

@@ -42,6 +42,30 @@ def main():
     t0 = time.perf_counter()
     data = table(n)
     print("table: %d rows x %d B in %.1f s" % (n, data.dtype.itemsize, time.perf_counter() - t0), flush=True)
+    lib = importlib.import_module("3dgsconverter_amd._lib")
+    ctx = lib.Context(0)
+    rates = {}
+    for label, nbytes in (("120MB", 120_000_000), ("table", data.nbytes)):
+        src = np.frombuffer(memoryview(data).cast("B")[:nbytes], dtype=np.uint8) if nbytes <= data.nbytes else None
+        d = ctx.alloc(nbytes)
+        for kind, fn in (("plain", ctx.lib.gsx_dev_upload), ("staged", ctx.lib.gsx_dev_upload_staged)):
+            best = 1e9
+            for _ in range(3):
+                t = time.perf_counter()
+                lib.check(fn(ctx.handle, d.ptr, src.ctypes.data, nbytes), "upload")
+                best = min(best, time.perf_counter() - t)
+            rates["up_%s_%s_GBs" % (label, kind)] = round(nbytes / best / 1e9, 1)
+        for kind, fn in (("plain", ctx.lib.gsx_dev_download), ("staged", ctx.lib.gsx_dev_download_staged)):
+            best = 1e9
+            for _ in range(3):
+                dst = np.empty(min(nbytes, 240_000_000), np.uint8)       # fresh pages every time, like the writer's texel arrays
+                t = time.perf_counter()
+                lib.check(fn(ctx.handle, dst.ctypes.data, d.ptr, dst.nbytes), "download")
+                best = min(best, time.perf_counter() - t)
+            rates["down_%s_%s_GBs" % (label, kind)] = round(dst.nbytes / best / 1e9, 1)
+        d.free()
+    ctx.close()
+    print(json.dumps(rates), flush=True)
     out = {"n": n, "level": level, "row_bytes": data.dtype.itemsize, "runs_ms": [], "stage_ms": None}
     np.random.seed(0)
     core = w.encode(data, level, device_resident=True, profile=True)      # warm-up (first touches, code objects) + stage clock
@@ -52,6 +76,10 @@ def main():
         t = time.perf_counter()
         core = w.encode(data, level, device_resident=True)
         out["runs_ms"].append(round((time.perf_counter() - t) * 1e3, 2))
+    t = time.perf_counter()
+    core = w.encode(data, level, device_resident=True, profile="host")
+    out["host_view_total_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+    out["host_view_ms"] = core["stage_ms"]
     out["best_ms"] = min(out["runs_ms"])
     out["texels_bytes"] = int(sum(v.nbytes for v in core["textures"].values()))
     print(json.dumps(out))
