@@ -29,6 +29,7 @@ are gsx_comm_* calls like the data path's collectives.  Prints ONE JSON line (ra
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -222,6 +223,94 @@ def kernel_groups(ctx, L, step, slots, steps):
     out = {name: round(ctx.timing(slot)[1] / steps, 4) for name, slot in slots.items()}
     ctx.set_timing(False)
     return out
+
+
+class ClockSampler:
+    """the GPU's shader clock while a timed loop runs: the active level of pp_dpm_sclk (amdgpu sysfs; readable by an ordinary
+    user) every 50 ms from a thread, `rocm-smi --showclocks` once as the fall-back.  Median / min / max in MHz, or None."""
+
+    def __init__(self):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self):
+        best = None
+        for p in self.paths:
+            try:
+                with open(p) as f:
+                    for ln in f:
+                        if "*" in ln:
+                            mhz = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+                            best = mhz if best is None else max(best, mhz)   # several cards visible: the busy one runs fastest
+            except (OSError, ValueError, IndexError):
+                pass
+        return best
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+                time.sleep(0.05)
+        if self.paths:
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        if self.samples:
+            v = sorted(self.samples)
+            return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), "source": "pp_dpm_sclk"}
+        try:
+            import re
+            import subprocess
+            txt = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+            m = [int(x) for x in re.findall(r"sclk clock level:.*?\((\d+)Mhz\)", txt)]
+            if m:
+                return {"sclk_mhz_median": max(m), "samples": 1, "source": "rocm-smi --showclocks, once after the loop"}
+        except Exception:   # noqa: BLE001
+            pass
+        return None
+
+
+def run_sustained(L, ctx, xyz_host, k, sigma, algo, min_seconds=3.2, window=100):
+    """the headline step back to back for >= 3 s (>= 1500 steps at ~2.1 ms) -- long enough for clocks and
+    thermals to settle and for a 5 s utilisation sampler to land inside it -- in windows of 100 steps (one synchronisation per
+    window: ~10 us per 0.2 s)."""
+    b = SorBench(L, ctx, xyz_host, k, sigma, algo)
+    try:
+        for _ in range(5):
+            b.step()
+        ctx.synchronize()
+        wins = []
+        with ClockSampler() as clk:
+            t_all = time.perf_counter()
+            while (time.perf_counter() - t_all) < min_seconds or len(wins) < 15:
+                t0 = time.perf_counter()
+                for _ in range(window):
+                    b.step()
+                ctx.synchronize()
+                wins.append((time.perf_counter() - t0) / window * 1e3)
+            total = time.perf_counter() - t_all
+        mask, stats = b.results()
+        n = b.n
+        steps = len(wins) * window
+        return {"workload": "the headline step (%d splats, k=%d) back to back, rows resident in HBM" % (n, k), "steps": steps,
+                "seconds": round(total, 3), "ms_per_step": round(total / steps * 1e3, 4), "value": round(n * steps / total / 1e6, 2),
+                "unit": "Msplats/s", "window_steps": window, "window_ms_min": round(min(wins), 4), "window_ms_max": round(max(wins), 4),
+                "window_ms_first": round(wins[0], 4), "window_ms_last": round(wins[-1], 4), "clock": clk.summary(),
+                "survivors": int(mask.sum()), "threshold": float(stats[2])}
+    finally:
+        b.free()
 
 
 def cpu_sor(xyz_host, k, sigma, gpu_mask):
@@ -528,6 +617,12 @@ def main_single(args):
         return main_slab_one_rank(args, gsx, L, ctx)
 
     xyz = synth_uniform(args.n, args.extent, 0)
+    sustained = None
+    if not args.no_secondary:   # FIRST: a utilisation sampler that looks at the first seconds of this process sees the GPU busy
+        try:
+            sustained = run_sustained(L, ctx, xyz, args.k, args.sigma, args.algo)
+        except Exception as e:   # noqa: BLE001
+            sustained = {"error": repr(e)}
     head = run_sor(L, ctx, xyz, args.k, args.sigma, args.steps, args.warmup, algo=args.algo, groups=True, cpu=want_cpu)
     roof = sor_roofline(args.n, args.k, head["knn_kernel_ms"], args.algo)
     out = {
@@ -826,6 +921,10 @@ def main_single(args):
                                        "textures_identical_to_gpu": bool(same)}
             return res
 
+        if sustained is not None:
+            if "ms_per_step" in sustained:
+                sustained["vs_timed_region"] = round(sustained["ms_per_step"] / head["ms_per_step"], 4)
+            configs["headline_sustained"] = sustained
         attempt("config1", config1)
         attempt("config1_brute", config1_brute)
         attempt("config3_one_gpu", config3_one_gpu)
@@ -881,6 +980,41 @@ def main_slab_one_rank(args, gsx, L, ctx):
     os.write(args.json_fd, (json.dumps(out) + "\n").encode())
 
 
+def _golden_files():
+    out = {}
+    for name in ("large_cases.json", "cases.json"):
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+                out[name] = json.load(f)
+        except OSError:
+            out[name] = {}
+    return out
+
+
+def golden_sor(n_total, extent, k, sigma):
+    """the committed hash of a run of the REFERENCE on the uniform seed-0 cloud of this size (tests/golden/*.json, generated by
+    oracle/make_golden*.py against /root/reference), or None"""
+    files = _golden_files()
+    cands = [(nm, c) for nm, c in files["large_cases.json"].items() if isinstance(c, dict)]
+    cands += [(nm, c) for nm, c in files["cases.json"].get("sor", {}).items()]
+    for nm, c in cands:
+        ds = c.get("dataset", {})
+        if (ds.get("kind") == "uniform" and ds.get("seed") == 0 and ds.get("n") == n_total and float(ds.get("extent", -1)) == float(extent)
+                and c.get("k", c.get("k_used")) == k and float(c.get("sigma", c.get("sigma_used", -1))) == float(sigma) and "mask_sha" in c):
+            return {"mask_sha": c["mask_sha"], "survivors": c["survivors"], "threshold_hex": c["threshold_hex"], "source": "tests/golden: " + nm}
+    return None
+
+
+def golden_chain(n_total, extent, sensitivity, k, sigma):
+    for nm, c in _golden_files()["large_cases.json"].items():
+        ds = c.get("dataset", {}) if isinstance(c, dict) else {}
+        if ("final_mask_sha" in c and ds.get("kind") == "uniform" and ds.get("seed") == 0 and ds.get("n") == n_total
+                and float(ds.get("extent", -1)) == float(extent) and float(c.get("sensitivity", -1)) == float(sensitivity)
+                and c.get("k") == k and float(c.get("sigma", -1)) == float(sigma)):
+            return dict(c, source="tests/golden: " + nm)
+    return None
+
+
 # --------------------------------------------------------------------------------------------------- N > 1: one process per GPU
 def main_multi(args):
     """`python bench.py --gpus N` run plainly becomes the launcher of its own N ranks (3dgsconverter_amd/launch.py); under
@@ -925,10 +1059,11 @@ def main_multi(args):
     watchdog.stage("communicator up (%s)" % comm.transport)
     exchange = {"path": "replicated (requested)" if args.exchange == "replicated" else "slab"}
 
-    def run(n, extent, steps, warmup, k=None):
-        """Time `steps` SOR steps on a fresh n-splat shard; returns a dict of raw measurements."""
+    def run(n, extent, steps, warmup, k=None, shard=None):
+        """Time `steps` SOR steps on a fresh n-splat shard (shard: this rank's rows of a GLOBAL cloud; None: a cloud of its own,
+        seed = rank); returns a dict of raw measurements."""
         k = args.k if k is None else k
-        rows = ctx.alloc(12 * n + 16).upload(synth_uniform(n, extent, rank))
+        rows = ctx.alloc(12 * n + 16).upload(synth_uniform(n, extent, rank) if shard is None else np.ascontiguousarray(shard, dtype=np.float32))
         exchange.pop("certified", None)
 
         def step():
@@ -1006,7 +1141,27 @@ def main_multi(args):
             phases["note"] = ("HIP events around each phase on every rank's stream, a separate pass of %d steps, MAX over the ranks; "
                               "an exchange interval includes the wait for the slowest peer to arrive" % side)
         rows.free()
-        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "survivors": int(mask.sum()), "threshold": float(stats[2]), "phases": phases}
+        return {"dt": dt, "knn_ms": ms_knn / max(n_knn, 1), "survivors": int(mask.sum()), "threshold": float(stats[2]), "phases": phases,
+                "mask": mask, "stats": stats}
+
+    def gather_mask(mask_local, sizes):
+        """every rank's survivor mask (u8 per splat) on every rank, in index order: one all-gather of padded blocks"""
+        cap = max(max(sizes), 1)
+        sb, rb = be.buf("par_mask_s", cap), be.buf("par_mask_r", cap * world)
+        padded = np.zeros(cap, np.uint8)
+        padded[:len(mask_local)] = mask_local
+        be.from_host(sb, padded)
+        comm.all_gather(sb, rb, cap)
+        allm = be.to_host(rb, np.uint8, cap * world).reshape(world, cap)
+        return np.concatenate([allm[r, :sizes[r]] for r in range(world)]).astype(bool)
+
+    def global_shard(n_total, extent):
+        """this rank's index range of the GLOBAL seed-0 cloud SURVEY.md 8(c) defines (the cloud the reference-run hashes of
+        tests/golden/ were computed on): every rank generates the whole cloud (~1 s at 50M) and keeps its rows"""
+        sizes = [(r + 1) * n_total // world - r * n_total // world for r in range(world)]
+        lo = rank * n_total // world
+        full = synth_uniform(n_total, extent, 0)
+        return np.ascontiguousarray(full[lo:lo + sizes[rank]]), sizes
 
     try:
         main_run = run(args.n, args.extent, args.steps, args.warmup)
@@ -1016,23 +1171,102 @@ def main_multi(args):
             # BASELINE.json configs[3]: 50M splats, SOR k=32, sharded by index across the GPUs of the job (the 8-GPU case; at
             # other N the same 50M are split N ways).  Reported next to the headline, never instead of it.
             try:
-                n3 = max(8192, (args.n3 // world) // 4 * 4)
+                n_tot3, k3 = int(args.n3), int(args.k3)
                 s3, w3 = max(3, min(args.steps, 10)), 2
-                r3 = run(n3, 10.0, s3, w3, k=32)
-                config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, seed=rank) over %d GPU(s), SOR k=32 "
-                                       "sigma=%g" % (n3 * world, world, args.sigma),
-                           "value": round(n3 * world * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
+                shard3, sizes3 = global_shard(n_tot3, 10.0)
+                r3 = run(sizes3[rank], 10.0, s3, w3, k=k3, shard=shard3)
+                del shard3
+                full3 = gather_mask(r3["mask"].view(np.uint8), sizes3)
+                gold3 = golden_sor(n_tot3, 10.0, k3, args.sigma)
+                sha3 = hashlib.sha256(np.packbits(full3)).hexdigest()[:16]
+                config3 = {"workload": "BASELINE.json configs[3]: %d uniform-random splats (L=10, the GLOBAL seed-0 cloud, sharded by index) over "
+                                       "%d GPU(s), SOR k=%d sigma=%g" % (n_tot3, world, k3, args.sigma),
+                           "value": round(n_tot3 * s3 / r3["dt"] / 1e6, 2), "unit": "Msplats/s",
                            "ms_per_step": round(r3["dt"] / s3 * 1e3, 4), "steps": s3, "exchange": exchange["path"],
-                           "scaling": "strong", "n_gpus": world, "one_gpu_ms_per_step": ONE_GPU_CONFIG3_MS,
-                           "speedup_vs_one_gpu": round(ONE_GPU_CONFIG3_MS / (r3["dt"] / s3 * 1e3), 3),
+                           "scaling": "strong", "n_gpus": world, "one_gpu_ms_per_step": ONE_GPU_CONFIG3_MS if (n_tot3, k3) == (50_000_000, 32) else None,
+                           "speedup_vs_one_gpu": round(ONE_GPU_CONFIG3_MS / (r3["dt"] / s3 * 1e3), 3) if (n_tot3, k3) == (50_000_000, 32) else None,
                            "speedup_note": "strong scaling of BASELINE configs[3]: the same 50M splats on 1 GPU take %.2f ms per step "
                                            "(profiles/r05_bench_50m_k32.json, measured on 1xMI355X); this line divides that by this run's "
                                            "step time" % ONE_GPU_CONFIG3_MS,
-                           "knn_kernel_ms": round(r3["knn_ms"], 4), "survivors_rank0": r3["survivors"], "phases": r3["phases"]}
+                           "knn_kernel_ms": round(r3["knn_ms"], 4), "survivors_rank0": r3["survivors"], "phases": r3["phases"],
+                           # parity INSIDE the multi-GPU run: the whole job's mask against the hash of a run of the
+                           # reference itself on the same cloud
+                           "survivors": int(full3.sum()), "mask_sha16": sha3, "threshold_hex": np.float32(r3["stats"][2]).tobytes().hex(),
+                           "mask_matches_reference_run": None if gold3 is None else bool(
+                               sha3 == gold3["mask_sha"] and int(full3.sum()) == gold3["survivors"]
+                               and np.float32(r3["stats"][2]).tobytes().hex() == gold3["threshold_hex"]),
+                           "reference_run": None if gold3 is None else gold3["source"]}
             except gsx._lib.GsxError as e:   # the headline line must survive a failure here (a GsxError is raised by every
                 config3 = {"workload": "BASELINE.json configs[3]", "error": repr(e)}   # rank that hits it; anything else aborts)
         ctx.check()
         watchdog.stage("configs[3] timed")
+        config2 = None
+        if not args.no_secondary:
+            # BASELINE.json configs[2] across the GPUs of the job: density (per-rank voxel histograms merged, dist_density.py) ->
+            # device compaction of each rank's rows -> SOR k=16 on the survivors (slab exchange), on the GLOBAL seed-0 cloud, with
+            # both masks checked against the hashes of the reference's own run of that chain
+            try:
+                import ctypes as C
+                gdens = importlib.import_module("3dgsconverter_amd.dist_density")
+                n_tot2, k2, sens2 = int(args.n2), 16, 0.5
+                shard2, sizes2 = global_shard(n_tot2, 5.0)
+                n_loc2 = sizes2[rank]
+                rows2 = ctx.alloc(12 * n_loc2 + 16).upload(shard2)
+                del shard2
+                keep_rows, keep_orig = be.buf("c2_rows", 12 * n_loc2 + 16), be.buf("c2_orig", 4 * n_loc2 + 16)
+
+                def sor_on(buf, n, k):
+                    if exchange["path"] == "slab":
+                        try:
+                            return gslab.slab_sor(be, comm, buf, n, k, args.sigma).check(), "slab"
+                        except gslab.SlabUncertain:     # raised on every rank together
+                            pass
+                    return gdist.replicated_sor(be, comm, buf, n, k, args.sigma, algo=args.algo).check(), "replicated"
+
+                def chain_step():
+                    d = gdens.sharded_density(be, comm, rows2, n_loc2, sensitivity=sens2)
+                    if d["empty"]:
+                        return d, 0, None, "none"
+                    n_out = C.c_int64()
+                    L.check(ctx.lib.gsx_compact_rows_dev(ctx.handle, rows2.ptr, None, d["mask"].ptr, n_loc2, keep_rows.ptr, keep_orig.ptr,
+                                                         C.byref(n_out)), "gsx_compact_rows_dev")
+                    r, path = sor_on(keep_rows, int(n_out.value), k2)
+                    return d, int(n_out.value), r, path
+                s2 = max(2, min(args.steps, 5))
+                chain_step()
+                comm.barrier()
+                t0 = time.perf_counter()
+                for _ in range(s2):
+                    d2, nk2, r2, path2 = chain_step()
+                comm.barrier()
+                dt2 = float(comm.reduce_scalar(time.perf_counter() - t0, gslab.KIND_F64_MAX))
+                dmask = be.to_host(d2["mask"], np.uint8, n_loc2).astype(bool) if not d2["empty"] else np.zeros(n_loc2, bool)
+                final = np.zeros(n_loc2, bool)
+                thr_hex = None
+                if r2 is not None:
+                    smask = be.to_host(r2["mask"], np.uint8, nk2).astype(bool)
+                    final[be.to_host(keep_orig, np.uint32, nk2)[smask]] = True
+                    thr_hex = np.float32(be.to_host(r2["stats"], np.float32, 3)[2]).tobytes().hex()
+                full_d, full_f = gather_mask(dmask.view(np.uint8), sizes2), gather_mask(final.view(np.uint8), sizes2)
+                rows2.free()
+                gold2 = golden_chain(n_tot2, 5.0, sens2, k2, args.sigma)
+                sha_d = hashlib.sha256(np.packbits(full_d)).hexdigest()[:16]
+                sha_f = hashlib.sha256(np.packbits(full_f)).hexdigest()[:16]
+                config2 = {"workload": "BASELINE.json configs[2] over %d GPU(s): %d uniform-random splats (L=5, the GLOBAL seed-0 cloud, sharded by index), "
+                                       "density sensitivity 0.5 (merged per-rank voxel histograms) -> device compaction -> SOR k=%d sigma=%g on the survivors"
+                                       % (world, n_tot2, k2, args.sigma),
+                           "value": round(n_tot2 * s2 / dt2 / 1e6, 2), "unit": "Msplats/s", "ms_per_step": round(dt2 / s2 * 1e3, 4), "steps": s2,
+                           "n_gpus": world, "scaling": "strong", "sor_exchange": path2,
+                           "after_density": int(full_d.sum()), "survivors": int(full_f.sum()), "density_mask_sha16": sha_d, "final_mask_sha16": sha_f,
+                           "sor_threshold_hex": thr_hex,
+                           "mask_matches_reference_run": None if gold2 is None else bool(
+                               sha_d == gold2["density_mask_sha"] and int(full_d.sum()) == gold2["density_kept"] and sha_f == gold2["final_mask_sha"]
+                               and int(full_f.sum()) == gold2["final_survivors"] and thr_hex == gold2["sor_threshold_hex"]),
+                           "reference_run": None if gold2 is None else gold2["source"]}
+            except gsx._lib.GsxError as e:
+                config2 = {"workload": "BASELINE.json configs[2]", "error": repr(e)}
+        ctx.check()
+        watchdog.stage("configs[2] timed")
         # cpu_baseline leg (rank 0, its own shard: what one GPU of the job replaces), while the other ranks wait at the barrier
         cpu = None
         if rank == 0 and not args.no_cpu_baseline:
@@ -1075,6 +1309,8 @@ def main_multi(args):
             out["cpu_baseline"] = cpu
         if config3 is not None:
             out["config3"] = config3
+        if config2 is not None:
+            out["config2"] = config2
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     comm.barrier()
     watchdog.done()
@@ -1100,6 +1336,8 @@ def main():
                     help="N>1 data path: slab (default) or the replicated all-gather; 'slab' with --gpus 1 runs the slab "
                          "pipeline through a one-rank RCCL communicator (what one rank of an N-GPU job executes)")
     ap.add_argument("--n3", type=int, default=50_000_000, help="N>1: total splats of the configs[3] line (k=32), split over the ranks")
+    ap.add_argument("--k3", type=int, default=32, help="N>1: k of the configs[3] line (tests: a size / k pair a committed reference-run hash exists for)")
+    ap.add_argument("--n2", type=int, default=10_000_000, help="N>1: total splats of the configs[2] line (density 0.5 -> SOR k=16), split over the ranks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -427,7 +427,8 @@ def test_bench_gpus_2_end_to_end(launcher, tmp_path):
     exchange (cross-checked against the replicated one inside the run) and configs[3] are the same code an 8-GPU node runs."""
     import json
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "400000", "--n3", "600000"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "400000", "--n3", "1000000", "--k3", "16",
+           "--n2", "1000000"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GSX_RDZV_FILE"):
         env.pop(k, None)
@@ -459,7 +460,26 @@ def test_bench_gpus_2_end_to_end(launcher, tmp_path):
         assert ph[key] > 0, (key, ph)
     assert ph["knn_ms"] < d["ms_per_step"] * 1.5
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
-    assert c3["scaling"] == "strong" and c3["n_gpus"] == 2 and c3["speedup_vs_one_gpu"] > 0 and c3["phases"]["knn_ms"] > 0
+    assert c3["scaling"] == "strong" and c3["n_gpus"] == 2 and c3["phases"]["knn_ms"] > 0
+    # round 6: parity INSIDE the multi-GPU run -- the secondary lines shard the GLOBAL seed-0 cloud by index and
+    # compare the gathered mask with the hash of the reference's own run (tests/golden/cases.json: sor_u1m_k16_s1 = SURVEY's KAT
+    # SOR-1M, 848 169 survivors); at BASELINE's full sizes (--n3 50000000 --k3 32, --n2 10000000: the defaults) the same fields are
+    # checked against tests/golden/large_cases.json
+    assert c3["mask_matches_reference_run"] is True and c3["survivors"] == 848169 and c3["mask_sha16"] == "bb601219805e74a7", c3
+    c2 = d["config2"]
+    assert "error" not in c2 and c2["value"] > 0 and c2["n_gpus"] == 2, c2
+    pts = datasets.uniform(1000000, 5.0, 0)
+    from oracle import density as oden
+    dref = oden.density_filter(pts, sensitivity=0.5)
+    sref = osor.sor(pts[dref["mask"]], 16, 1.0)
+    final = np.zeros(len(pts), bool)
+    final[np.flatnonzero(dref["mask"])[sref["mask"]]] = True
+    import hashlib
+    assert c2["after_density"] == int(dref["mask"].sum()) and c2["survivors"] == int(final.sum()), c2
+    assert c2["density_mask_sha16"] == hashlib.sha256(np.packbits(dref["mask"])).hexdigest()[:16]
+    assert c2["final_mask_sha16"] == hashlib.sha256(np.packbits(final)).hexdigest()[:16]
+    assert c2["sor_threshold_hex"] == np.float32(sref["threshold"]).tobytes().hex()
+    assert c2["mask_matches_reference_run"] is None      # (no committed reference run of the chain at this size; 10M has one)
     # the survivors of rank 0's shard of the 2 x 400 000 cloud, against the oracle on the whole cloud
     full = np.concatenate([datasets.uniform(400000, 5.0, r) for r in range(2)])
     ref = osor.sor(full, 16, 1.0)
