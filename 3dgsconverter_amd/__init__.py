@@ -14,9 +14,9 @@ HIP in csrc/.  No CPU fallback: without libgsx_hip.so and a gfx950 device the fi
 entry points raise ``GsxError``.
 """
 from . import _lib
-from ._lib import GsxError, has_hip, device_count  # noqa: F401
+from ._lib import GsxError, has_hip, device_count, release_arenas as release_device_cache  # noqa: F401
 from . import processing  # noqa: F401
 from .processing import DataProcessor, gpu_ops  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 
-__all__ = ["processing", "DataProcessor", "gpu_ops", "GsxError", "has_hip", "device_count", "install", "uninstall"]
+__all__ = ["processing", "DataProcessor", "gpu_ops", "GsxError", "has_hip", "device_count", "install", "uninstall", "release_device_cache"]

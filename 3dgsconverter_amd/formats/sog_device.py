@@ -145,20 +145,17 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
     width, height = texture_size(n)
     texels = width * height
     t_enter = time.perf_counter()
-    ctx = _lib.Context(device)
+    ar = _lib.arena(device)        # work buffers and contexts outlive the call (DeviceArena: no hipMalloc / hipFree in a repeated write)
+    ctx = ar.ctx
     st = _Stages(ctx, profile)
     st.t = t_enter
-    bufs = []
+    names = iter(range(1 << 30))
 
-    def alloc(nbytes):
-        b = ctx.alloc(max(int(nbytes), 16))
-        bufs.append(b)
-        return b
+    def alloc(nbytes, name=None):
+        return ar.buf("sog_%s" % (name if name is not None else next(names)), nbytes)
 
     def release(*bs):
-        for b in bs:
-            b.free()
-            bufs.remove(b)
+        pass                       # (grow-only arena: nothing is handed back between calls)
 
     out = {"n": n, "width": width, "height": height, "textures": {}, "stats": {}}
     try:
@@ -295,12 +292,8 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             worker = threading.Thread(target=run_palette, name="gsx-sog-palette")
             worker.start()
         try:
-            ctx2 = _lib.Context(device, own_stream=True) if worker else ctx
-            try:
-                _lib.check(lib.gsx_dev_download_staged(ctx2.handle, host_tex.ctypes.data, d_tex.ptr, 5 * 4 * texels), "gsx_dev_download_staged")
-            finally:
-                if ctx2 is not ctx:
-                    ctx2.close()
+            ctx2 = ar.side if worker else ctx
+            _lib.check(lib.gsx_dev_download_staged(ctx2.handle, host_tex.ctypes.data, d_tex.ptr, 5 * 4 * texels), "gsx_dev_download_staged")
             with np.errstate(all="ignore"):
                 if len(pos_list):
                     # one fancy assignment for the three channels: the tag (texel * 4 + channel) IS the flat index into the RGBA array
@@ -338,14 +331,9 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         if profile:
             out["_lists"] = (pos_list, al_list)
         out["stats"] = {"uncertain_positions": int(len(pos_list)), "uncertain_alpha": int(len(al_list)), "n": n}
-        for b_ in list(bufs):
-            b_.free()
-        bufs.clear()
-        st.mark("free")
         if profile:
             out["stage_ms"] = {k_: round(v_, 3) for k_, v_ in st.ms.items()}
         return out
-    finally:
-        for b in bufs:
-            b.free()
-        ctx.close()
+    except _lib.GsxError:
+        _lib.release_arenas()      # a failed HIP call: do not keep a context in an unknown state
+        raise
