@@ -419,60 +419,95 @@ static int collect_dense(gsx_ctx *c, const VoxelFrame &hvf, const VoxTable &t, i
 // density stage's 155 us at 10M splats) -- and flushed into the same HBM table as before (one table_add per occupied voxel and
 // tile), so that the collect / cluster / mask kernels are untouched.
 constexpr int VOX_DENSE_MAX = 4096;
+constexpr int VOX_DENSE_LDS = 4096;   // histogram words per workgroup (16 KiB: ten workgroups per CU): the frame's bins, replicated while they fit
+constexpr int VOX_DENSE_ROWS = 8;     // rows in flight per lane
+// Round 6: (i) the kernel also leaves each point's dense voxel index in a 2-byte side array (`ids`, 0xffff = outside the frame),
+// so that the membership pass reads 2 B per point instead of the 12-byte row again; (ii) the histogram is REPLICATED in LDS
+// (copy = lane & (copies - 1)): 64 lanes adding into ~125 bins of one copy serialise, 16 copies spread them over 2000 words;
+// (iii) (n,3) rows -- what the drop-in and the device chain pass -- are read as one 12-byte load per point instead of three
+// 4-byte loads 12 bytes apart.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void voxel_count_dense_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                 const float *__restrict__ z, int64_t stride, int64_t n, float voxel,
                                                                 const VoxelFrame *__restrict__ vfp, unsigned long long *__restrict__ tkeys,
                                                                 unsigned *__restrict__ tcnt, unsigned tmask,
-                                                                unsigned *__restrict__ oob /* nullable */)
+                                                                unsigned *__restrict__ oob /* nullable */, uint16_t *__restrict__ ids /* nullable */)
 {
-    __shared__ unsigned bins[VOX_DENSE_MAX];
+    __shared__ unsigned bins[VOX_DENSE_LDS];
     const VoxelFrame f = *vfp;
     if (!f.ok) return;
     const int d1 = f.dim[1], d2 = f.dim[2];
     const int nv = f.dim[0] * d1 * d2;   // <= VOX_DENSE_MAX (the host checked)
-    for (int i = threadIdx.x; i < nv; i += 256) bins[i] = 0u;
+    int copies = 1;
+    while (copies < 16 && 2 * copies * nv <= VOX_DENSE_LDS) copies *= 2;
+    for (int i = threadIdx.x; i < copies * nv; i += 256) bins[i] = 0u;   // (copies * nv <= max(nv, VOX_DENSE_LDS / 2 ... VOX_DENSE_LDS))
     __syncthreads();
+    unsigned *mine = bins + (threadIdx.x & (copies - 1)) * nv;
     bool out = false;
     const int64_t step = (int64_t)gridDim.x * 256;
-    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * step) {   // 12 loads in flight per lane
-        float v[4][3];
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += VOX_DENSE_ROWS * step) {   // 8 rows (24 dwords) in flight per lane
+        float v[VOX_DENSE_ROWS][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = (i0 + u * step < n ? i0 + u * step : i0) * stride;
-            v[u][0] = x[i];
-            v[u][1] = y[i];
-            v[u][2] = z[i];
+        for (int u = 0; u < VOX_DENSE_ROWS; ++u) {
+            const int64_t r = i0 + u * step < n ? i0 + u * step : i0;
+            if (PACKED) {
+                const float3 p = reinterpret_cast<const float3 *>(x)[r];
+                v[u][0] = p.x;
+                v[u][1] = p.y;
+                v[u][2] = p.z;
+            } else {
+                v[u][0] = x[r * stride];
+                v[u][1] = y[r * stride];
+                v[u][2] = z[r * stride];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < VOX_DENSE_ROWS; ++u) {
             if (i0 + u * step >= n) continue;
             const unsigned a = (unsigned)(voxel_key(v[u][0], voxel) - f.kmin[0]), b = (unsigned)(voxel_key(v[u][1], voxel) - f.kmin[1]),
                            c = (unsigned)(voxel_key(v[u][2], voxel) - f.kmin[2]);
             if (a >= (unsigned)f.dim[0] || b >= (unsigned)d1 || c >= (unsigned)d2) {   // only possible with a caller's box (see `oob`)
                 out = true;
+                if (ids) ids[i0 + u * step] = 0xffffu;
                 continue;
             }
-            atomicAdd(&bins[(a * d1 + b) * d2 + c], 1u);
+            const unsigned id = (a * d1 + b) * d2 + c;
+            atomicAdd(&mine[id], 1u);
+            if (ids) ids[i0 + u * step] = (uint16_t)id;
         }
     }
     if (out && oob) *oob = 1u;
     __syncthreads();
     for (int i = threadIdx.x; i < nv; i += 256) {
-        const unsigned cnt = bins[i];
+        unsigned cnt = 0;
+        for (int cp = 0; cp < copies; ++cp) cnt += bins[cp * nv + i];
         if (!cnt) continue;
         const int a = i / (d1 * d2), r = i - a * d1 * d2, b = r / d2, c = r - b * d2;
         table_add<false>(tkeys, nullptr, tcnt, tmask, pack_key<false>(f, a + f.kmin[0], b + f.kmin[1], c + f.kmin[2]), cnt);
     }
 }
 
-static int count_points(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, float voxel,
-                        const VoxelFrame *dvf, const VoxTable &t, unsigned *oob = nullptr, const VoxelFrame *host_frame = nullptr)
+static bool dense_frame(const VoxelFrame *host_frame, const VoxTable &t)
 {
-    if (host_frame && !t.wide && host_frame->ok == 1 &&
-        (int64_t)host_frame->dim[0] * host_frame->dim[1] * host_frame->dim[2] <= VOX_DENSE_MAX) {
-        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4096), (int64_t)c->num_cu * 4));
-        hipLaunchKernelGGL(voxel_count_dense_kernel, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, voxel, dvf, t.tkeys, t.tcnt,
-                           (unsigned)(t.tsize - 1), oob);
+    return host_frame && !t.wide && host_frame->ok == 1 &&
+           (int64_t)host_frame->dim[0] * host_frame->dim[1] * host_frame->dim[2] <= VOX_DENSE_MAX;
+}
+
+static int count_points(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, float voxel,
+                        const VoxelFrame *dvf, const VoxTable &t, unsigned *oob = nullptr, const VoxelFrame *host_frame = nullptr,
+                        uint16_t *ids = nullptr)
+{
+    if (dense_frame(host_frame, t)) {
+        // measured at 10M points, 125 voxels (profiles/r06_variants.txt): 1 / 2 / 3 / 4 / 6 / 8 workgroups per CU -> 55 / 47 / 50 / 59 /
+        // 77 / 91 us -- the same with the final per-bin atomics replaced by side-by-side histograms and one reducing workgroup
+        static const int per_cu = getenv("GSX_VOX_DENSE_WGS") ? std::max(1, atoi(getenv("GSX_VOX_DENSE_WGS"))) : 2;
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4096), (int64_t)c->num_cu * per_cu));
+        if (stride == 3 && y == x + 1 && z == x + 2)
+            hipLaunchKernelGGL(voxel_count_dense_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, voxel, dvf, t.tkeys,
+                               t.tcnt, (unsigned)(t.tsize - 1), oob, ids);
+        else
+            hipLaunchKernelGGL(voxel_count_dense_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, x, y, z, stride, n, voxel, dvf, t.tkeys,
+                               t.tcnt, (unsigned)(t.tsize - 1), oob, ids);
         GSX_HIP(hipGetLastError());
         return 0;
     }
@@ -931,6 +966,44 @@ __global__ __launch_bounds__(256) void voxel_mask_dev_kernel(const float *__rest
     }
 }
 
+// membership from the side array: mask[i] = the voxel with dense index ids[i] is in the kept list (narrow keys)
+__global__ __launch_bounds__(256) void voxel_mask_ids_kernel(const uint16_t *__restrict__ ids, int64_t n, VoxelFrame f,
+                                                             const unsigned long long *__restrict__ kept, const ClusterOut *__restrict__ co,
+                                                             uint8_t *__restrict__ mask)
+{
+    __shared__ uint8_t flag[VOX_DENSE_MAX + 4];
+    const int d1 = f.dim[1], d2 = f.dim[2];
+    const int nv = f.dim[0] * d1 * d2;
+    for (int i = threadIdx.x; i < nv; i += 256) flag[i] = 0;
+    __syncthreads();
+    const int n_kept = co->status == 0u ? (int)co->n_kept_voxels : 0;
+    for (int i = threadIdx.x; i < n_kept; i += 256) {
+        const unsigned long long k = kept[i] - 1ull;   // pack_key<false>: (a << 42 | b << 21 | c) + 1
+        const unsigned a = (unsigned)(k >> 42), b = (unsigned)((k >> 21) & 0x1fffffu), c = (unsigned)(k & 0x1fffffu);
+        flag[(a * d1 + b) * d2 + c] = 1;
+    }
+    __syncthreads();
+    // eight points per lane and step: one 16-byte load of ids, one 8-byte store of mask bytes
+    const int64_t n8 = n / 8;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n8; j += (int64_t)gridDim.x * 256) {
+        const uint4 w = reinterpret_cast<const uint4 *>(ids)[j];
+        const unsigned u[4] = {w.x, w.y, w.z, w.w};
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned lo = u[q] & 0xffffu, hi = u[q] >> 16;
+            m |= (unsigned long long)(lo < (unsigned)nv ? flag[lo] : 0) << (16 * q);
+            m |= (unsigned long long)(hi < (unsigned)nv ? flag[hi] : 0) << (16 * q + 8);
+        }
+        reinterpret_cast<unsigned long long *>(mask)[j] = m;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += 256) {
+            const unsigned id = ids[i];
+            mask[i] = id < (unsigned)nv ? flag[id] : 0;
+        }
+}
+
 // box6 (host, nullable): per-axis minima then maxima of a SUPERSET of the rows (e.g. the box of the table the rows were
 // filtered from) -- the key frame then needs no pass over the rows and no synchronisation
 int density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n, double voxel_size,
@@ -976,10 +1049,22 @@ int density_filter_dev(gsx_ctx *c, const float *x, const float *y, const float *
     unsigned long long *kept_a = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctr) + 32);
     unsigned *kept_b = reinterpret_cast<unsigned *>(kept_a + CL_MAX);
     GSX_HIP(hipMemsetAsync(ctr, 0, 16, c->stream));   // [0] unique, [1] dense, [2] a row outside the caller's box
-    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t, from_box ? ctr + 2 : nullptr, &hvf));
+    // a frame of <= 4096 voxels (configs[2]: 5 x 5 x 5): ONE pass over the rows -- the count kernel parks every point's voxel index in
+    // a 2-byte side array the membership pass reads instead of the rows (needs an 8-byte aligned mask)
+    uint16_t *ids = nullptr;
+    if (dense_frame(&hvf, t) && (reinterpret_cast<uintptr_t>(mask_dev) & 7) == 0) {
+        GSX_CHECK(c->vox_ids.reserve(2 * (size_t)n + 64));
+        ids = c->vox_ids.as<uint16_t>();
+    }
+    GSX_CHECK(count_points(c, x, y, z, stride, n, voxel, dvf, t, from_box ? ctr + 2 : nullptr, &hvf, ids));
     const unsigned mp = (unsigned)std::min<int64_t>(std::max<int64_t>(min_points, 0), 0xffffffffll);
     hipLaunchKernelGGL(voxel_collect_kernel, dim3(blocks_for(c, (int64_t)t.tsize, 1024)), dim3(256), 0, c->stream, t.tkeys, t.tkb,
                        t.tcnt, (unsigned)t.tsize, mp, (unsigned)cap, okeys, okb, ocnt, ctr);
+    if (ids) {
+        hipLaunchKernelGGL((voxel_cluster_kernel<false>), dim3(1), dim3(256), 0, c->stream, okeys, okb, ctr, (unsigned)cap, hvf, keep_multi,
+                           kept_a, kept_b, dco);
+        hipLaunchKernelGGL(voxel_mask_ids_kernel, dim3(blocks_for(c, n, 8192)), dim3(256), 0, c->stream, ids, n, hvf, kept_a, dco, mask_dev);
+    } else
     if (t.wide) {
         hipLaunchKernelGGL((voxel_cluster_kernel<true>), dim3(1), dim3(256), 0, c->stream, okeys, okb, ctr, (unsigned)cap, hvf, keep_multi,
                            kept_a, kept_b, dco);
