@@ -3,7 +3,7 @@
 # commands, PMC passes (separate passes: TCC FETCH / WRITE, SQ issue counters).  usage: run_round_artifacts.sh r02
 set -u
 export TMPDIR=/tmp
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -12,12 +12,22 @@ timeout 900 python bench.py > $OUT/bench_${R}_10m.json 2> $OUT/bench_${R}.err
 timeout 600 python bench.py --exchange slab --steps 20 --no-cpu-baseline > $OUT/bench_${R}_slab_1rank.json 2>> $OUT/bench_${R}.err
 timeout 600 python bench.py --n 50000000 --extent 10 --k 32 --steps 10 --no-cpu-baseline --no-secondary > $OUT/bench_${R}_50m_k32.json 2>> $OUT/bench_${R}.err
 # the N-rank code path on this one-GPU box: bench.py starts its own ranks, which share the GPU over the hostwire transport
-timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --n 2000000 --n3 4000000 > $OUT/bench_${R}_gpus2_hostwire.json 2>> $OUT/bench_${R}.err
+# (round 6: the secondary lines run BASELINE's own sizes -- 50M k=32, 10M density -> SOR -- on the GLOBAL seed-0 clouds and check the
+#  gathered masks against the reference-run hashes of tests/golden/large_cases.json: mask_matches_reference_run)
+timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --n 2000000 --no-cpu-baseline > $OUT/bench_${R}_gpus2_hostwire.json 2>> $OUT/bench_${R}.err
 cd /tmp
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R} -o trace -- python $ROOT/bench.py $B > $OUT/prof_${R}.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_km -o trace -- python $ROOT/tools/probe_kmeans.py > $OUT/prof_${R}_km.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_slab -o trace -- python $ROOT/bench.py --exchange slab $B > $OUT/prof_${R}_slab.log 2>&1
+# the SOG writer's device-resident core (10M x 248-byte rows -> texel arrays): stage clock + kernel trace of the same command
+timeout 600 python $ROOT/tools/probe_sog.py > $OUT/sog_probe_${R}_10m.log 2>&1
+PROBE_REPS=1 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_sog -o trace -- python $ROOT/tools/probe_sog.py > $OUT/prof_${R}_sog.log 2>&1
+python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_sog/trace_results.db > $OUT/kernel_stats_${R}_sog.txt 2>&1
+rm -rf $OUT/prof_${R}_sog
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_dens -o trace -- python $ROOT/tools/probe_density.py > $OUT/prof_${R}_dens.log 2>&1
+python $ROOT/tools/rocpd_summary.py $OUT/prof_${R}_dens/trace_results.db > $OUT/kernel_stats_${R}_density.txt 2>&1
+rm -rf $OUT/prof_${R}_dens
 P="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
@@ -27,6 +37,10 @@ timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 -d $OUT/pmc_sq3_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_BF16 -d $OUT/pmc_sq4_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+# what bucket_scatter waits for: write-request stalls at the L2's memory interface, pending-request stalls in the L1
+timeout 600 rocprofv3 --pmc TCC_EA0_WRREQ_STALL TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_RDREQ -d $OUT/pmc_ea_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ TCP_TCC_READ_REQ TCP_GATE_EN1 -d $OUT/pmc_tcp_${R} -o pmc -- python $ROOT/bench.py $P > /dev/null 2>&1
+python $ROOT/tools/rocpd_summary.py --pmc $OUT/pmc_ea_${R}/pmc_results.db $OUT/pmc_tcp_${R}/pmc_results.db $OUT/pmc_grbm_${R}/pmc_results.db 2>&1 | grep -E "^#|^kernel|bucket_|bbox_partial" > $OUT/pmc_${R}_binning.txt
 # the clouds a uniform grid is bad at: adaptive mode -> Morton-tree path (csrc/sor_tree.hip)
 for C in "clustered 1000000 16" "floaters 10000000 16" "clustered 10000000 16" "clustered 10000000 25" "clustered 10000000 50"; do
   set -- $C
@@ -50,7 +64,7 @@ python $ROOT/tools/rocpd_summary.py --pmc $OUT/calib_fetch_${R}/pmc_results.db $
 rm -rf $OUT/calib_fetch_${R} $OUT/calib_write_${R}
 timeout 120 $ROOT/tools/ubench/mfma_valu_overlap > $OUT/mfma_valu_overlap_${R}.txt 2>&1
 cd $ROOT
-timeout 600 python bench.py --gpus 8 --steps 5 --warmup 2 --n 1000000 --n3 4000000 --no-cpu-baseline > $OUT/bench_${R}_gpus8_hostwire.json 2>> $OUT/bench_${R}.err
+timeout 1200 python bench.py --gpus 8 --steps 5 --warmup 2 --n 1000000 --no-cpu-baseline > $OUT/bench_${R}_gpus8_hostwire.json 2>> $OUT/bench_${R}.err
 for T in "" _km _slab; do python tools/rocpd_summary.py $OUT/prof_${R}${T}/trace_results.db > $OUT/kernel_stats_${R}${T}.txt 2>&1; done
 python tools/rocpd_summary.py --pmc $OUT/pmc_fetch_${R}/pmc_results.db $OUT/pmc_write_${R}/pmc_results.db > $OUT/pmc_${R}_tcc.txt 2>&1
 python tools/rocpd_summary.py --pmc $OUT/pmc_sq1_${R}/pmc_results.db $OUT/pmc_sq2_${R}/pmc_results.db $OUT/pmc_sq3_${R}/pmc_results.db $OUT/pmc_sq4_${R}/pmc_results.db $OUT/pmc_grbm_${R}/pmc_results.db > $OUT/pmc_${R}_sq.txt 2>&1
