@@ -23,3 +23,11 @@ def test_fuzz_parity_slice(gsx):
 def test_fuzz_more_slice(gsx):
     import fuzz_more
     assert fuzz_more.main(cases=20, seed=20260927) == 0
+
+
+def test_fuzz_sog_slice(gsx):
+    """round 6: the SOG writer's device-resident core (formats/sog_device.py) on 16 random tables -- sizes 1100 ... 400k, SH degree
+    0-3 with zeroed coefficient tails, tied / duplicate / signed-zero / wide-range coordinates, rows widened by u1 fields, every
+    compression level -- against the restated reference statements (oracle/sog.py), five images byte for byte"""
+    import fuzz_sog
+    assert fuzz_sog.main(cases=16, seed=20260930) == 0
