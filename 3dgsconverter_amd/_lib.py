@@ -181,6 +181,8 @@ SIGNATURES = {
     "gsx_morton_order_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _P, C.POINTER(_I)]),
     "gsx_cply_pack_dev": (_I, [_P, _P, _P, _I64, _P, _P]),
     "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
+    "gsx_cply_pack_strided_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P]),
+    "gsx_cply_sh_strided_dev": (_I, [_P, _P, _I, _I64, _I64, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
     "gsx_density_filter_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I, _P, _P, C.POINTER(DensityInfo)]),
@@ -795,51 +797,121 @@ def cply_pack(columns: dict, order: "np.ndarray | None", sh_columns=(), ctx: "Co
             ctx.close()
 
 
-def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = None, ctx: "Context | None" = None):
-    """The compressed-PLY writer's numeric core on a whole splat table (formats/compressed_ply.py:200-297): ONE threaded gather
-    of the 13 + 1 + len(sh_names) columns (host_gather_columns), numpy's sigmoid of the opacity (the reference's expression, so
-    its bits), ONE upload, Morton order (unless `order` is given), chunk packers and SH bytes on the device.
+def _sigmoid_f32_threaded(x: np.ndarray) -> np.ndarray:
+    """numpy's own `1.0 / (1.0 + np.exp(-x))` on float32 (formats/compressed_ply.py:200-203), slices of the array on a few threads
+    (the ufuncs release the GIL; the value of an element does not depend on where in an array it sits)"""
+    n = len(x)
+    out = np.empty(n, dtype=np.float32)
+    nt = max(1, min(16, (os.cpu_count() or 1) // 2, n // 200_000))
+
+    def run(t):
+        a, b = n * t // nt, n * (t + 1) // nt
+        with np.errstate(over="ignore"):
+            out[a:b] = 1.0 / (1.0 + np.exp(-x[a:b]))
+    if nt == 1:
+        run(0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(nt) as ex:
+            list(ex.map(run, range(nt)))
+    return out
+
+
+def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = None, ctx: "Context | None" = None, stage_ms: "dict | None" = None):
+    """The compressed-PLY writer's numeric core on a whole splat table (formats/compressed_ply.py:200-297).  Round 6: the raw rows
+    are uploaded ONCE (gsx_dev_upload_staged) and the Morton sort, the chunk packers and the SH packer read their fields straight
+    out of them (element stride = row_bytes / 4: gsx_cply_pack_strided_dev / gsx_cply_sh_strided_dev) -- round 5 gathered the 59
+    columns on the host (one threaded pass, 472 MB of freshly faulted pages per 2M splats) and uploaded that.  numpy's sigmoid of
+    the opacity (the reference's expression, so its bits) is evaluated on ONE gathered column, on a few threads, and uploaded as
+    the one contiguous column; results come back through the staging lanes.  Tables the row path does not take (fields that are
+    not float32, rows that are not a multiple of 4 bytes, f_rest fields that are not consecutive) and calls with a caller's
+    context gather their columns on the host as before.
     -> (chunks (ceil(n/256), 18) f32, vertices (n, 4) u32, sh (n, m) u8 or None, order u32[n], recursion levels or None)"""
-    require_hip()
+    lib = require_hip()
     n = len(data)
     sh_names = list(sh_names)
     m = len(sh_names)
     names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS] + sh_names
-    mat = host_gather_columns(data, names)                         # (14 + m, n), row 9 = opacity
-    with np.errstate(over="ignore"):
-        mat[9] = 1.0 / (1.0 + np.exp(-mat[9]))                     # :200-203 (float32 in, float32 out, as in the reference)
+    fields = data.dtype.fields or {}
+    resident = (ctx is None and n >= 4096 and data.ndim == 1 and data.flags.c_contiguous and data.dtype.itemsize % 4 == 0
+                and all(nm in fields and fields[nm][0] == np.dtype("<f4") and fields[nm][1] % 4 == 0 for nm in names)
+                and all(fields[sh_names[i]][1] == fields[sh_names[0]][1] + 4 * i for i in range(m)))
     nchunks = (n + 255) // 256
-    own = ctx is None
-    ctx = ctx or Context(0)
+    own = ctx is None and not resident
+    ar = arena(0) if resident else None
+    ctx = ar.ctx if resident else (ctx or Context(0))
     bufs = []
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def mark(name):   # stage clock (a synchronisation per stage) when the caller asks for it
+        if stage_ms is not None:
+            ctx.synchronize()
+            now = _time.perf_counter()
+            stage_ms[name] = round(stage_ms.get(name, 0.0) + (now - _t[0]) * 1e3, 3)
+            _t[0] = now
+
+    def alloc(nbytes, name):
+        if ar is not None:
+            return ar.buf("cply_" + name, nbytes)
+        b = ctx.alloc(max(int(nbytes), 16))
+        bufs.append(b)
+        return b
     try:
-        d_mat = ctx.alloc(max(mat.nbytes, 16)).upload(mat)
-        bufs.append(d_mat)
-        col = lambda i: d_mat.ptr + 4 * n * i
+        if resident:
+            rd = data.dtype.itemsize // 4
+            d_rows = alloc(data.nbytes, "rows")
+            check(lib.gsx_dev_upload_staged(ctx.handle, d_rows.ptr, data.ctypes.data, data.nbytes), "gsx_dev_upload_staged")
+            mark("upload")
+            alpha = _sigmoid_f32_threaded(host_gather_columns(data, ["opacity"])[0])
+            d_alpha = alloc(4 * n, "alpha")
+            check(lib.gsx_dev_upload(ctx.handle, d_alpha.ptr, alpha.ctypes.data, alpha.nbytes), "gsx_dev_upload")
+            mark("sigmoid_host")
+            col = lambda i: d_alpha.ptr if i == 9 else d_rows.ptr + int(fields[names[i]][1])
+            strides = (_I64 * 14)(*[1 if i == 9 else rd for i in range(14)])
+            xyz_stride, sh_ptr, sh_col_stride, sh_elem_stride = rd, (d_rows.ptr + int(fields[sh_names[0]][1])) if m else None, 1, rd
+        else:
+            mat = host_gather_columns(data, names)                     # (14 + m, n), row 9 = opacity
+            with np.errstate(over="ignore"):
+                mat[9] = 1.0 / (1.0 + np.exp(-mat[9]))                 # :200-203 (float32 in, float32 out, as in the reference)
+            d_mat = alloc(max(mat.nbytes, 16), "mat")
+            d_mat.upload(mat)
+            col = lambda i: d_mat.ptr + 4 * n * i
+            strides = (_I64 * 14)(*([1] * 14))
+            xyz_stride, sh_ptr, sh_col_stride, sh_elem_stride = 1, col(14), n, 1
         levels = None
-        d_order = ctx.alloc(max(4 * n, 16))
-        bufs.append(d_order)
+        d_order = alloc(4 * n, "order")
         if order is None:
             lv = C.c_int()
-            check(ctx.lib.gsx_morton_order_dev(ctx.handle, col(0), col(1), col(2), 1, n, d_order.ptr, C.byref(lv)), "gsx_morton_order_dev")
+            check(lib.gsx_morton_order_dev(ctx.handle, col(0), col(1), col(2), xyz_stride, n, d_order.ptr, C.byref(lv)), "gsx_morton_order_dev")
             levels = int(lv.value)
+            mark("morton")
             order = d_order.download(np.uint32, n) if n else np.zeros(0, np.uint32)
         else:
             order = np.ascontiguousarray(order, dtype=np.uint32)
             d_order.upload(order)
         ptrs = (C.c_void_p * 14)(*[col(i) for i in range(14)])
-        d_chunk, d_vert = ctx.alloc(max(72 * nchunks, 16)), ctx.alloc(max(16 * n, 16))
-        bufs += [d_chunk, d_vert]
-        check(ctx.lib.gsx_cply_pack_dev(ctx.handle, ptrs, d_order.ptr, n, d_chunk.ptr, d_vert.ptr), "gsx_cply_pack_dev")
-        chunks = d_chunk.download(np.float32, 18 * nchunks).reshape(nchunks, 18)
-        verts = d_vert.download(np.uint32, 4 * n).reshape(n, 4)
-        sh = None
+        d_chunk, d_vert = alloc(72 * nchunks, "chunk"), alloc(16 * n, "vert")
+        check(lib.gsx_cply_pack_strided_dev(ctx.handle, ptrs, strides, d_order.ptr, n, d_chunk.ptr, d_vert.ptr), "gsx_cply_pack_strided_dev")
+        d_out = None
         if m:
-            d_out = ctx.alloc(max(n * m, 16))
-            bufs.append(d_out)
-            check(ctx.lib.gsx_cply_sh_dev(ctx.handle, col(14), m, n, d_order.ptr, n, d_out.ptr), "gsx_cply_sh_dev")
-            sh = d_out.download(np.uint8, n * m).reshape(n, m)
+            d_out = alloc(n * m, "sh")
+            check(lib.gsx_cply_sh_strided_dev(ctx.handle, sh_ptr, m, sh_col_stride, sh_elem_stride, d_order.ptr, n, d_out.ptr), "gsx_cply_sh_strided_dev")
+        mark("pack")
+        chunks = d_chunk.download(np.float32, 18 * nchunks).reshape(nchunks, 18)
+        verts = np.empty((n, 4), np.uint32)
+        sh = np.empty((n, m), np.uint8) if m else None
+        dl = lib.gsx_dev_download_staged if resident else lib.gsx_dev_download
+        if n:
+            check(dl(ctx.handle, verts.ctypes.data, d_vert.ptr, verts.nbytes), "gsx_dev_download")
+            if m:
+                check(dl(ctx.handle, sh.ctypes.data, d_out.ptr, sh.nbytes), "gsx_dev_download")
+        mark("download")
         return chunks, verts, sh, order, levels
+    except GsxError:
+        if ar is not None:
+            release_arenas()
+        raise
     finally:
         for b in bufs:
             b.free()

@@ -268,6 +268,8 @@ static int morton_order_dev(gsx_ctx *c, const float *x, const float *y, const fl
 // ---------------------------------------------------------------- chunk bounds + packers
 struct CplyCols {
     const float *col[14];   // x y z | scale_0..2 | f_dc_0..2 | alpha (sigmoid of opacity, computed by numpy) | rot_0..3
+    int64_t stride[14];     // elements between consecutive splats of column a: 1 = a contiguous column, row_bytes / 4 = the field
+                            // inside raw rows resident in HBM (round 6: the 13 fields of one splat then share two cache lines)
 };
 
 __device__ __forceinline__ unsigned quant_unit(float v, float lo, float hi, float t)
@@ -322,14 +324,14 @@ __global__ __launch_bounds__(256) void cply_pack_kernel(CplyCols c, const unsign
     if (live) {
         const size_t s = order ? order[i] : (size_t)i;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) v[a] = c.col[a][s];
+        for (int a = 0; a < 3; ++a) v[a] = c.col[a][s * c.stride[a]];
 #pragma unroll
-        for (int a = 3; a < 6; ++a) v[a] = fminf(fmaxf(c.col[a][s], -20.0f), 20.0f);            // np.clip(scale, -20, 20)  (:212-214)
+        for (int a = 3; a < 6; ++a) v[a] = fminf(fmaxf(c.col[a][s * c.stride[a]], -20.0f), 20.0f);            // np.clip(scale, -20, 20)  (:212-214)
 #pragma unroll
-        for (int a = 6; a < 9; ++a) v[a] = __fadd_rn(__fmul_rn(c.col[a][s], 0.28209479177387814f), 0.5f);   // f_dc * SH_C0 + 0.5  (:195-198)
-        al = c.col[9][s];
+        for (int a = 6; a < 9; ++a) v[a] = __fadd_rn(__fmul_rn(c.col[a][s * c.stride[a]], 0.28209479177387814f), 0.5f);   // f_dc * SH_C0 + 0.5  (:195-198)
+        al = c.col[9][s * c.stride[9]];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) rq[a] = c.col[10 + a][s];
+        for (int a = 0; a < 4; ++a) rq[a] = c.col[10 + a][s * c.stride[10 + a]];
     }
     float lo[9], hi[9];
 #pragma unroll
@@ -376,17 +378,30 @@ __global__ __launch_bounds__(256) void cply_pack_kernel(CplyCols c, const unsign
     vertex_out[i] = o;
 }
 
-// SH AC (:236-241): u8( clip((v / 8.0 + 0.5) * 256, 0, 255) ), m columns of the original table -> (n, m) bytes in the new order
-__global__ __launch_bounds__(256) void cply_sh_kernel(const float *__restrict__ cols, int m, int64_t col_stride,
+// SH AC (:236-241): u8( clip((v / 8.0 + 0.5) * 256, 0, 255) ), m columns of the original table -> (n, m) bytes in the new order.
+// Coefficient c of splat s is cols[c * col_stride + s * elem_stride]: contiguous columns (col_stride >= n, elem_stride 1) or the
+// consecutive f_rest fields of raw rows (col_stride 1, elem_stride = row_bytes / 4).  Round 6: lane = coefficient, a wave walks
+// its 64 splats (one 180-byte read per splat in row mode), the block's 256 x m bytes leave LDS as whole dwords -- rounds 3-5
+// had every thread store its 45 bytes one by one, 45 bytes apart from its neighbour's.
+__global__ __launch_bounds__(256) void cply_sh_kernel(const float *__restrict__ cols, int m, int64_t col_stride, int64_t elem_stride,
                                                       const unsigned *__restrict__ order, int64_t n, uint8_t *__restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t s = order ? order[i] : (size_t)i;
-    for (int cidx = 0; cidx < m; ++cidx) {
-        const float t = __fmul_rn(__fadd_rn(__fmul_rn(cols[(size_t)cidx * col_stride + s], 0.125f), 0.5f), 256.0f);
-        out[(size_t)i * m + cidx] = (uint8_t)fminf(fmaxf(t, 0.0f), 255.0f);
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[256 * 48];
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int rows_here = (int)min((int64_t)256, n - i0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv * 64; r < min(rows_here, wv * 64 + 64); ++r) {
+        const size_t s = order ? order[i0 + r] : (size_t)(i0 + r);   // wave-uniform
+        if (lane < m) {
+            const float t = __fmul_rn(__fadd_rn(__fmul_rn(cols[(size_t)lane * col_stride + s * elem_stride], 0.125f), 0.5f), 256.0f);
+            s_out[r * m + lane] = (uint8_t)fminf(fmaxf(t, 0.0f), 255.0f);
+        }
     }
+    __syncthreads();
+    const int total = rows_here * m;
+    uint8_t *dst = out + (size_t)i0 * m;   // 256 m bytes per block: dword aligned for every m
+    for (int e = threadIdx.x * 4; e < (total & ~3); e += 256 * 4) *reinterpret_cast<unsigned *>(dst + e) = *reinterpret_cast<const unsigned *>(s_out + e);
+    if (threadIdx.x < (total & 3)) dst[(total & ~3) + threadIdx.x] = s_out[(total & ~3) + threadIdx.x];
 }
 
 }  // namespace gsx
@@ -409,6 +424,12 @@ int gsx_morton_order_dev(gsx_ctx *c, const float *x, const float *y, const float
 int gsx_cply_pack_dev(gsx_ctx *c, const float *const *cols14_dev, const uint32_t *order_dev, int64_t n, float *chunk_out_dev,
                       uint32_t *vertex_out_dev)
 {
+    return gsx_cply_pack_strided_dev(c, cols14_dev, nullptr, order_dev, n, chunk_out_dev, vertex_out_dev);
+}
+
+int gsx_cply_pack_strided_dev(gsx_ctx *c, const float *const *cols14_dev, const int64_t *strides14, const uint32_t *order_dev, int64_t n,
+                              float *chunk_out_dev, uint32_t *vertex_out_dev)
+{
     if (!c || !cols14_dev || (n > 0 && (!chunk_out_dev || !vertex_out_dev))) GSX_FAIL("gsx_cply_pack_dev: null argument");
     if (n < 0 || n >= (1LL << 32)) GSX_FAIL("gsx_cply_pack_dev: bad size");
     if (reinterpret_cast<uintptr_t>(vertex_out_dev) & 15) GSX_FAIL("gsx_cply_pack_dev: vertex output must be 16-byte aligned");
@@ -418,6 +439,8 @@ int gsx_cply_pack_dev(gsx_ctx *c, const float *const *cols14_dev, const uint32_t
     for (int a = 0; a < 14; ++a) {
         if (!cols14_dev[a]) GSX_FAIL("gsx_cply_pack_dev: column %d is null", a);
         cc.col[a] = cols14_dev[a];
+        cc.stride[a] = strides14 ? strides14[a] : 1;
+        if (cc.stride[a] < 1) GSX_FAIL("gsx_cply_pack_strided_dev: stride %d must be >= 1", a);
     }
     hipLaunchKernelGGL(cply_pack_kernel, dim3((unsigned)div_up(n, (int64_t)CPLY_CHUNK)), dim3(256), 0, c->stream, cc, order_dev, n,
                        chunk_out_dev, reinterpret_cast<uint4 *>(vertex_out_dev));
@@ -428,11 +451,20 @@ int gsx_cply_pack_dev(gsx_ctx *c, const float *const *cols14_dev, const uint32_t
 int gsx_cply_sh_dev(gsx_ctx *c, const float *cols_dev, int m, int64_t col_stride, const uint32_t *order_dev, int64_t n,
                     uint8_t *out_dev)
 {
+    if (n > 0 && col_stride < n) GSX_FAIL("gsx_cply_sh_dev: bad size");
+    return gsx_cply_sh_strided_dev(c, cols_dev, m, col_stride, 1, order_dev, n, out_dev);
+}
+
+int gsx_cply_sh_strided_dev(gsx_ctx *c, const float *cols_dev, int m, int64_t col_stride, int64_t elem_stride, const uint32_t *order_dev,
+                            int64_t n, uint8_t *out_dev)
+{
     if (!c || (n > 0 && m > 0 && (!cols_dev || !out_dev))) GSX_FAIL("gsx_cply_sh_dev: null argument");
-    if (n < 0 || n >= (1LL << 32) || m < 0 || m > 45 || col_stride < n) GSX_FAIL("gsx_cply_sh_dev: bad size");
+    if (n < 0 || n >= (1LL << 32) || m < 0 || m > 45 || col_stride < 1 || elem_stride < 1) GSX_FAIL("gsx_cply_sh_dev: bad size");
+    if (reinterpret_cast<uintptr_t>(out_dev) & 3) GSX_FAIL("gsx_cply_sh_dev: output must be 4-byte aligned");
     GSX_HIP(hipSetDevice(c->device));
     if (n == 0 || m == 0) return 0;
-    hipLaunchKernelGGL(cply_sh_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, cols_dev, m, col_stride, order_dev, n, out_dev);
+    hipLaunchKernelGGL(cply_sh_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, cols_dev, m, col_stride, elem_stride, order_dev, n,
+                       out_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

@@ -377,6 +377,13 @@ int staged_copy(gsx_ctx *c, char *dev, char *host, size_t bytes, bool upload)
                           upload ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
         return 0;
     }
+    if (!upload) {
+        // the destination is usually a fresh allocation: ask for huge pages before the lanes first touch it (a hint; 4 KiB
+        // first-touch faults otherwise dominate the drain, as in gsx_host_take_rows)
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(host) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(host) + bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
     const unsigned hw = std::thread::hardware_concurrency();
     const int lanes = (int)std::max<size_t>(1, std::min<size_t>({(size_t)STAGE_LANES_MAX, (size_t)(hw ? hw : 4), bytes / (2 * STAGE_CHUNK)}));
     int rc = stage_prepare(c->device, lanes);

@@ -562,6 +562,15 @@ int gsx_cply_pack_dev(gsx_ctx *ctx, const float *const *cols14_dev, const uint32
  * of col_stride floats each (m <= 45), out_dev = (n, m) bytes = the reference's `sh` element */
 int gsx_cply_sh_dev(gsx_ctx *ctx, const float *cols_dev, int m, int64_t col_stride, const uint32_t *order_dev, int64_t n,
                     uint8_t *out_dev);
+/* Round 6: the same two packers on RAW ROWS resident in HBM (the table uploaded once, no column gather on the host): column a of
+ * splat s is cols14_dev[a][s * strides14[a]] (strides14: HOST array, 1 = a contiguous column such as the numpy-computed alpha,
+ * row_bytes / 4 = a field inside the rows; NULL = all 1); coefficient c of splat s is cols_dev[c * col_stride + s * elem_stride]
+ * (the consecutive f_rest fields of a row: col_stride 1, elem_stride = row_bytes / 4).  gsx_morton_order_dev takes its stride
+ * argument the same way.  out_dev of the SH packer must be 4-byte aligned. */
+int gsx_cply_pack_strided_dev(gsx_ctx *ctx, const float *const *cols14_dev, const int64_t *strides14, const uint32_t *order_dev,
+                              int64_t n, float *chunk_out_dev, uint32_t *vertex_out_dev);
+int gsx_cply_sh_strided_dev(gsx_ctx *ctx, const float *cols_dev, int m, int64_t col_stride, int64_t elem_stride,
+                            const uint32_t *order_dev, int64_t n, uint8_t *out_dev);
 
 #ifdef __cplusplus
 }

@@ -129,3 +129,31 @@ def test_write_compressed_ply_file(gsx, writer, tmp_path, gold):
     assert head.count(b"property uchar f_rest_") == 9
     v = np.frombuffer(body[4 * 72:4 * 72 + 777 * 16], dtype=np.uint32).reshape(-1, 4)
     np.testing.assert_array_equal(v, gold[tag + "/vertex_stable"])
+
+
+def test_pack_table_from_device_resident_rows_equals_the_host_gather_path(gsx):
+    """round 6: the writer uploads the raw rows once and cuts its 59 columns out of them on the device
+    (gsx_rows_to_columns_dev); tables it does not take, and calls with a caller's context, gather on the host as in round 5.
+    Same kernels downstream: every output identical -- also for 251-byte rows (host path) and against the oracle."""
+    lib = gsx._lib
+    from oracle import cply as ocply
+    for n, seed, kind in ((5000, 1, "clustered"), (70001, 2, "plain"), (12000, 3, "clustered")):
+        scene = ocply.cply_scene(n, seed, kind)
+        sh_names = [nm for nm in scene.dtype.names if nm.startswith("f_rest_")]
+        a = lib.cply_pack_table(scene, sh_names)                      # device-resident rows (n >= 4096, float32 fields)
+        ctx = lib.Context(0)
+        b = lib.cply_pack_table(scene, sh_names, ctx=ctx)             # a caller's context: the host gather path
+        ctx.close()
+        for u, v in zip(a[:4], b[:4]):
+            if u is None:
+                assert v is None
+            else:
+                np.testing.assert_array_equal(np.asarray(u).view(np.uint8), np.asarray(v).view(np.uint8))
+        want_order, _ = ocply.morton_order(scene["x"], scene["y"], scene["z"])
+        oc, ov, osh = ocply.encode(scene, want_order, sh_names)
+        np.testing.assert_array_equal(a[3], want_order)
+        np.testing.assert_array_equal(a[1], ov)
+        np.testing.assert_array_equal(a[0].view(np.uint32), oc.view(np.uint32))
+        if sh_names:
+            np.testing.assert_array_equal(a[2], osh)
+    lib.release_arenas()
