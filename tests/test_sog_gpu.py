@@ -324,3 +324,33 @@ def test_device_resident_core_degenerate_axes_and_wide_ranges(gsx):
         _check_core_against_numpy(core, data, 4)
     st = core["stats"]
     assert st["uncertain_alpha"] <= 0.005 * n and st["uncertain_positions"] <= 0.2 * 3 * n, st
+
+
+def test_device_resident_core_takes_any_field_layout(gsx):
+    """fields in another order with foreign fields in between (the device reads each float32 field at its own offset), and rows
+    longer than the 512 bytes the device tile holds (packed by one host pass): the same images as the standard table"""
+    w = _sog_writer()
+    src = datasets.sog_scene(20011, 71)
+    names = list(src.dtype.names)
+    rng = np.random.default_rng(71)
+    shuffled = [names[i] for i in rng.permutation(len(names))]
+    descr = []
+    for i, nm in enumerate(shuffled):
+        descr.append((nm, "f4"))
+        if i % 7 == 3:
+            descr.append(("pad_%d" % i, "i4"))
+    mixed = np.zeros(len(src), dtype=descr)
+    long_rows = np.zeros(len(src), dtype=descr + [("blob", "f4", (80,))])
+    assert mixed.dtype.itemsize % 4 == 0 and mixed.dtype.itemsize <= 512 < long_rows.dtype.itemsize
+    for nm in names:
+        mixed[nm] = src[nm]
+        long_rows[nm] = src[nm]
+    outs = []
+    for tab in (src, mixed, long_rows):
+        np.random.seed(9)
+        outs.append(w.encode(tab, 3, device_resident=True))
+    for other in outs[1:]:
+        assert other["bands"] == outs[0]["bands"] and other["palette"] == outs[0]["palette"]
+        for name in outs[0]["textures"]:
+            np.testing.assert_array_equal(other["textures"][name], outs[0]["textures"][name], err_msg=name)
+        np.testing.assert_array_equal(other["shn_centroid_index"], outs[0]["shn_centroid_index"])
