@@ -354,3 +354,32 @@ def test_device_resident_core_takes_any_field_layout(gsx):
         for name in outs[0]["textures"]:
             np.testing.assert_array_equal(other["textures"][name], outs[0]["textures"][name], err_msg=name)
         np.testing.assert_array_equal(other["shn_centroid_index"], outs[0]["shn_centroid_index"])
+
+
+def _sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("name", ["sog_120k_l5", "sog_60k_l0_bands2", "sog_40k_l9_lattice", "sog_30k_l3_bands1"])
+def test_device_resident_core_against_reference_run_hashes(gsx, name):
+    """tests/golden/sog_ref_hashes.json: what the UN-PATCHED reference's SogFormat.write put into its bundle for these tables
+    (oracle/make_golden_sog.py, run in the build container) -- a larger scene, band downgrades to 2 and 1, lattice coordinates with
+    ties and signed zeros.  Every init-independent texture (padding included), the means' min / max, the detected bands and the
+    palette size of the device-resident core must be the reference's."""
+    from oracle import make_golden_sog as mgs
+    with open(os.path.join(GOLDEN_DIR, "sog_ref_hashes.json")) as f:
+        case = json.load(f)[name]
+    data = mgs.build(case)
+    w = _sog_writer()
+    np.random.seed(case["np_seed"])
+    core = w.encode(data, case["level"], device_resident=True)
+    tex = core["textures"]
+    assert len(tex["means_l"]) == case["texels"]
+    assert _sha16(tex["means_l"]) == case["sha"]["means_l"] and _sha16(tex["means_u"]) == case["sha"]["means_u"]
+    assert _sha16(tex["quats"]) == case["sha"]["quats"]
+    assert _sha16(tex["sh0"][:, 3]) == case["sha"]["sh0_alpha"] and _sha16(tex["scales"][:, 3]) == case["sha"]["scales_alpha"]
+    assert [float(m) for m in core["mins"]] == case["means"]["mins"] and [float(m) for m in core["maxs"]] == case["means"]["maxs"]
+    assert core["bands"] == case["bands"] and core.get("palette", 0) == case["palette"]
+    if case["sha"]["labels_pad_alpha"] is not None:
+        assert _sha16(tex["shN_labels"][case["n"]:, 3]) == case["sha"]["labels_pad_alpha"]
+        assert not tex["shN_labels"][case["n"]:].any()      # np.zeros in the reference (sog.py:598); see the fixture's note on alpha 0
