@@ -833,7 +833,7 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
     m = len(sh_names)
     names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS] + sh_names
     fields = data.dtype.fields or {}
-    resident = (ctx is None and n >= 4096 and data.ndim == 1 and data.flags.c_contiguous and data.dtype.itemsize % 4 == 0
+    resident = (ctx is None and n >= 1024 and data.ndim == 1 and data.flags.c_contiguous and data.dtype.itemsize % 4 == 0
                 and all(nm in fields and fields[nm][0] == np.dtype("<f4") and fields[nm][1] % 4 == 0 for nm in names)
                 and all(fields[sh_names[i]][1] == fields[sh_names[0]][1] + 4 * i for i in range(m)))
     nchunks = (n + 255) // 256

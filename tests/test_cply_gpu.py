@@ -140,7 +140,7 @@ def test_pack_table_from_device_resident_rows_equals_the_host_gather_path(gsx):
     for n, seed, kind in ((5000, 1, "clustered"), (70001, 2, "plain"), (12000, 3, "clustered")):
         scene = ocply.cply_scene(n, seed, kind)
         sh_names = [nm for nm in scene.dtype.names if nm.startswith("f_rest_")]
-        a = lib.cply_pack_table(scene, sh_names)                      # device-resident rows (n >= 4096, float32 fields)
+        a = lib.cply_pack_table(scene, sh_names)                      # device-resident rows (n >= 1024, float32 fields)
         ctx = lib.Context(0)
         b = lib.cply_pack_table(scene, sh_names, ctx=ctx)             # a caller's context: the host gather path
         ctx.close()
