@@ -182,6 +182,7 @@ SIGNATURES = {
     "gsx_cply_pack_dev": (_I, [_P, _P, _P, _I64, _P, _P]),
     "gsx_cply_sh_dev": (_I, [_P, _P, _I, _I64, _P, _I64, _P]),
     "gsx_cply_pack_strided_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P]),
+    "gsx_cply_pack_opacity_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _I64, _P]),
     "gsx_cply_sh_strided_dev": (_I, [_P, _P, _I, _I64, _I64, _P, _I64, _P]),
     "gsx_density_voxels_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _I64, _I64, C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "gsx_density_mask_dev": (_I, [_P, _P, _P, _P, _I64, _I64, _D, _P, _I64, _P]),
@@ -797,33 +798,13 @@ def cply_pack(columns: dict, order: "np.ndarray | None", sh_columns=(), ctx: "Co
             ctx.close()
 
 
-def _sigmoid_f32_threaded(x: np.ndarray) -> np.ndarray:
-    """numpy's own `1.0 / (1.0 + np.exp(-x))` on float32 (formats/compressed_ply.py:200-203), slices of the array on a few threads
-    (the ufuncs release the GIL; the value of an element does not depend on where in an array it sits)"""
-    n = len(x)
-    out = np.empty(n, dtype=np.float32)
-    nt = max(1, min(16, (os.cpu_count() or 1) // 2, n // 200_000))
-
-    def run(t):
-        a, b = n * t // nt, n * (t + 1) // nt
-        with np.errstate(over="ignore"):
-            out[a:b] = 1.0 / (1.0 + np.exp(-x[a:b]))
-    if nt == 1:
-        run(0)
-    else:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(nt) as ex:
-            list(ex.map(run, range(nt)))
-    return out
-
-
 def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = None, ctx: "Context | None" = None, stage_ms: "dict | None" = None):
     """The compressed-PLY writer's numeric core on a whole splat table (formats/compressed_ply.py:200-297).  Round 6: the raw rows
     are uploaded ONCE (gsx_dev_upload_staged) and the Morton sort, the chunk packers and the SH packer read their fields straight
     out of them (element stride = row_bytes / 4: gsx_cply_pack_strided_dev / gsx_cply_sh_strided_dev) -- round 5 gathered the 59
-    columns on the host (one threaded pass, 472 MB of freshly faulted pages per 2M splats) and uploaded that.  numpy's sigmoid of
-    the opacity (the reference's expression, so its bits) is evaluated on ONE gathered column, on a few threads, and uploaded as
-    the one contiguous column; results come back through the staging lanes.  Tables the row path does not take (fields that are
+    columns on the host (one threaded pass, 472 MB of freshly faulted pages per 2M splats) and uploaded that.  The alpha byte comes
+    from the opacity field on the device (float64 exp + the rounding certificate of the SOG textures; numpy's own sigmoid only for
+    the ~1e-4 listed splats: gsx_cply_pack_opacity_dev); results come back through the staging lanes.  Tables the row path does not take (fields that are
     not float32, rows that are not a multiple of 4 bytes, f_rest fields that are not consecutive) and calls with a caller's
     context gather their columns on the host as before.
     -> (chunks (ceil(n/256), 18) f32, vertices (n, 4) u32, sh (n, m) u8 or None, order u32[n], recursion levels or None)"""
@@ -863,12 +844,10 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
             d_rows = alloc(data.nbytes, "rows")
             check(lib.gsx_dev_upload_staged(ctx.handle, d_rows.ptr, data.ctypes.data, data.nbytes), "gsx_dev_upload_staged")
             mark("upload")
-            alpha = _sigmoid_f32_threaded(host_gather_columns(data, ["opacity"])[0])
-            d_alpha = alloc(4 * n, "alpha")
-            check(lib.gsx_dev_upload(ctx.handle, d_alpha.ptr, alpha.ctypes.data, alpha.nbytes), "gsx_dev_upload")
-            mark("sigmoid_host")
-            col = lambda i: d_alpha.ptr if i == 9 else d_rows.ptr + int(fields[names[i]][1])
-            strides = (_I64 * 14)(*[1 if i == 9 else rd for i in range(14)])
+            # (round 6: the sigmoid's byte is decided on the device from the opacity field, with a rounding certificate; numpy only
+            #  evaluates the listed ~1e-4 of the splats, below)
+            col = lambda i: d_rows.ptr + int(fields[names[i]][1])
+            strides = (_I64 * 14)(*([rd] * 14))
             xyz_stride, sh_ptr, sh_col_stride, sh_elem_stride = rd, (d_rows.ptr + int(fields[sh_names[0]][1])) if m else None, 1, rd
         else:
             mat = host_gather_columns(data, names)                     # (14 + m, n), row 9 = opacity
@@ -892,7 +871,10 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
             d_order.upload(order)
         ptrs = (C.c_void_p * 14)(*[col(i) for i in range(14)])
         d_chunk, d_vert = alloc(72 * nchunks, "chunk"), alloc(16 * n, "vert")
-        check(lib.gsx_cply_pack_strided_dev(ctx.handle, ptrs, strides, d_order.ptr, n, d_chunk.ptr, d_vert.ptr), "gsx_cply_pack_strided_dev")
+        unc_cap = n // 64 + 4096
+        d_list, d_cnt = (alloc(8 * unc_cap, "unc"), alloc(16, "unc_count")) if resident else (None, None)
+        check(lib.gsx_cply_pack_opacity_dev(ctx.handle, ptrs, strides, d_order.ptr, n, d_chunk.ptr, d_vert.ptr, d_list.ptr if resident else None,
+                                            unc_cap if resident else 0, d_cnt.ptr if resident else None), "gsx_cply_pack_opacity_dev")
         d_out = None
         if m:
             d_out = alloc(n * m, "sh")
@@ -907,6 +889,20 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
             if m:
                 check(dl(ctx.handle, sh.ctypes.data, d_out.ptr, sh.nbytes), "gsx_dev_download")
         mark("download")
+        if resident:
+            m_unc = int(d_cnt.download(np.uint32, 1)[0])
+            if m_unc > unc_cap:      # (thousands of opacities beyond +-80, or NaNs: numpy's expression for the whole column)
+                pos = np.arange(n, dtype=np.int64)
+                x = np.ascontiguousarray(data["opacity"])[order]
+            else:
+                lst = d_list.download(np.uint32, 2 * m_unc).reshape(m_unc, 2) if m_unc else np.zeros((0, 2), np.uint32)
+                pos, x = lst[:, 0].astype(np.int64), lst[:, 1].copy().view(np.float32)
+            if len(pos):
+                with np.errstate(all="ignore"):
+                    a = 1.0 / (1.0 + np.exp(-x))                                               # :200-203
+                    byte = np.clip(np.floor(a * 255 + 0.5), 0, 255).astype(np.uint32)       # :312
+                verts[pos, 3] = (verts[pos, 3] & np.uint32(0xffffff00)) | byte
+            mark("host_patch")
         return chunks, verts, sh, order, levels
     except GsxError:
         if ar is not None:

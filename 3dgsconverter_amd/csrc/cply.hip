@@ -24,6 +24,7 @@
 #include <rocprim/device/device_select.hpp>
 
 #include "gsx_common.h"
+#include "sog_math.h"
 
 namespace gsx {
 
@@ -313,8 +314,30 @@ __device__ __forceinline__ unsigned pack_quat(float q0, float q1, float q2, floa
     return res;
 }
 
+// alpha byte of the packed colour from the OPACITY (round 6): the reference evaluates `1.0 / (1.0 + np.exp(-x))` with numpy's float32
+// SIMD exp (not correctly rounded: <= 2.52 ulp), then floor(a * 255 + 0.5) (:200-203, :312).  As for the SOG textures (sog_math.h):
+// exp in float64, both ends of the bracket of numpy's possible float32 result through numpy's exact float32 sequence; equal codes
+// -> certain, else the splat goes on a short list and the host patches the byte with numpy's own expression.
+__device__ __forceinline__ unsigned cply_alpha_code(float x, bool *ok_out)
+{
+    const double et = ::exp(-(double)x);
+    bool ok = (x == x) && fabsf(x) < 80.0f;
+    const float a = ok ? (float)et : 1.0f;
+    const float e[2] = {ulp_step(a, -SOG_ULPS_EXP), ulp_step(a, SOG_ULPS_EXP)};
+    unsigned q[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float r = __fdiv_rn(1.0f, __fadd_rn(1.0f, e[s]));
+        q[s] = (unsigned)fminf(fmaxf(floorf(__fadd_rn(__fmul_rn(r, 255.0f), 0.5f)), 0.0f), 255.0f);
+    }
+    *ok_out = ok && q[0] == q[1];
+    return q[0];
+}
+
 __global__ __launch_bounds__(256) void cply_pack_kernel(CplyCols c, const unsigned *__restrict__ order, int64_t n,
-                                                        float *__restrict__ chunk_out, uint4 *__restrict__ vertex_out)
+                                                        float *__restrict__ chunk_out, uint4 *__restrict__ vertex_out,
+                                                        uint2 *__restrict__ unc_list /* null: column 9 is numpy's alpha */, unsigned unc_cap,
+                                                        unsigned *__restrict__ unc_count)
 {
     __shared__ float s_part[4][18];
     __shared__ float s_box[18];
@@ -372,7 +395,17 @@ __global__ __launch_bounds__(256) void cply_pack_kernel(CplyCols c, const unsign
     o.x = (quant_unit(v[0], lo[0], hi[0], 2047.0f) << 21) | (quant_unit(v[1], lo[1], hi[1], 1023.0f) << 11) | quant_unit(v[2], lo[2], hi[2], 2047.0f);
     o.y = pack_quat(rq[0], rq[1], rq[2], rq[3]);
     o.z = (quant_unit(v[3], lo[3], hi[3], 2047.0f) << 21) | (quant_unit(v[4], lo[4], hi[4], 1023.0f) << 11) | quant_unit(v[5], lo[5], hi[5], 2047.0f);
-    const unsigned na = (unsigned)fminf(fmaxf(floorf(__fadd_rn(__fmul_rn(al, 255.0f), 0.5f)), 0.0f), 255.0f);   // :312
+    unsigned na;
+    if (unc_list) {   // column 9 is the opacity itself
+        bool ok;
+        na = cply_alpha_code(al, &ok);
+        if (!ok) {
+            const unsigned p = atomicAdd(unc_count, 1u);
+            if (p < unc_cap) unc_list[p] = make_uint2((unsigned)i, __float_as_uint(al));
+        }
+    } else {
+        na = (unsigned)fminf(fmaxf(floorf(__fadd_rn(__fmul_rn(al, 255.0f), 0.5f)), 0.0f), 255.0f);   // :312
+    }
     o.w = (quant_unit(v[6], lo[6], hi[6], 255.0f) << 24) | (quant_unit(v[7], lo[7], hi[7], 255.0f) << 16) |
           (quant_unit(v[8], lo[8], hi[8], 255.0f) << 8) | na;
     vertex_out[i] = o;
@@ -430,6 +463,13 @@ int gsx_cply_pack_dev(gsx_ctx *c, const float *const *cols14_dev, const uint32_t
 int gsx_cply_pack_strided_dev(gsx_ctx *c, const float *const *cols14_dev, const int64_t *strides14, const uint32_t *order_dev, int64_t n,
                               float *chunk_out_dev, uint32_t *vertex_out_dev)
 {
+    return gsx_cply_pack_opacity_dev(c, cols14_dev, strides14, order_dev, n, chunk_out_dev, vertex_out_dev, nullptr, 0, nullptr);
+}
+
+int gsx_cply_pack_opacity_dev(gsx_ctx *c, const float *const *cols14_dev, const int64_t *strides14, const uint32_t *order_dev, int64_t n,
+                              float *chunk_out_dev, uint32_t *vertex_out_dev, uint32_t *list_dev, int64_t cap, uint32_t *count_dev)
+{
+    if ((list_dev != nullptr) != (count_dev != nullptr) || cap < 0 || cap > 0xffffffffLL) GSX_FAIL("gsx_cply_pack_opacity_dev: list and counter come together");
     if (!c || !cols14_dev || (n > 0 && (!chunk_out_dev || !vertex_out_dev))) GSX_FAIL("gsx_cply_pack_dev: null argument");
     if (n < 0 || n >= (1LL << 32)) GSX_FAIL("gsx_cply_pack_dev: bad size");
     if (reinterpret_cast<uintptr_t>(vertex_out_dev) & 15) GSX_FAIL("gsx_cply_pack_dev: vertex output must be 16-byte aligned");
@@ -442,8 +482,9 @@ int gsx_cply_pack_strided_dev(gsx_ctx *c, const float *const *cols14_dev, const 
         cc.stride[a] = strides14 ? strides14[a] : 1;
         if (cc.stride[a] < 1) GSX_FAIL("gsx_cply_pack_strided_dev: stride %d must be >= 1", a);
     }
+    if (count_dev) GSX_HIP(hipMemsetAsync(count_dev, 0, 4, c->stream));
     hipLaunchKernelGGL(cply_pack_kernel, dim3((unsigned)div_up(n, (int64_t)CPLY_CHUNK)), dim3(256), 0, c->stream, cc, order_dev, n,
-                       chunk_out_dev, reinterpret_cast<uint4 *>(vertex_out_dev));
+                       chunk_out_dev, reinterpret_cast<uint4 *>(vertex_out_dev), reinterpret_cast<uint2 *>(list_dev), (unsigned)cap, count_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

@@ -571,6 +571,13 @@ int gsx_cply_pack_strided_dev(gsx_ctx *ctx, const float *const *cols14_dev, cons
                               int64_t n, float *chunk_out_dev, uint32_t *vertex_out_dev);
 int gsx_cply_sh_strided_dev(gsx_ctx *ctx, const float *cols_dev, int m, int64_t col_stride, int64_t elem_stride,
                             const uint32_t *order_dev, int64_t n, uint8_t *out_dev);
+/* ... with column 9 = the OPACITY itself (compressed_ply.py:200-203 `1.0 / (1.0 + np.exp(-x))`, then :312 floor(a * 255 + 0.5)): the
+ * alpha byte comes from a float64 exp + the rounding certificate of gsx_sog_alpha; list_dev receives `cap` entries of two uint32
+ * (position in the NEW order, bits of the opacity) for the ~1e-4 splats whose byte the caller patches with numpy's own expression
+ * (`vertex[pos, 3] = vertex[pos, 3] & ~0xff | byte`); *count_dev (zeroed by the call) keeps counting past cap */
+int gsx_cply_pack_opacity_dev(gsx_ctx *ctx, const float *const *cols14_dev, const int64_t *strides14, const uint32_t *order_dev,
+                              int64_t n, float *chunk_out_dev, uint32_t *vertex_out_dev, uint32_t *list_dev, int64_t cap,
+                              uint32_t *count_dev);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,12 @@ def test_pack_table_from_device_resident_rows_equals_the_host_gather_path(gsx):
     from oracle import cply as ocply
     for n, seed, kind in ((5000, 1, "clustered"), (70001, 2, "plain"), (12000, 3, "clustered")):
         scene = ocply.cply_scene(n, seed, kind)
+        # opacities ON the rounding boundaries of the alpha byte (floor(a * 255 + 0.5) steps at a = (j + 0.5) / 255), far tails, zeros:
+        # the device decides the byte from a float64 exp + certificate and lists what it cannot decide for numpy
+        aa = (np.arange(0, 255, dtype=np.float64) + 0.5) / 255.0
+        edge = np.log(aa / (1 - aa)).astype(np.float32)
+        scene["opacity"][:len(edge)] = edge
+        scene["opacity"][len(edge):len(edge) + 8] = [0.0, -0.0, 90.0, -90.0, 17.0, -17.0, 1e-8, -1e-8]
         sh_names = [nm for nm in scene.dtype.names if nm.startswith("f_rest_")]
         a = lib.cply_pack_table(scene, sh_names)                      # device-resident rows (n >= 1024, float32 fields)
         ctx = lib.Context(0)
