@@ -304,7 +304,7 @@ int stage_prepare(int device, int lanes)
 constexpr size_t REG_CHUNK = 32u << 20;
 constexpr int REG_LANES = 6;
 
-int register_upload(gsx_ctx *c, char *dev, char *host, size_t bytes)
+int register_copy(gsx_ctx *c, char *dev, char *host, size_t bytes, bool upload)
 {
     if (g_stage_busy.test_and_set()) return 1;
     int rc = stage_prepare(c->device, REG_LANES);   // (the lanes' streams and events; their pinned buffers stay unused here)
@@ -341,7 +341,8 @@ int register_upload(gsx_ctx *c, char *dev, char *host, size_t bytes)
                     break;
                 }
                 held[b] = src;
-                if (hipMemcpyAsync(dev + (cut[ch] - a0), src, len, hipMemcpyHostToDevice, s.stream) != hipSuccess) failed = 1;
+                if ((upload ? hipMemcpyAsync(dev + (cut[ch] - a0), src, len, hipMemcpyHostToDevice, s.stream)
+                            : hipMemcpyAsync(src, dev + (cut[ch] - a0), len, hipMemcpyDeviceToHost, s.stream)) != hipSuccess) failed = 1;
                 if (hipEventRecord(s.ev[b], s.stream) != hipSuccess) failed = 1;
             }
             if (hipStreamSynchronize(s.stream) != hipSuccess) failed = 1;
@@ -366,11 +367,22 @@ int staged_copy(gsx_ctx *c, char *dev, char *host, size_t bytes, bool upload)
     }
     if (upload && bytes >= 8 * REG_CHUNK && !(mode_env && !strcmp(mode_env, "lanes"))) {
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = register_upload(c, dev, host, bytes);
+        const int rc = register_copy(c, dev, host, bytes, true);
         if (dbg) fprintf(stderr, "[gsx] upload of %zu MiB through pinned-in-place chunks: rc %d, %.1f GB/s\n", bytes >> 20, rc,
                          (double)bytes / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 1e9);
         if (rc == 0) return 0;
         // (a range the driver would not pin: the staging lanes below take the whole transfer again)
+    }
+    // downloads of >= 128 MiB: the DESTINATION pinned in place, chunk by chunk, like the upload's source -- 54 GB/s into a result
+    // array whose pages a helper thread touched while the device worked (_lib.prefault), against 26-34 GB/s through the staging
+    // lanes (429 + 152 MiB of compressed-PLY elements: 11.4 ms against 18-24).  GSX_DOWNLOAD_MODE=lanes: A/B.
+    static const char *dmode_env = getenv("GSX_DOWNLOAD_MODE");
+    if (!upload && bytes >= 4 * REG_CHUNK && !(dmode_env && !strcmp(dmode_env, "lanes"))) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = register_copy(c, dev, host, bytes, false);
+        if (dbg) fprintf(stderr, "[gsx] download of %zu MiB into pages pinned in place: rc %d, %.1f GB/s\n", bytes >> 20, rc,
+                         (double)bytes / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 1e9);
+        if (rc == 0) return 0;
     }
     if (bytes < 4 * STAGE_CHUNK || g_stage_busy.test_and_set()) {   // small, or another thread is inside: the plain copy
         GSX_HIP(hipMemcpy(upload ? (void *)dev : (void *)host, upload ? (void *)host : (void *)dev, bytes,

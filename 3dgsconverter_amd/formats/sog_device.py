@@ -159,6 +159,10 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
 
     out = {"n": n, "width": width, "height": height, "textures": {}, "stats": {}}
     try:
+        n_img = 5 + (1 if coeffs_present else 0)
+        host_tex_all = np.empty((n_img, texels, 4), np.uint8)
+        toucher = None      # (touching the result pages during the upload -- _lib.prefault, what the compressed-PLY writer does -- slowed the
+                            #  upload's own page pinning by as much as it saved here, where the download hides behind the palette anyway)
         # ---- the table crosses PCIe once
         d_rows = alloc(rows.nbytes)
         st.mark("alloc_rows")
@@ -267,7 +271,9 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         # ---- SH palette (:496-552) as ONE batched Lloyd call on a worker thread (the C call releases the GIL): while its ~40 ms of
         # kernels run, this thread brings the five finished images back through a second context (its own stream, the staging
         # lanes' DMA engines) and evaluates numpy's log / exp for the listed texels
-        host_tex = np.empty((len(tex_names), texels, 4), np.uint8)
+        host_tex = host_tex_all[:len(tex_names)]      # (one image fewer when the band detection found no SH)
+        if toucher is not None:
+            toucher.join()
         for i, nm in enumerate(tex_names):
             out["textures"][nm] = host_tex[i]
         worker, werr = None, []

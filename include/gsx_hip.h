@@ -130,8 +130,9 @@ int gsx_dev_memset(gsx_ctx *ctx, void *dst_dev, int value, size_t bytes);       
  * PLACE, 32 MiB at a time, by a few lanes that run ahead of the DMA (hipHostRegister on the lane's thread -> hipMemcpyAsync on
  * its stream -> hipHostUnregister two chunks later): link rate on the FIRST copy of a buffer, where hipMemcpy of pageable memory
  * pins, copies, pins ... (24-30 GB/s; its pinned-range cache is emptied by any munmap in the process).  A range the driver will
- * not pin, and every download (the destination is usually a fresh allocation whose pages fault in), goes through lanes that
- * fill / drain one pinned 8 MiB staging buffer while the DMA of their other one is in flight.  Synchronous; waits for the
+ * not pin, and every transfer below 128 / 256 MiB, goes through lanes that fill / drain one pinned 8 MiB staging buffer while the
+ * DMA of their other one is in flight; large downloads pin the DESTINATION in place the same way (touch its pages first:
+ * _lib.prefault does that on a helper thread while the device works).  Synchronous; waits for the
  * context's stream first.  What the writers move: the 2.48 GB splat table up, 240 MB of texels down. */
 int gsx_dev_upload_staged(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gsx_dev_download_staged(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
