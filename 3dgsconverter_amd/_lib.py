@@ -814,6 +814,28 @@ def prefault(*arrays):
     return th
 
 
+def file_backed(a) -> bool:
+    """is this array a view of a memory-mapped FILE (np.memmap, np.frombuffer over an mmap)?  Pinning such pages in place would
+    either fail (read-only mapping) or, for a copy-on-write mapping, make the kernel copy every page first"""
+    import mmap
+    seen = 0
+    while a is not None and seen < 16:
+        if isinstance(a, (np.memmap, mmap.mmap)):
+            return True
+        a = a.base if isinstance(a, np.ndarray) else (a.obj if isinstance(a, memoryview) else None)
+        seen += 1
+    return False
+
+
+def upload_table(lib, ctx, dev_ptr: int, rows: np.ndarray):
+    """the writers' one upload of a whole table: anonymous memory goes through gsx_dev_upload_staged (pages pinned in place ahead of
+    the DMA), a view of a mapped file through the runtime's plain copy"""
+    if file_backed(rows):
+        check(lib.gsx_dev_upload(ctx.handle, dev_ptr, rows.ctypes.data, rows.nbytes), "gsx_dev_upload")
+    else:
+        check(lib.gsx_dev_upload_staged(ctx.handle, dev_ptr, rows.ctypes.data, rows.nbytes), "gsx_dev_upload_staged")
+
+
 def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = None, ctx: "Context | None" = None, stage_ms: "dict | None" = None):
     """The compressed-PLY writer's numeric core on a whole splat table (formats/compressed_ply.py:200-297).  Round 6: the raw rows
     are uploaded ONCE (gsx_dev_upload_staged) and the Morton sort, the chunk packers and the SH packer read their fields straight
@@ -861,7 +883,7 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
         if resident:
             rd = data.dtype.itemsize // 4
             d_rows = alloc(data.nbytes, "rows")
-            check(lib.gsx_dev_upload_staged(ctx.handle, d_rows.ptr, data.ctypes.data, data.nbytes), "gsx_dev_upload_staged")
+            upload_table(lib, ctx, d_rows.ptr, data)
             mark("upload")
             # (round 6: the sigmoid's byte is decided on the device from the opacity field, with a rounding certificate; numpy only
             #  evaluates the listed ~1e-4 of the splats, below)

@@ -163,10 +163,25 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         host_tex_all = np.empty((n_img, texels, 4), np.uint8)
         toucher = None      # (touching the result pages during the upload -- _lib.prefault, what the compressed-PLY writer does -- slowed the
                             #  upload's own page pinning by as much as it saved here, where the download hides behind the palette anyway)
+        # ---- the write's random draws (the 50 000-scalar samples of the two codebook fits, :392-397 / :436-440, and the palette's
+        # initial centroids) need only n: a helper thread makes them while this one sits in the upload (6-7 ms at 10M splats)
+        rng = _draws()
+        drawn, draw_err = {}, []
+
+        def draw_all():
+            try:
+                for which in ("scales", "sh0"):
+                    drawn[which] = np.ascontiguousarray(rng.choice(3 * n, 50000, replace=False), dtype=np.int64) if 3 * n > 50000 else None
+                if coeffs_present:
+                    drawn["init"] = np.concatenate([s + rng.choice(e - s, k, replace=False) for s, e in bounds]).astype(np.int64)
+            except BaseException as e:
+                draw_err.append(e)
+        drawer = threading.Thread(target=draw_all, name="gsx-sog-draws")
+        drawer.start()
         # ---- the table crosses PCIe once
         d_rows = alloc(rows.nbytes)
         st.mark("alloc_rows")
-        _lib.check(lib.gsx_dev_upload_staged(ctx.handle, d_rows.ptr, rows.ctypes.data, rows.nbytes), "gsx_dev_upload_staged")
+        _lib.upload_table(lib, ctx, d_rows.ptr, rows)
         st.mark("upload")
         d_keys = alloc(12 * n)
         scan = _lib.SogScan()
@@ -240,7 +255,9 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
 
         # ---- scalar codebooks (:392-449): 50 000-sample -> sorted-run solver (the quality of the reference's sklearn path,
         # deterministic: DESIGN.md section 9) -> nearest-entry indices, written as texels
-        rng = _draws()
+        drawer.join()
+        if draw_err:
+            raise draw_err[0]
         d_fit, d_idx, d_cb = alloc(4 * 50000), alloc(8 * 50000), alloc(4 * 256 * 2)
         books = {}
         for which, d_cols in (("scales", d_scale), ("sh0", d_dc)):
@@ -248,8 +265,7 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             m = 3 * n
             fit_ptr, fit_n = d_cols.ptr, m
             if m > 50000:
-                idx = np.ascontiguousarray(rng.choice(m, 50000, replace=False), dtype=np.int64)
-                d_idx.upload(idx)
+                d_idx.upload(drawn[which])
                 _lib.check(lib.gsx_gather_rows_dev(ctx.handle, d_cols.ptr, 1, d_idx.ptr, 50000, d_fit.ptr), "gsx_gather_rows_dev")
                 fit_ptr, fit_n = d_fit.ptr, 50000
             cb_ptr = d_cb.ptr + (0 if which == "scales" else 4 * 256)
@@ -282,7 +298,7 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             status_print(f"SH Clustering: K={plan['target_k']}, Points={n}. Strategy: GPU (HIP gfx950)")
             nprob = len(bounds)
             off = np.array([b[0] for b in bounds] + [n], dtype=np.int64)
-            init_rows = np.concatenate([s + rng.choice(e - s, k, replace=False) for s, e in bounds]).astype(np.int64)
+            init_rows = drawn["init"]
             d_init, d_cent, d_lab = alloc(8 * len(init_rows)), alloc(4 * nprob * k * coeffs), alloc(4 * n + 16)
             d_init.upload(init_rows)
             _lib.check(lib.gsx_gather_rows_dev(ctx.handle, d_sh.ptr, coeffs, d_init.ptr, len(init_rows), d_cent.ptr), "gsx_gather_rows_dev")

@@ -112,3 +112,24 @@ def test_encode_without_a_gpu_fails_loudly():
         pytest.skip("a GPU is present")
     with pytest.raises(lib.GsxError):
         sd.encode(datasets.sog_scene(2000, 1), 0)
+
+
+def test_file_backed_tables_are_recognised(tmp_path):
+    """views of a mapped file take the plain upload (pinning them in place would copy every page of a copy-on-write mapping or
+    fail on a read-only one): np.memmap in every mode, views and reinterpretations of it, np.frombuffer over an mmap"""
+    import mmap
+    a = np.zeros(64, np.float32)
+    assert not lib.file_backed(a) and not lib.file_backed(a[3:]) and not lib.file_backed(a.view(np.uint8)[8:])
+    path = tmp_path / "rows.bin"
+    a.tofile(path)
+    for mode in ("r", "c", "r+"):
+        m = np.memmap(path, dtype=np.float32, mode=mode)
+        assert lib.file_backed(m) and lib.file_backed(m[5:]) and lib.file_backed(np.asarray(m).view(np.uint8))
+        assert not lib.file_backed(np.array(m))          # a copy is anonymous memory again
+        del m
+    with open(path, "r+b") as fh:
+        mm = mmap.mmap(fh.fileno(), 0)
+        b = np.frombuffer(mm, dtype=np.float32)
+        assert lib.file_backed(b) and lib.file_backed(b[1:])
+        del b
+        mm.close()

@@ -383,3 +383,22 @@ def test_device_resident_core_against_reference_run_hashes(gsx, name):
     if case["sha"]["labels_pad_alpha"] is not None:
         assert _sha16(tex["shN_labels"][case["n"]:, 3]) == case["sha"]["labels_pad_alpha"]
         assert not tex["shN_labels"][case["n"]:].any()      # np.zeros in the reference (sog.py:598); see the fixture's note on alpha 0
+
+
+def test_device_resident_core_on_a_memory_mapped_table(gsx, tmp_path):
+    """a table that is a view of a mapped file (np.memmap, copy-on-write and read-only) is uploaded by the plain copy and gives
+    the textures of the same table in anonymous memory"""
+    w = _sog_writer()
+    data = datasets.sog_scene(40000, 77)
+    path = tmp_path / "table.bin"
+    data.tofile(path)
+    np.random.seed(3)
+    want = w.encode(data, 8, device_resident=True)
+    for mode in ("c", "r"):
+        mapped = np.memmap(path, dtype=data.dtype, mode=mode)
+        assert gsx._lib.file_backed(mapped)
+        np.random.seed(3)
+        got = w.encode(mapped, 8, device_resident=True)
+        for name in want["textures"]:
+            np.testing.assert_array_equal(got["textures"][name], want["textures"][name], err_msg="%s %s" % (mode, name))
+        del mapped
