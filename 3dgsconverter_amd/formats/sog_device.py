@@ -232,7 +232,7 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
 
         # ---- positions, rotations
         cap = n // 8 + 4096
-        d_list, d_cnt = alloc(8 * cap), alloc(16)
+        d_list, d_cnt = alloc(8 * cap, "list"), alloc(16)
         # the texel images are slices of ONE device buffer and come back as slices of ONE host array: a single bulk copy
         tex_names = ["means_l", "means_u", "quats", "scales", "sh0"] + (["shN_labels"] if coeffs else [])
         d_tex = alloc(4 * texels * len(tex_names))
@@ -243,11 +243,20 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         tex = {nm: _Slice(i) for i, nm in enumerate(tex_names)}
         mn3, mx3 = np.array(mins, np.float32), np.array(maxs, np.float32)
         amn3, amx3 = np.array(arg_mn, np.float32), np.array(arg_mx, np.float32)
-        _lib.check(lib.gsx_sog_means_texels_dev(ctx.handle, d_pos.ptr, n, texels, mn3.ctypes.data, mx3.ctypes.data, amn3.ctypes.data,
-                                                amx3.ctypes.data, tex["means_l"].ptr,
-                                                tex["means_u"].ptr, d_list.ptr, cap, d_cnt.ptr), "gsx_sog_means_texels_dev")
-        m_pos = int(d_cnt.download(np.uint32, 1)[0])
-        if m_pos > cap:
+        for attempt in range(2):
+            _lib.check(lib.gsx_sog_means_texels_dev(ctx.handle, d_pos.ptr, n, texels, mn3.ctypes.data, mx3.ctypes.data, amn3.ctypes.data,
+                                                    amx3.ctypes.data, tex["means_l"].ptr,
+                                                    tex["means_u"].ptr, d_list.ptr, cap, d_cnt.ptr), "gsx_sog_means_texels_dev")
+            m_pos = int(d_cnt.download(np.uint32, 1)[0])
+            if m_pos <= cap:
+                break
+            # a scene far from the origin on some axis: every log value is large against the axis' range, the +-5 ulp bracket of
+            # numpy's log spans a sizeable part of a texel step and far more than the usual ~1 % of the texels are listed (x in
+            # [10, 30]: ~18 %).  The kernel has counted them: once more with a list that holds them all -- numpy's log of the listed
+            # values on the host is still orders of magnitude cheaper than the host-staged path
+            cap = m_pos + 4096
+            d_list = alloc(8 * cap, "list")
+        else:
             raise NotEligible("too many position texels next to a rounding boundary")
         pos_list = d_list.download(np.uint32, 2 * m_pos).reshape(m_pos, 2) if m_pos else np.zeros((0, 2), np.uint32)
         _lib.check(lib.gsx_sog_quats_texels_dev(ctx.handle, d_rot.ptr, n, texels, tex["quats"].ptr), "gsx_sog_quats_texels_dev")
@@ -275,10 +284,15 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         out["scale_codebook"], out["color_codebook"] = cbs[:256].copy(), cbs[256:].copy()
         _lib.check(lib.gsx_sog_codes_texels_dev(ctx.handle, d_scale.ptr, n, texels, books["scales"], 256, None, tex["scales"].ptr, None, 0, None),
                    "gsx_sog_codes_texels_dev")
-        _lib.check(lib.gsx_sog_codes_texels_dev(ctx.handle, d_dc.ptr, n, texels, books["sh0"], 256, d_op.ptr, tex["sh0"].ptr, d_list.ptr, cap,
-                                                d_cnt.ptr), "gsx_sog_codes_texels_dev")
-        m_al = int(d_cnt.download(np.uint32, 1)[0])
-        if m_al > cap:
+        for attempt in range(2):
+            _lib.check(lib.gsx_sog_codes_texels_dev(ctx.handle, d_dc.ptr, n, texels, books["sh0"], 256, d_op.ptr, tex["sh0"].ptr, d_list.ptr, cap,
+                                                    d_cnt.ptr), "gsx_sog_codes_texels_dev")
+            m_al = int(d_cnt.download(np.uint32, 1)[0])
+            if m_al <= cap:
+                break
+            cap = m_al + 4096          # (opacities that are NaN or beyond +-80 by the million: listed all the same)
+            d_list = alloc(8 * cap, "list")
+        else:
             raise NotEligible("too many alpha texels next to a rounding boundary")
         al_list = d_list.download(np.uint32, 2 * m_al).reshape(m_al, 2) if m_al else np.zeros((0, 2), np.uint32)
         st.mark("codebooks_codes")

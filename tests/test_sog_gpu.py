@@ -402,3 +402,27 @@ def test_device_resident_core_on_a_memory_mapped_table(gsx, tmp_path):
         for name in want["textures"]:
             np.testing.assert_array_equal(got["textures"][name], want["textures"][name], err_msg="%s %s" % (mode, name))
         del mapped
+
+
+def test_device_resident_core_on_a_scene_far_from_the_origin(gsx):
+    """every coordinate large against its axis' range (a capture that is not centred: x in [10, 30], y in [200, 201], z one-sided):
+    the +-5 ulp bracket of numpy's float32 log covers a sizeable part of a texel step, a fifth and more of the position texels
+    are listed as uncertain -- far beyond the first list's capacity.  The core lists them all on a second pass (it used to hand
+    the table to the host-staged path) and stays numpy's bytes"""
+    w = _sog_writer()
+    n = 60000
+    rng = np.random.default_rng(91)
+    data = datasets.sog_scene(n, 91)
+    data["x"] = rng.uniform(10, 30, n).astype(np.float32)
+    data["y"] = rng.uniform(200, 201, n).astype(np.float32)
+    data["z"] = (np.abs(rng.standard_normal(n)) + 4).astype(np.float32)
+    core = w.encode(data, 4, device_resident=True)
+    assert core["stats"]["uncertain_positions"] > n // 8 + 4096, core["stats"]
+    _check_core_against_numpy(core, data, 4)
+    # opacities by the thousand outside the range where the sigmoid's byte can be certified: NaN, +-inf, +-1e30
+    data["opacity"][rng.integers(0, n, 20000)] = np.float32(np.nan)
+    data["opacity"][rng.integers(0, n, 5000)] = np.float32(np.inf)
+    data["opacity"][rng.integers(0, n, 5000)] = np.float32(-1e30)
+    with np.errstate(all="ignore"):
+        core = w.encode(data, 4, device_resident=True)
+        _check_core_against_numpy(core, data, 4)

@@ -31,6 +31,8 @@ def table(n, seed=0):
         elif nm == "opacity":
             v *= np.float32(2.0)
         a[nm] = v
+    if os.environ.get("PROBE_OFFSET"):      # a capture that is not centred on the origin: far more position texels are listed
+        a["x"] += np.float32(float(os.environ["PROBE_OFFSET"]))
     return a
 
 
