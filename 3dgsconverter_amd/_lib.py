@@ -114,6 +114,7 @@ SIGNATURES = {
     "gsx_dev_copy": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
+    "gsx_fields_nonzero_dev": (_I, [_P, _P, _I64, _I64, _I, C.POINTER(C.c_uint64)]),
     "gsx_dev_upload_staged": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download_staged": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
@@ -848,13 +849,23 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
     -> (chunks (ceil(n/256), 18) f32, vertices (n, 4) u32, sh (n, m) u8 or None, order u32[n], recursion levels or None)"""
     lib = require_hip()
     n = len(data)
-    sh_names = list(sh_names)
-    m = len(sh_names)
-    names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS] + sh_names
     fields = data.dtype.fields or {}
+    # sh_names: the list itself, or a function (highest f_rest index holding a non-zero | None) -> list: the writer's degree
+    # detection (compressed_ply.py:139-171), which on resident rows takes the index from ONE device pass (gsx_fields_nonzero_dev)
+    # instead of numpy's `np.any(data[f] != 0)` per strided column (~0.1 s each at 10M splats: more than this whole function)
+    resolve = sh_names if callable(sh_names) else None
+    present = [i for i in range(45) if "f_rest_%d" % i in fields]
+    sh_names = ["f_rest_%d" % i for i in present] if resolve else list(sh_names)
+    m = len(sh_names)
+    base_names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS]
+    names = base_names + sh_names
     resident = (ctx is None and n >= 1024 and data.ndim == 1 and data.flags.c_contiguous and data.dtype.itemsize % 4 == 0
                 and all(nm in fields and fields[nm][0] == np.dtype("<f4") and fields[nm][1] % 4 == 0 for nm in names)
                 and all(fields[sh_names[i]][1] == fields[sh_names[0]][1] + 4 * i for i in range(m)))
+    if resolve and not resident:
+        sh_names = list(resolve(None))          # the host's own scan
+        m = len(sh_names)
+        names = base_names + sh_names
     nchunks = (n + 255) // 256
     own = ctx is None and not resident
     ar = arena(0) if resident else None
@@ -878,13 +889,27 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
         return b
     try:
         verts = np.empty((n, 4), np.uint32)
-        sh = np.empty((n, m), np.uint8) if m else None
+        sh = np.empty((n, m), np.uint8) if m and not (resolve and resident) else None
         toucher = prefault(*(a for a in (verts, sh) if a is not None)) if resident and n >= (1 << 18) else None
+        toucher2 = None
         if resident:
             rd = data.dtype.itemsize // 4
             d_rows = alloc(data.nbytes, "rows")
             upload_table(lib, ctx, d_rows.ptr, data)
             mark("upload")
+            if resolve:
+                word = C.c_uint64(0)
+                if m:
+                    check(lib.gsx_fields_nonzero_dev(ctx.handle, d_rows.ptr + int(fields[sh_names[0]][1]), rd, n, m, C.byref(word)),
+                          "gsx_fields_nonzero_dev")
+                active = [present[j] for j in range(m) if (word.value >> j) & 1]
+                sh_names = list(resolve(max(active) if active else -1))
+                m = len(sh_names)
+                names = base_names + sh_names
+                sh = np.empty((n, m), np.uint8) if m else None
+                if sh is not None and toucher is not None:
+                    toucher2 = prefault(sh)
+                mark("sh_detect")
             # (round 6: the sigmoid's byte is decided on the device from the opacity field, with a rounding certificate; numpy only
             #  evaluates the listed ~1e-4 of the splats, below)
             col = lambda i: d_rows.ptr + int(fields[names[i]][1])
@@ -922,8 +947,9 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
             check(lib.gsx_cply_sh_strided_dev(ctx.handle, sh_ptr, m, sh_col_stride, sh_elem_stride, d_order.ptr, n, d_out.ptr), "gsx_cply_sh_strided_dev")
         mark("pack")
         chunks = d_chunk.download(np.float32, 18 * nchunks).reshape(nchunks, 18)
-        if toucher is not None:
-            toucher.join()
+        for th in (toucher, toucher2):
+            if th is not None:
+                th.join()
         dl = lib.gsx_dev_download_staged if resident else lib.gsx_dev_download
         if n:
             check(dl(ctx.handle, verts.ctypes.data, d_vert.ptr, verts.nbytes), "gsx_dev_download")

@@ -183,7 +183,7 @@ void gsx_ctx_destroy(gsx_ctx *c)
     for (auto &w : c->ws) w.release_all();
     c->tree_ws.release_all();
     c->slab_ws.release_all();
-    gsx::DevBuf *bufs[] = {&c->commscratch, &c->devflags, &c->vox_ids, &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
+    gsx::DevBuf *bufs[] = {&c->commscratch, &c->devflags, &c->vox_ids, &c->nzmask, &c->statspart, &c->scratch, &c->scratch2, &c->scratch3, &c->scratch4, &c->scratch5};
     for (auto b : bufs) b->release();
     if (c->owned_stream) (void)hipStreamDestroy(c->owned_stream);
     delete c;

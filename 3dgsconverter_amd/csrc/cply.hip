@@ -441,6 +441,30 @@ __global__ __launch_bounds__(256) void cply_sh_kernel(const float *__restrict__ 
 
 using namespace gsx;
 
+// compressed_ply.py:139-150 (and sog.py:476-486): which of m consecutive float fields of the rows hold a value != 0 (NaN counts, -0.0
+// does not: numpy's `data[f] != 0`).  Lane = field, a wave walks rows with 8 loads in flight; one OR per wave at the end.
+__global__ __launch_bounds__(256) void fields_nonzero_kernel(const float *__restrict__ base, int64_t row_stride, int64_t n, int m,
+                                                             unsigned long long *__restrict__ mask_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    bool any = false;
+    if (lane < m) {
+        const float *col = base + lane;
+        int64_t r = wave * 8;
+        for (; r + 8 <= n; r += nwaves * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(r + u) * row_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) any |= v[u] != 0.0f;
+        }
+        for (; r < n; ++r) any |= col[r * row_stride] != 0.0f;   // (the last, partial group of eight rows: one wave gets here with r < n)
+    }
+    const unsigned long long bits = __ballot(any);
+    if (lane == 0 && bits) atomicOr(mask_out, bits);
+}
+
 extern "C" {
 
 int gsx_morton_order_dev(gsx_ctx *c, const float *x, const float *y, const float *z, int64_t stride, int64_t n,
@@ -507,6 +531,25 @@ int gsx_cply_sh_strided_dev(gsx_ctx *c, const float *cols_dev, int m, int64_t co
     hipLaunchKernelGGL(cply_sh_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, cols_dev, m, col_stride, elem_stride, order_dev, n,
                        out_dev);
     GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int gsx_fields_nonzero_dev(gsx_ctx *c, const float *first_field_dev, int64_t row_stride, int64_t n, int m, uint64_t *mask_out)
+{
+    if (!c || !mask_out || (n > 0 && m > 0 && !first_field_dev)) GSX_FAIL("gsx_fields_nonzero_dev: null argument");
+    if (n < 0 || m < 0 || m > 64 || row_stride < m) GSX_FAIL("gsx_fields_nonzero_dev: bad size");
+    GSX_HIP(hipSetDevice(c->device));
+    *mask_out = 0;
+    if (n == 0 || m == 0) return 0;
+    GSX_CHECK(c->nzmask.reserve(16));
+    unsigned long long *d_mask = c->nzmask.as<unsigned long long>();
+    GSX_HIP(hipMemsetAsync(d_mask, 0, 8, c->stream));
+    const int64_t groups = div_up(n, (int64_t)8);
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(groups, (int64_t)4), (int64_t)c->num_cu * 16));
+    hipLaunchKernelGGL(fields_nonzero_kernel, dim3(blocks), dim3(256), 0, c->stream, first_field_dev, row_stride, n, m, d_mask);
+    GSX_HIP(hipGetLastError());
+    GSX_HIP(hipMemcpyAsync(mask_out, d_mask, 8, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

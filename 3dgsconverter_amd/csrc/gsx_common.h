@@ -188,6 +188,7 @@ struct gsx_ctx {
     gsx::DevBuf commscratch; // gsx_comm_barrier's word
     gsx::DevBuf devflags;    // u32[16]: device-side error word (bit 0: non-finite coordinates), read by gsx_ctx_check
     gsx::DevBuf vox_ids;     // u16[n]: dense voxel index of every point between the two passes of the density filter (density.hip)
+    gsx::DevBuf nzmask;      // one 64-bit word: gsx_fields_nonzero_dev's result before it is copied out (cply.hip)
     gsx::DevBuf statspart;   // float chunk sums
     gsx::DevBuf scratch;     // host-API staging
     gsx::DevBuf scratch2;

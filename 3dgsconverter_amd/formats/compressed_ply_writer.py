@@ -32,16 +32,21 @@ CHUNK_DTYPE = np.dtype([(p + a, "f4") for p, axes in (("min_", "xyz"), ("max_", 
 VERTEX_DTYPE = np.dtype([("packed_position", "u4"), ("packed_rotation", "u4"), ("packed_scale", "u4"), ("packed_color", "u4")])
 
 
-def active_sh_names(data):
-    """:139-171 -- the f_rest_* columns up to the highest degree that has a non-zero coefficient"""
+def active_sh_names(data, last_active_idx=None):
+    """:139-171 -- the f_rest_* columns up to the highest degree that has a non-zero coefficient.  last_active_idx: the highest
+    f_rest index that holds a non-zero, when the caller already knows it (the device's pass over resident rows); None = scan"""
     names = data.dtype.names
-    last_active_idx = -1
-    if any(n.startswith("f_rest_") for n in names):
+    if last_active_idx is not None:
+        pass
+    elif any(n.startswith("f_rest_") for n in names):
+        last_active_idx = -1
         for i in range(44, -1, -1):
             fname = f"f_rest_{i}"
             if fname in names and np.any(data[fname] != 0):
                 last_active_idx = i
                 break
+    else:
+        last_active_idx = -1
     if last_active_idx >= 24:
         target_degree = 3
     elif last_active_idx >= 9:
@@ -60,10 +65,15 @@ def encode(data: np.ndarray, order=None):
     """-> (chunk_data, vertex_data, sh_data or None, order): the three structured arrays the reference hands to
     ``_write_ply_file``.  order: a precomputed splat order (e.g. the reference's own) instead of the Morton sort."""
     n = len(data)
-    sh_names = active_sh_names(data)
+    found = []
+
+    def resolve(last_active_idx):      # (called once by cply_pack_table: with the device's answer on resident rows, with None otherwise)
+        found[:] = active_sh_names(data, last_active_idx)
+        return found
     # round 5: one threaded gather of every column the writer needs, one upload, Morton order + packers + SH bytes on the device
     # (_lib.cply_pack_table; the per-column path below it -- _lib.morton_order + _lib.cply_pack -- is kept for callers with columns)
-    chunks, verts, sh, order, levels = _lib.cply_pack_table(data, sh_names, order)
+    chunks, verts, sh, order, levels = _lib.cply_pack_table(data, resolve, order)
+    sh_names = list(found)
     if levels is not None:
         debug_print(f"[DEBUG] Morton order: {levels} recursion level(s)")
     chunk_data = np.ascontiguousarray(chunks).view(CHUNK_DTYPE).reshape(-1)

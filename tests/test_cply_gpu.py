@@ -163,3 +163,53 @@ def test_pack_table_from_device_resident_rows_equals_the_host_gather_path(gsx):
         if sh_names:
             np.testing.assert_array_equal(a[2], osh)
     lib.release_arenas()
+
+
+def test_fields_nonzero_is_numpys_any_not_equal_zero(gsx):
+    """gsx_fields_nonzero_dev against `np.any(data[f] != 0)` (compressed_ply.py:139-150): NaN counts, -0.0 does not; row counts
+    around the eight-row groups of the kernel; the only non-zero in the first / last row; m up to 64 fields"""
+    import ctypes as C
+    lib = gsx._lib
+    ctx = lib.Context(0)
+    rng = np.random.default_rng(3)
+    try:
+        for n, m, stride in [(1, 1, 1), (7, 3, 5), (8, 45, 62), (9, 45, 62), (1000, 64, 64), (100_003, 45, 62), (300_000, 24, 30)]:
+            for trial in range(4):
+                rows = np.zeros((n, stride), np.float32)
+                want = 0
+                cols = rng.choice(m, size=int(rng.integers(0, min(m, 6) + 1)), replace=False)
+                for c in cols:
+                    r = [0, n - 1, int(rng.integers(0, n))][int(rng.integers(0, 3))]
+                    rows[r, c] = [np.float32(np.nan), np.float32(1e-45), np.float32(-3.0)][int(rng.integers(0, 3))]
+                    want |= 1 << int(c)
+                rows[rng.integers(0, n, 5), rng.integers(0, m, 5)] += np.float32(-0.0)      # (-0.0 into zeros stays "zero"; into others no change)
+                if stride > m:
+                    rows[:, m:] = 7.0                                                       # fields beyond m are not looked at
+                d = ctx.alloc(rows.nbytes).upload(rows)
+                word = C.c_uint64(123)
+                lib.check(lib.require_hip().gsx_fields_nonzero_dev(ctx.handle, d.ptr, stride, n, m, C.byref(word)), "gsx_fields_nonzero_dev")
+                d.free()
+                ref = sum(1 << c for c in range(m) if np.any(rows[:, c] != 0))
+                assert word.value == ref == want, (n, m, stride, trial, hex(word.value), hex(ref))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("last", [-1, 0, 8, 9, 23, 24, 44])
+def test_degree_detection_on_resident_rows_is_the_host_scan(gsx, writer, last):
+    """the writer's SH degree (compressed_ply.py:139-171) from the device's pass over the uploaded rows: tables whose coefficients
+    are zero above index `last` (with -0.0 among the zeros), resident path against the reference's per-column scan"""
+    d = ocply.cply_scene(5000, 17 + last, "plain")
+    for i in range(last + 1, 45):
+        d["f_rest_%d" % i] = np.float32(-0.0) if i % 3 == 0 else np.float32(0.0)
+    if last >= 0:
+        d["f_rest_%d" % last] = 0
+        d["f_rest_%d" % last][4999] = np.float32(1e-30)       # one non-zero, in the last row
+    want_names = writer.active_sh_names(d)
+    assert len(want_names) == {-1: 0, 0: 9, 8: 9, 9: 24, 23: 24, 24: 45, 44: 45}[last]
+    chunk, vertex, sh, order = writer.encode(d)
+    assert (list(sh.dtype.names) if sh is not None else []) == want_names
+    wc, wv, wsh = ocply.encode(d, order, want_names)
+    np.testing.assert_array_equal(vertex.view(np.uint32).reshape(-1, 4), wv)
+    if want_names:
+        np.testing.assert_array_equal(sh.view(np.uint8).reshape(len(d), -1), wsh)
