@@ -36,7 +36,23 @@ constexpr int SOGT_MAX_ROW_DWORDS = 128;   // 512-byte rows: a tile is 64 KiB of
 struct SogLayoutDev {
     int row_dwords, n_rest;
     int off[SOGT_FIELDS];   // dword offset of x y z | rot_0..3 | scale_0..2 | f_dc_0..2 | opacity | f_rest_0..44 inside a row
+    int row_bytes;          // BYTES layouts (rows that are not a multiple of 4 bytes -- the table widened by three u1 colour fields, 251 bytes:
+    int bytes;              //  data_processor.py:262-274 -- or fields at odd offsets): off[] are BYTE offsets, bytes = 1
 };
+
+// A field out of a tile in LDS.  Aligned layouts: `row` = dword index of the row, `off` = dword offset.  BYTES layouts: `row` = BYTE
+// position of the row's first byte inside the tile (the tile starts at the 4-byte boundary below its first row), `off` = byte offset;
+// the value straddles two dwords (v_alignbyte_b32; the tile has one spare dword behind its last row).
+template <bool BYTES>
+__device__ __forceinline__ unsigned tile_field(const unsigned *s, int row, int off)
+{
+    if constexpr (!BYTES) {
+        return s[row + off];
+    } else {
+        const int b = row + off;
+        return __builtin_amdgcn_alignbyte(s[(b >> 2) + 1], s[b >> 2], (unsigned)(b & 3));
+    }
+}
 
 struct SogScanDev {
     unsigned kmin[3], kmax[3];
@@ -57,6 +73,7 @@ __device__ __forceinline__ void load_tile(unsigned *s_rows, const unsigned *src,
 }
 
 // table order: keys of x, y, z (three columns of n), extremes of the keys, non-zero mask of the f_rest columns
+template <bool BYTES>
 __global__ __launch_bounds__(256) void sog_scan_kernel(const unsigned *__restrict__ rows, SogLayoutDev L, int64_t n,
                                                        unsigned *__restrict__ keys, SogScanDev *__restrict__ out)
 {
@@ -71,22 +88,30 @@ __global__ __launch_bounds__(256) void sog_scan_kernel(const unsigned *__restric
         const int64_t r0 = tile * SOGT_ROWS;
         const int rows_here = (int)min((int64_t)SOGT_ROWS, n - r0);
         __syncthreads();   // the previous tile has been read
-        load_tile(s_rows, rows + r0 * rd, rows_here * rd);
+        int shift = 0;         // BYTES: the tile's first row starts `shift` bytes behind a 4-byte boundary
+        if constexpr (BYTES) {
+            const int64_t g0 = r0 * L.row_bytes;
+            shift = (int)(g0 & 3);
+            load_tile(s_rows, reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(rows) + (g0 - shift)),
+                      (shift + rows_here * L.row_bytes + 3) >> 2);
+        } else {
+            load_tile(s_rows, rows + r0 * rd, rows_here * rd);
+        }
         __syncthreads();
         const int r = threadIdx.x & (SOGT_ROWS - 1), half = threadIdx.x >> 7;
         if (r < rows_here) {
-            const unsigned *rw = s_rows + r * rd;
+            const int rw = BYTES ? shift + r * L.row_bytes : r * rd;
             if (half == 0) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const unsigned key = sort_key(__uint_as_float(rw[s_off[a]]));
+                    const unsigned key = sort_key(__uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[a])));
                     keys[(int64_t)a * n + r0 + r] = key;
                     kmin[a] = min(kmin[a], key);
                     kmax[a] = max(kmax[a], key);
                 }
             }
             for (int f = half; f < L.n_rest; f += 2)   // `data_s[fn] != 0` (:484): +-0.0 are zero, a NaN is not
-                if ((rw[s_off[14 + f]] << 1) != 0u) nz |= 1ull << f;
+                if ((tile_field<BYTES>(s_rows, rw, s_off[14 + f]) << 1) != 0u) nz |= 1ull << f;
         }
     }
     // wave reduction, one atomic per wave and word
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(256) void sog_order_keys_kernel(const unsigned *__r
 }
 
 // `data_s = data[indices]` (:265) for the columns the writer reads: output row j = table row perm[j]
-template <int D>
+template <int D, bool BYTES>
 __global__ __launch_bounds__(256) void sog_gather_kernel(const unsigned *__restrict__ rows, SogLayoutDev L, const unsigned *__restrict__ perm,
                                                          int64_t n, float *__restrict__ pos, float4 *__restrict__ rot, float *__restrict__ scale,
                                                          float *__restrict__ dc, float *__restrict__ opacity, float *__restrict__ sh)
@@ -161,6 +186,9 @@ __global__ __launch_bounds__(256) void sog_gather_kernel(const unsigned *__restr
     extern __shared__ unsigned s_rows[];
     __shared__ int s_off[SOGT_FIELDS];
     if (threadIdx.x < SOGT_FIELDS) s_off[threadIdx.x] = L.off[threadIdx.x];
+    // (BYTES: a row of the tile occupies `rd` dwords -- the row, up to 3 bytes in front of it back to a 4-byte boundary, rounded up, an ODD
+    //  count so that the lanes' rows fall into different LDS banks -- and s_shift[r] is where inside them the row starts)
+    __shared__ unsigned char s_shift[SOGT_ROWS];
     const int rd = L.row_dwords;
     const int64_t j0 = (int64_t)blockIdx.x * SOGT_ROWS;
     const int rows_here = (int)min((int64_t)SOGT_ROWS, n - j0);
@@ -168,26 +196,34 @@ __global__ __launch_bounds__(256) void sog_gather_kernel(const unsigned *__restr
     // a wave reads one permuted row per instruction: 248 contiguous bytes
     for (int r = wave; r < rows_here; r += 4) {
         const unsigned srow = __builtin_amdgcn_readfirstlane(perm[j0 + r]);
-        const unsigned *src = rows + (int64_t)srow * rd;
-        for (int e = lane; e < rd; e += 64) s_rows[r * rd + e] = src[e];
+        if constexpr (BYTES) {
+            const int64_t g = (int64_t)srow * L.row_bytes;
+            const int sh_b = (int)(g & 3), nd = (sh_b + L.row_bytes + 3) >> 2;
+            const unsigned *src = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(rows) + (g - sh_b));
+            for (int e = lane; e < nd; e += 64) s_rows[r * rd + e] = src[e];
+            if (lane == 0) s_shift[r] = (unsigned char)sh_b;
+        } else {
+            const unsigned *src = rows + (int64_t)srow * rd;
+            for (int e = lane; e < rd; e += 64) s_rows[r * rd + e] = src[e];
+        }
     }
     __syncthreads();
     const int r = threadIdx.x & (SOGT_ROWS - 1), half = threadIdx.x >> 7;
     if (r < rows_here) {
-        const unsigned *rw = s_rows + r * rd;
+        const int rw = BYTES ? r * rd * 4 + s_shift[r] : r * rd;
         const int64_t j = j0 + r;
         if (half == 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) pos[(int64_t)a * n + j] = __uint_as_float(rw[s_off[a]]);
-            rot[j] = make_float4(__uint_as_float(rw[s_off[3]]), __uint_as_float(rw[s_off[4]]), __uint_as_float(rw[s_off[5]]),
-                                 __uint_as_float(rw[s_off[6]]));
+            for (int a = 0; a < 3; ++a) pos[(int64_t)a * n + j] = __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[a]));
+            rot[j] = make_float4(__uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[3])), __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[4])),
+                                 __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[5])), __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[6])));
         } else {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                scale[(int64_t)a * n + j] = __uint_as_float(rw[s_off[7 + a]]);
-                dc[(int64_t)a * n + j] = __uint_as_float(rw[s_off[10 + a]]);
+                scale[(int64_t)a * n + j] = __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[7 + a]));
+                dc[(int64_t)a * n + j] = __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[10 + a]));
             }
-            opacity[j] = __uint_as_float(rw[s_off[13]]);
+            opacity[j] = __uint_as_float(tile_field<BYTES>(s_rows, rw, s_off[13]));
         }
     }
     if constexpr (D > 0) {
@@ -195,7 +231,7 @@ __global__ __launch_bounds__(256) void sog_gather_kernel(const unsigned *__restr
         float *dst = sh + j0 * D;
         for (int e = threadIdx.x; e < rows_here * D; e += 256) {
             const int rr = e / D, c = e - rr * D;
-            dst[e] = __uint_as_float(s_rows[rr * rd + s_off[14 + c]]);
+            dst[e] = __uint_as_float(tile_field<BYTES>(s_rows, BYTES ? rr * rd * 4 + s_shift[rr] : rr * rd, s_off[14 + c]));
         }
     }
 }
@@ -317,22 +353,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
 static int layout_to_dev(const gsx_sog_layout *l, int n_rest, SogLayoutDev *out, const char *who)
 {
     if (!l) GSX_FAIL("%s: null layout", who);
-    if (l->row_bytes < 4 || (l->row_bytes & 3) || l->row_bytes > 4 * SOGT_MAX_ROW_DWORDS)
-        GSX_FAIL("%s: rows of %lld bytes (a multiple of 4 up to %d is supported: pack other tables with gsx_host_gather_f32 first)", who,
-                 (long long)l->row_bytes, 4 * SOGT_MAX_ROW_DWORDS);
+    if (l->row_bytes < 4 || l->row_bytes > 4 * SOGT_MAX_ROW_DWORDS)
+        GSX_FAIL("%s: rows of %lld bytes (4 ... %d are supported)", who, (long long)l->row_bytes, 4 * SOGT_MAX_ROW_DWORDS);
     if (n_rest < 0 || n_rest > 45) GSX_FAIL("%s: 0 <= n_rest <= 45", who);
-    out->row_dwords = (int)(l->row_bytes / 4);
-    out->n_rest = n_rest;
-    for (int f = 0; f < SOGT_FIELDS; ++f) {
+    bool bytes = (l->row_bytes & 3) != 0;
+    for (int f = 0; f < 14 + n_rest; ++f) {
         const int o = l->offset[f];
-        const bool needed = f < 14 + n_rest;
-        if (!needed) {
-            out->off[f] = 0;
-            continue;
-        }
-        if (o < 0 || (o & 3) || o + 4 > l->row_bytes) GSX_FAIL("%s: field %d at byte offset %d of a %lld-byte row", who, f, o, (long long)l->row_bytes);
-        out->off[f] = o / 4;
+        if (o < 0 || o + 4 > l->row_bytes) GSX_FAIL("%s: field %d at byte offset %d of a %lld-byte row", who, f, o, (long long)l->row_bytes);
+        bytes = bytes || (o & 3) != 0;
     }
+    if (bytes && l->row_bytes > 500) GSX_FAIL("%s: rows of %lld bytes with fields off the 4-byte grid (up to 500 bytes are supported)", who, (long long)l->row_bytes);
+    out->bytes = bytes ? 1 : 0;
+    out->row_bytes = (int)l->row_bytes;
+    // aligned: dwords per row.  BYTES: dwords a row occupies in the gather kernel's tile (see there), odd
+    out->row_dwords = bytes ? (int)(((l->row_bytes + 6) >> 2) | 1) : (int)(l->row_bytes / 4);
+    out->n_rest = n_rest;
+    for (int f = 0; f < SOGT_FIELDS; ++f) out->off[f] = f < 14 + n_rest ? (bytes ? l->offset[f] : l->offset[f] / 4) : 0;
     return 0;
 }
 
@@ -359,9 +395,14 @@ int gsx_sog_scan_dev(gsx_ctx *c, const void *rows_dev, const gsx_sog_layout *lay
     SogScanDev *d = c->scratch3.as<SogScanDev>();
     hipLaunchKernelGGL(sog_scan_init_kernel, dim3(1), dim3(64), 0, c->stream, d);
     const int64_t ntiles = (n + SOGT_ROWS - 1) / SOGT_ROWS;
-    const size_t lds = sizeof(unsigned) * (size_t)SOGT_ROWS * L.row_dwords;
     const int blocks = (int)std::min<int64_t>(ntiles, (int64_t)c->num_cu * 5);
-    hipLaunchKernelGGL(sog_scan_kernel, dim3(blocks), dim3(256), lds, c->stream, reinterpret_cast<const unsigned *>(rows_dev), L, n, keys3_dev, d);
+    if (L.bytes) {   // the tile = SOGT_ROWS consecutive rows from the 4-byte boundary below the first one, + the spare dword of tile_field
+        const size_t lds = ((size_t)SOGT_ROWS * L.row_bytes + 3 + 3) / 4 * 4 + 4;
+        hipLaunchKernelGGL(sog_scan_kernel<true>, dim3(blocks), dim3(256), lds, c->stream, reinterpret_cast<const unsigned *>(rows_dev), L, n, keys3_dev, d);
+    } else {
+        const size_t lds = sizeof(unsigned) * (size_t)SOGT_ROWS * L.row_dwords;
+        hipLaunchKernelGGL(sog_scan_kernel<false>, dim3(blocks), dim3(256), lds, c->stream, reinterpret_cast<const unsigned *>(rows_dev), L, n, keys3_dev, d);
+    }
     GSX_HIP(hipGetLastError());
     SogScanDev h;
     GSX_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -443,13 +484,21 @@ int gsx_sog_gather_dev(gsx_ctx *c, const void *rows_dev, const gsx_sog_layout *l
     if (reinterpret_cast<uintptr_t>(rot_dev) & 15) GSX_FAIL("gsx_sog_gather_dev: the quaternion rows must be 16-byte aligned");
     SogLayoutDev L;
     GSX_CHECK(layout_to_dev(layout, d_sh, &L, "gsx_sog_gather_dev"));
+    if (reinterpret_cast<uintptr_t>(rows_dev) & 3) GSX_FAIL("gsx_sog_gather_dev: rows must be 4-byte aligned");
     GSX_HIP(hipSetDevice(c->device));
     const unsigned ntiles = (unsigned)((n + SOGT_ROWS - 1) / SOGT_ROWS);
-    const size_t lds = sizeof(unsigned) * (size_t)SOGT_ROWS * L.row_dwords;
+    const size_t lds = sizeof(unsigned) * ((size_t)SOGT_ROWS * L.row_dwords + 1);
     const unsigned *rows = reinterpret_cast<const unsigned *>(rows_dev);
     float4 *rot4 = reinterpret_cast<float4 *>(rot_dev);
-#define GSX_SOG_GATHER(D) \
-    hipLaunchKernelGGL(sog_gather_kernel<D>, dim3(ntiles), dim3(256), lds, c->stream, rows, L, perm_dev, n, pos_dev, rot4, scale_dev, dc_dev, opacity_dev, sh_dev)
+#define GSX_SOG_GATHER(D)                                                                                                                     \
+    do {                                                                                                                                      \
+        if (L.bytes)                                                                                                                          \
+            hipLaunchKernelGGL((sog_gather_kernel<D, true>), dim3(ntiles), dim3(256), lds, c->stream, rows, L, perm_dev, n, pos_dev, rot4,     \
+                               scale_dev, dc_dev, opacity_dev, sh_dev);                                                                       \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((sog_gather_kernel<D, false>), dim3(ntiles), dim3(256), lds, c->stream, rows, L, perm_dev, n, pos_dev, rot4,    \
+                               scale_dev, dc_dev, opacity_dev, sh_dev);                                                                       \
+    } while (0)
     switch (d_sh) {
     case 0: GSX_SOG_GATHER(0); break;
     case 9: GSX_SOG_GATHER(9); break;

@@ -91,15 +91,17 @@ def table_layout(data: np.ndarray):
         raise NotEligible("a field the writer reads is not float32")
     lay = _lib.SogLayout()
     lay.n_rest = coeffs
-    direct = (data.flags.c_contiguous and data.dtype.itemsize % 4 == 0 and data.dtype.itemsize <= 512
-              and all(fields[nm][1] % 4 == 0 for nm in names))
+    aligned = data.dtype.itemsize % 4 == 0 and all(fields[nm][1] % 4 == 0 for nm in names)
+    # (rows off the 4-byte grid -- the table widened by three u1 colour fields, which is what the reference's converter hands the SOG
+    #  writer, converter.py:243-252: 251 bytes -- are read as they are: the kernels assemble a field from two words of their LDS tile)
+    direct = data.flags.c_contiguous and data.dtype.itemsize <= (512 if aligned else 500)
     if direct:
         lay.row_bytes = data.dtype.itemsize
         for i, nm in enumerate(names):
             lay.offset[i] = int(fields[nm][1])
         return data, lay
-    # odd row sizes (e.g. the table widened by three u1 colour fields: 251 bytes) or unaligned fields: ONE threaded host pass
-    # packs the float32 columns the writer reads into rows of their own
+    # rows of more than 500 / 512 bytes (many extra fields) or a table that is not contiguous: ONE threaded host pass packs the
+    # float32 columns the writer reads into rows of their own
     packed = _lib.host_gather_xyz(data, names)
     lay.row_bytes = 4 * len(names)
     for i in range(len(names)):

@@ -483,10 +483,13 @@ int gsx_sog_quats_dev(gsx_ctx *ctx, const float *rot_rows_dev, int64_t n, uint8_
  * scan -> extremes -> order -> gather -> *_texels (+ gsx_kmeans1d_dev / gsx_kmeans_lloyd_batch_dev for the codebooks). */
 #define GSX_SOG_FIELDS 59
 typedef struct gsx_sog_layout {
-    int64_t row_bytes;                 /* itemsize of the structured dtype: a multiple of 4, at most 512 */
+    int64_t row_bytes;                 /* itemsize of the structured dtype: at most 512; ANY size up to 500 (the table widened by the
+                                          three u1 colour fields of data_processor.py:262-274 has 251-byte rows: the kernels then
+                                          assemble every field from two words of their LDS tile, and read up to 3 bytes past the
+                                          last row -- rows_dev must be readable up to the next 4-byte boundary) */
     int32_t n_rest;                    /* f_rest columns present (0, 9, 24 or 45: sog.py:468-474) */
     int32_t offset[GSX_SOG_FIELDS];    /* byte offset of the float32 fields x y z | rot_0..3 | scale_0..2 | f_dc_0..2 | opacity |
-                                          f_rest_0..44 inside a row (multiples of 4; entries beyond 14 + n_rest are ignored) */
+                                          f_rest_0..44 inside a row (any offset; entries beyond 14 + n_rest are ignored) */
 } gsx_sog_layout;
 typedef struct gsx_sog_scan {
     float    vmin[3], vmax[3];         /* np.min / np.max of x, y, z (a -0.0 is reported as +0.0) */

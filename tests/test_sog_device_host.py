@@ -74,11 +74,31 @@ def test_layout_packs_odd_rows_and_declines_foreign_dtypes():
     wide = np.zeros(100, dtype=np.dtype(src.dtype.descr + [("red", "u1"), ("green", "u1"), ("blue", "u1")]))
     for nm in src.dtype.names:
         wide[nm] = src[nm]
+    # 251-byte rows (what the reference's converter hands the SOG writer after add_rgb_from_sh) are described as they are
     rows, lay = sd.table_layout(wide)
-    assert rows.shape == (100, 59) and rows.dtype == np.float32 and lay.row_bytes == 236
+    assert rows is wide and lay.row_bytes == 251
+    raw = wide.view(np.uint8).reshape(100, 251)
     for i, nm in enumerate(lib.SOG_FIELD_NAMES):
-        assert lay.offset[i] == 4 * i
-        np.testing.assert_array_equal(rows[:, i], src[nm])
+        assert lay.offset[i] == wide.dtype.fields[nm][1]
+        np.testing.assert_array_equal(raw[:, lay.offset[i]:lay.offset[i] + 4].copy().view(np.float32).reshape(-1), src[nm])
+    # a u1 field in FRONT of the floats: every offset off the 4-byte grid, still direct
+    front = np.zeros(100, dtype=np.dtype([("tag", "u1")] + src.dtype.descr))
+    for nm in src.dtype.names:
+        front[nm] = src[nm]
+    rows, lay = sd.table_layout(front)
+    assert rows is front and lay.row_bytes == 249 and lay.offset[0] == 1
+    # rows beyond what a tile of the kernels holds (500 bytes off the grid, 512 on it), or a strided view: one host pass packs the 59 columns
+    for extra in (300, 272):      # 548-byte rows on the grid, 520-byte rows on it too -> both beyond 512
+        big = np.zeros(100, dtype=np.dtype(src.dtype.descr + [("blob", "V%d" % extra)]))
+        for nm in src.dtype.names:
+            big[nm] = src[nm]
+        rows, lay = sd.table_layout(big)
+        assert rows.shape == (100, 59) and rows.dtype == np.float32 and lay.row_bytes == 236
+        for i, nm in enumerate(lib.SOG_FIELD_NAMES):
+            assert lay.offset[i] == 4 * i
+            np.testing.assert_array_equal(rows[:, i], src[nm])
+    rows, lay = sd.table_layout(wide[::2])
+    assert rows.shape == (50, 59) and lay.row_bytes == 236
     with pytest.raises(sd.NotEligible):
         sd.table_layout(src[["x", "y", "z"]])                                    # fields the writer reads are missing
     f8 = src.astype([(nm, "f8" if nm == "scale_1" else "f4") for nm in src.dtype.names])

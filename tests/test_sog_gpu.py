@@ -426,3 +426,34 @@ def test_device_resident_core_on_a_scene_far_from_the_origin(gsx):
     with np.errstate(all="ignore"):
         core = w.encode(data, 4, device_resident=True)
         _check_core_against_numpy(core, data, 4)
+
+
+@pytest.mark.parametrize("front,back,deg", [(0, 3, 3), (1, 0, 3), (2, 1, 2), (3, 2, 1), (0, 1, 0), (5, 6, 3), (1, 251, 3)])
+def test_device_resident_core_reads_rows_off_the_four_byte_grid(gsx, front, back, deg):
+    """round 6: rows whose size is not a multiple of 4 (the reference's converter appends three u1 colour fields before it calls the
+    SOG writer, converter.py:243-252 -> 251 bytes) and float fields at odd offsets (u1 fields in front) are read on the device as
+    they are -- a field assembled from two words of the LDS tile -- instead of being packed by a host pass.  Same textures as the
+    same values in a plain 4-byte table; sizes around the 128-row tiles; band detection and the key extremes included"""
+    w = _sog_writer()
+    sd = __import__("importlib").import_module("3dgsconverter_amd.formats.sog_device")
+    for n in (1100, 128 * 40 + 1, 30011):
+        src = datasets.sog_scene(n, 50 + n % 7, sh_degree=deg)
+        if deg >= 2:
+            for i in range(3 * ((deg + 1) ** 2 - 1) - 4, 3 * ((deg + 1) ** 2 - 1)):
+                src["f_rest_%d" % i][: n - 1] = 0          # the only non-zero of these fields in the last row
+        descr = [("pre%d" % i, "u1") for i in range(front)] + src.dtype.descr + [("post%d" % i, "u1") for i in range(back)]
+        odd = np.zeros(n, dtype=np.dtype(descr))
+        rng = np.random.default_rng(n)
+        for nm in odd.dtype.names:
+            odd[nm] = src[nm] if nm in src.dtype.names else rng.integers(0, 256, n, dtype=np.uint8)
+        rows, lay = sd.table_layout(odd)
+        assert rows is odd and lay.row_bytes == odd.dtype.itemsize      # no host pack
+        np.random.seed(9)
+        a = w.encode(odd, 7, device_resident=True)
+        np.random.seed(9)
+        b = w.encode(src, 7, device_resident=True)
+        assert a["bands"] == b["bands"] == deg
+        for name in b["textures"]:
+            np.testing.assert_array_equal(a["textures"][name], b["textures"][name], err_msg="%s n=%d" % (name, n))
+        assert [np.float32(v).tobytes() for v in a["mins"] + a["maxs"]] == [np.float32(v).tobytes() for v in b["mins"] + b["maxs"]]
+    _check_core_against_numpy(a, odd, 7)
