@@ -123,6 +123,7 @@ SIGNATURES = {
     "gsx_host_take_rows": (_I, [_P, _I64, _I64, _P, _I64, _P]),
     "gsx_host_zero_columns": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I]),
     "gsx_host_append_columns": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64]),
+    "gsx_host_take_rows_append": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64]),
     "gsx_rgb_from_sh": (_I, [_P, _I64, _P, _P]),
     "gsx_rgb_from_sh_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
@@ -370,6 +371,23 @@ def host_append_u8_columns(rows: np.ndarray, names, columns: np.ndarray) -> np.n
         return out
     check(load().gsx_host_append_columns(rows.ctypes.data, rows.dtype.itemsize, len(rows), cols.ctypes.data, len(names),
                                          out.ctypes.data, new_dtype.itemsize), "gsx_host_append_columns")
+    return out
+
+
+def host_take_rows_append_u8(rows: np.ndarray, idx: np.ndarray, names, columns: np.ndarray) -> np.ndarray:
+    """host_append_u8_columns(host_take_rows(rows, idx), names, columns[idx]) in ONE threaded pass (C ABI gsx_host_take_rows_append):
+    the filters' compaction and add_rgb_from_sh's widened copy (data_processor.py:114,149 + :262-274) without the table in between.
+    columns: (len(rows), len(names)) uint8, indexed like `rows`"""
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    new_dtype = np.dtype(rows.dtype.descr + [(nm, "u1") for nm in names])
+    cols = np.ascontiguousarray(columns, dtype=np.uint8).reshape(len(rows), len(names))
+    tail_ok = all(new_dtype.fields[nm][1] == rows.dtype.itemsize + i for i, nm in enumerate(names))
+    if rows.ndim != 1 or not rows.flags.c_contiguous or rows.dtype.hasobject or not tail_ok:
+        return host_append_u8_columns(host_take_rows(rows, idx), names, cols[idx])
+    out = np.empty(len(idx), dtype=new_dtype)
+    if len(idx):
+        check(load().gsx_host_take_rows_append(rows.ctypes.data, rows.dtype.itemsize, len(rows), idx.ctypes.data, len(idx), cols.ctypes.data,
+                                               len(names), out.ctypes.data, new_dtype.itemsize), "gsx_host_take_rows_append")
     return out
 
 

@@ -245,6 +245,45 @@ extern "C" int gsx_host_append_columns(const void *rows, int64_t row_bytes, int6
     return 0;
 }
 
+// Both at once (round 6): the filters' compaction `self.data = vertices[mask]` (data_processor.py:114,149) followed by add_rgb_from_sh's
+// widened copy (:262-274) -- what the reference's converter does for every target that needs colours (converter.py:243-252) -- as
+// ONE pass: output row j = source row idx[j] followed by the extra bytes of THAT source row (extra: n x extra_bytes, indexed like
+// the source table).  idx: strictly ascending row numbers (the device chain's survivor list).
+extern "C" int gsx_host_take_rows_append(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
+                                         const uint8_t *extra, int64_t extra_bytes, void *out, int64_t out_row_bytes)
+{
+    if (!rows || !extra || (!idx && n_idx > 0) || (!out && n_idx > 0)) GSX_FAIL("gsx_host_take_rows_append: null argument");
+    if (n < 0 || row_bytes <= 0 || n_idx < 0 || extra_bytes <= 0 || out_row_bytes < row_bytes + extra_bytes) GSX_FAIL("gsx_host_take_rows_append: bad shape");
+    if (n_idx == 0) return 0;
+    const int nt = worker_count(2 * n_idx * out_row_bytes);
+    const char *src = static_cast<const char *>(rows);
+    char *dst = static_cast<char *>(out);
+    {
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + (size_t)n_idx * (size_t)out_row_bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    const int64_t pad = out_row_bytes - row_bytes - extra_bytes;
+    std::vector<int> bad(nt, 0);
+    run_threads(nt, [&](int t) {
+        const int64_t i0 = n_idx * t / nt, i1 = n_idx * (t + 1) / nt;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int64_t r = idx[i];
+            if (r >= n || (i > 0 && idx[i] <= idx[i - 1])) {
+                bad[t] = 1;
+                return;
+            }
+            char *d = dst + i * out_row_bytes;
+            memcpy(d, src + r * row_bytes, (size_t)row_bytes);
+            memcpy(d + row_bytes, extra + r * extra_bytes, (size_t)extra_bytes);
+            if (pad) memset(d + row_bytes + extra_bytes, 0, (size_t)pad);
+        }
+    });
+    for (int t = 0; t < nt; ++t)
+        if (bad[t]) GSX_FAIL("gsx_host_take_rows_append: the index list is not strictly ascending inside [0, n)");
+    return 0;
+}
+
 // ---- bulk copies between pageable host memory and HBM through pinned staging, threaded (round 6) ------------------------
 // hipMemcpy of a PAGEABLE buffer is one runtime thread copying through one staging buffer: measured 24 GB/s up for the 2.48 GB
 // splat table of the SOG writer and 14 GB/s down into freshly allocated (not yet faulted) numpy arrays, on a link that moves

@@ -73,6 +73,7 @@ class DataProcessor:
         self._data = data
         self._chain = None          # _lib.DeviceChain over the rows of self._data, or None
         self._pending_zero = []     # lazy cap_sh_degree: columns to zero once the host table has been compacted
+        self._pending_rgb = None    # lazy add_rgb_from_sh: (n0, 3) u8 colours of the UNcompacted table, appended by the compaction pass
         self.lazy = DataProcessor.lazy_default if lazy is None else bool(lazy)
 
     @property
@@ -92,6 +93,7 @@ class DataProcessor:
             names, self._pending_zero = self._pending_zero, []
             _lib.host_zero_columns(self._data, names)
         self._pending_zero = []
+        self._pending_rgb = None
         self._drop_chain()
         self._data = value
 
@@ -103,6 +105,7 @@ class DataProcessor:
     def _materialize(self):
         """apply the composed survivor list of the device chain to the host table (one threaded compaction), then the
         deferred column fills of cap_sh_degree on the rows that are left"""
+        rgb, self._pending_rgb = self._pending_rgb, None
         if self._chain is not None:
             ch = self._chain
             self._chain = None
@@ -110,9 +113,17 @@ class DataProcessor:
                 if ch.n != ch.n0:
                     # the chain's survivor list (ascending row indices) applied to the host table directly -- round 5: the
                     # boolean mask numpy would index with (`mask[survivors] = True` on 8M indices) cost more than the compaction
-                    self._data = _lib.host_take_rows(self._data, ch.survivors())
+                    if rgb is not None:
+                        # round 6: ... and add_rgb_from_sh's widened copy (:262-274) in the same pass (the reference's converter calls
+                        # it after the filters for every target that needs colours, converter.py:243-252): one new table, not two
+                        self._data = _lib.host_take_rows_append_u8(self._data, ch.survivors(), ("red", "green", "blue"), rgb)
+                        rgb = None
+                    else:
+                        self._data = _lib.host_take_rows(self._data, ch.survivors())
             finally:
                 ch.close()
+        if rgb is not None:
+            self._data = _lib.host_append_u8_columns(self._data, ("red", "green", "blue"), rgb)
         if self._pending_zero:
             names, self._pending_zero = self._pending_zero, []
             if isinstance(self._data, np.ndarray):
@@ -124,12 +135,18 @@ class DataProcessor:
             self._chain = _lib.DeviceChain(_xyz_rows(vertices))
         return self._chain
 
+    def _flush_rgb(self):
+        """a deferred add_rgb_from_sh changes the table's dtype: any further method sees the table the reference would have by then"""
+        if self._pending_rgb is not None:
+            self._materialize()
+
     def __len__(self):   # rows currently surviving, without materialising
         return self._chain.n if self._chain is not None else len(self._data)
 
     # ------------------------------------------------------------------ SOR
     def remove_flyers(self, k=25, threshold_factor=10.5, chunk_size=50000, intensity=None):
         debug_print("[DEBUG] Executing 'remove_flyers' function...")
+        self._flush_rgb()
         if not isinstance(self._data, np.ndarray):
             raise TypeError("self.data must be a numpy structured array.")
         if intensity is not None:
@@ -167,6 +184,7 @@ class DataProcessor:
     def apply_density_filter(self, voxel_size=1.0, threshold_percentage=0.32, sensitivity=None,
                              keep_multicluster=False):
         debug_print("[DEBUG] Executing 'apply_density_filter' function...")
+        self._flush_rgb()
         if not isinstance(self._data, np.ndarray):
             raise TypeError("self.data must be a numpy structured array.")
         if sensitivity is not None:
@@ -243,6 +261,7 @@ class DataProcessor:
     # call at 10M splats in numpy -- goes through the threaded C compaction.
     def apply_alpha_filter(self, min_opacity_u8):
         """reference :184-213"""
+        self._flush_rgb()
         debug_print(f"[DEBUG] Executing 'apply_alpha_filter' with min={min_opacity_u8}")
         if 'opacity' not in self._data.dtype.names:
             status_print("Warning: No opacity channel found. Alpha filter skipped.")
@@ -269,6 +288,7 @@ class DataProcessor:
 
     def crop_by_bbox(self, min_x, min_y, min_z, max_x, max_y, max_z):
         """reference :215-231"""
+        self._flush_rgb()
         if self.lazy and isinstance(self._data, np.ndarray) and len(self) > 0 and all(
                 self._data.dtype[f] == np.float32 for f in ("x", "y", "z")):
             left = self._chain_for(self._data).bbox_keep((min_x, min_y, min_z, max_x, max_y, max_z))
@@ -317,11 +337,32 @@ class DataProcessor:
             f_dc = np.column_stack(cols)
             rgb = np.power(np.clip(0.5 + f_dc * 0.28209479177387814, 0.0, 1.0), 1.0 / 2.2)
             return (rgb * 255).astype(np.uint8)
-        return np.column_stack([_lib.rgb_from_sh(c) for c in cols])
+        # (round 6: the three columns leave the table in ONE threaded pass and go through the device as one array -- three strided
+        #  numpy copies of a 248-byte-stride column cost ~50 ms each at 10M splats)
+        mat = _lib.host_gather_columns(vertices, [prefix + "f_dc_%d" % c for c in range(3)])
+        return np.ascontiguousarray(_lib.rgb_from_sh(mat.reshape(-1)).reshape(3, len(vertices)).T)
 
     def add_rgb_from_sh(self):
         """reference :233-274: append (red, green, blue) u1 fields computed from the SH DC term"""
         debug_print("[DEBUG] Executing 'add_rgb_from_sh' function...")
+        self._flush_rgb()
+        if self.lazy and self._chain is not None and self._chain.n != self._chain.n0 and isinstance(self._data, np.ndarray) \
+                and self._chain.n > 0:
+            # a compaction is pending: colours for the rows of the table as it is (per-row arithmetic: the survivors' colours are what
+            # the reference computes on the filtered table), appended by the ONE pass that compacts it (_materialize)
+            src = self._data
+            if "red" in src.dtype.names:
+                debug_print("[DEBUG] RGB fields already exist.")
+                return
+            if "f_dc_0" not in src.dtype.names and "scalar_f_dc_0" not in src.dtype.names:
+                debug_print("[DEBUG] No SH DC components found, cannot compute RGB.")
+                return
+            colors = self._compute_rgb_from_sh(src)
+            if colors is None:
+                return
+            self._pending_rgb = colors
+            debug_print("[DEBUG] RGB added to data.")
+            return
         data = self.data
         names = data.dtype.names
         if "red" in names:

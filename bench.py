@@ -913,6 +913,23 @@ def main_single(args):
                                 "note": "bytes over PCIe (the table up once, texels down) / the call; peak = the pageable-copy rate measured on these "
                                         "boxes when the host pages sit on the GPU's NUMA node (configs.host_to_host); the upload alone is %.0f %% of the "
                                         "call, the palette K-Means (configs.config4) most of the rest" % (100.0 * prof["stage_ms"].get("upload", 0.0) / max(sum(prof["stage_ms"].values()), 1e-9))}}
+            # the table as the reference's converter hands it to the SOG writer: three u1 colour fields appended by add_rgb_from_sh
+            # (converter.py:243-252 -> 251-byte rows).  Read on the device as they are (fields assembled from two words of the LDS tile)
+            try:
+                wide = L.host_append_u8_columns(tab, ("red", "green", "blue"), np.zeros((m, 3), np.uint8))
+                sogw.encode(wide, level, device_resident=True)
+                wruns = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    wcore = sogw.encode(wide, level, device_resident=True)
+                    wruns.append((time.perf_counter() - t0) * 1e3)
+                res["rows_251_bytes"] = {"ms_per_step": round(sorted(wruns)[1], 2), "all_runs_ms": [round(v, 2) for v in wruns],
+                                         "note": "the same table widened by red / green / blue u1 fields (what converter.py:243-252 hands the writer): no host repack",
+                                         "geometry_textures_identical_to_248_byte_rows": bool(all(
+                                             np.array_equal(wcore["textures"][k_], core["textures"][k_]) for k_ in ("means_l", "means_u", "quats")))}
+                del wide, wcore
+            except Exception as e:   # noqa: BLE001
+                res["rows_251_bytes"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if want_cpu:   # cpu_baseline leg: the reference's own statements minus its K-Means calls, on a bounded subsample
                 from oracle import sog as osog
                 sub_n = 2_000_000

@@ -187,6 +187,12 @@ int gsx_rgb_from_sh_dev(gsx_ctx *ctx, const float *f_dc_dev, int64_t n, uint8_t 
 int gsx_host_zero_columns(void *rows, int64_t row_bytes, int64_t n, const int64_t *offsets, int ncols);
 int gsx_host_append_columns(const void *rows, int64_t row_bytes, int64_t n, const uint8_t *extra, int64_t extra_bytes,
                             void *out, int64_t out_row_bytes);
+/* both steps at once -- `self.data = vertices[mask]` (data_processor.py:114,149) then the widened copy of add_rgb_from_sh
+ * (:262-274), which is what the reference's converter does before every writer that needs colours (converter.py:243-252): output
+ * row j = source row idx[j] + the extra_bytes of THAT source row (extra: n x extra_bytes, indexed like the source table; idx strictly
+ * ascending).  One pass over the survivors instead of two copies of the table. */
+int gsx_host_take_rows_append(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
+                              const uint8_t *extra, int64_t extra_bytes, void *out, int64_t out_row_bytes);
 
 /*
  * The O(N) row filters that run before density / SOR (converter.py:196-203), as device masks over the chain's rows --

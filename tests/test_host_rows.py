@@ -202,3 +202,28 @@ def test_take_rows_by_the_survivor_list_is_boolean_indexing():
         L.host_take_rows(t, np.array([7, 7], dtype=np.uint32))
     with pytest.raises(L.GsxError):
         L.host_take_rows(t, np.array([1, len(t)], dtype=np.uint32))
+
+
+def test_take_rows_and_append_columns_in_one_pass():
+    """round 6: gsx_host_take_rows_append == the reference's two steps -- `vertices[mask]` (data_processor.py:114,149), then the
+    widened copy of add_rgb_from_sh (:262-274) with the colours of the surviving rows -- byte for byte; no survivors, every row,
+    bad index lists refused"""
+    rng = np.random.default_rng(12)
+    for n in (1, 9, 100_003):
+        t = _table(n, False, seed=n)
+        cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        for frac in (0.0, 0.4, 1.0):
+            mask = rng.random(n) < frac
+            idx = np.flatnonzero(mask).astype(np.uint32)
+            got = L.host_take_rows_append_u8(t, idx, ("red", "green", "blue"), cols)
+            kept = t[mask]
+            want = np.empty(len(kept), dtype=np.dtype(t.dtype.descr + [("red", "u1"), ("green", "u1"), ("blue", "u1")]))
+            for nm in t.dtype.names:
+                want[nm] = kept[nm]
+            for i, nm in enumerate(("red", "green", "blue")):
+                want[nm] = cols[mask, i]
+            assert got.dtype == want.dtype and got.tobytes() == want.tobytes()
+    with pytest.raises(L.GsxError):
+        L.host_take_rows_append_u8(t, np.array([5, 5], dtype=np.uint32), ("red", "green", "blue"), cols)
+    with pytest.raises(L.GsxError):
+        L.host_take_rows_append_u8(t, np.array([0, n], dtype=np.uint32), ("red", "green", "blue"), cols)
