@@ -391,6 +391,24 @@ def host_take_rows_append_u8(rows: np.ndarray, idx: np.ndarray, names, columns: 
     return out
 
 
+def nonzero_bytes(flags: np.ndarray) -> np.ndarray:
+    """np.flatnonzero of a SPARSE uint8 flag array, eight flags per look (the uncertain-element flags of the certificate kernels:
+    a few hundred set bytes in 30M; numpy's byte-wise scan takes 5x as long)"""
+    flags = np.ascontiguousarray(flags).reshape(-1)
+    n = len(flags)
+    m = n // 8 if flags.ctypes.data % 8 == 0 else 0
+    parts = []
+    if m:
+        words = np.flatnonzero(flags[:8 * m].view(np.uint64))
+        if len(words):
+            r, c = np.nonzero(flags[:8 * m].reshape(m, 8)[words])
+            parts.append(words[r] * 8 + c)
+    tail = np.flatnonzero(flags[8 * m:])
+    if len(tail):
+        parts.append(tail + 8 * m)
+    return np.concatenate(parts).astype(np.int64) if parts else np.zeros(0, np.int64)
+
+
 def rgb_from_sh(f_dc: np.ndarray, stats: dict | None = None) -> np.ndarray:
     """one channel of data_processor.py:316-343 -> u8[n], byte-identical to numpy (C ABI gsx_rgb_from_sh: float64 power on
     the GPU + rounding certificate; numpy's own expression for the flagged elements)"""
@@ -402,7 +420,7 @@ def rgb_from_sh(f_dc: np.ndarray, stats: dict | None = None) -> np.ndarray:
         return out
     unc = np.empty(n, dtype=np.uint8)
     check(lib.gsx_rgb_from_sh(v.ctypes.data, n, out.ctypes.data, unc.ctypes.data), "gsx_rgb_from_sh")
-    idx = np.flatnonzero(unc)
+    idx = nonzero_bytes(unc)
     if len(idx):
         with np.errstate(all="ignore"):
             lin = np.clip(0.5 + v[idx] * 0.28209479177387814, 0.0, 1.0)
@@ -1235,6 +1253,7 @@ class DeviceChain:
             b = out.download(np.float32, 7)
         finally:
             out.free()
+        self.bbox_nonfinite = bool(b[6] != 0)      # a NaN or an infinity among the coordinates (numpy's min / max would propagate a NaN)
         return [-b[0], -b[1], -b[2]], [b[3], b[4], b[5]]
 
     def density_voxels(self, voxel_size: float, min_points: int):

@@ -102,15 +102,16 @@ class DataProcessor:
             self._chain.close()
             self._chain = None
 
-    def _materialize(self):
+    def _materialize(self, copy_always=False):
         """apply the composed survivor list of the device chain to the host table (one threaded compaction), then the
-        deferred column fills of cap_sh_degree on the rows that are left"""
+        deferred column fills of cap_sh_degree on the rows that are left.  copy_always: a NEW table even when every row survives
+        (the eager methods: `self.data = vertices[mask]` is a copy whatever the mask, data_processor.py:114,149,212,224)"""
         rgb, self._pending_rgb = self._pending_rgb, None
         if self._chain is not None:
             ch = self._chain
             self._chain = None
             try:
-                if ch.n != ch.n0:
+                if ch.n != ch.n0 or copy_always:
                     # the chain's survivor list (ascending row indices) applied to the host table directly -- round 5: the
                     # boolean mask numpy would index with (`mask[survivors] = True` on 8M indices) cost more than the compaction
                     if rgb is not None:
@@ -134,6 +135,23 @@ class DataProcessor:
         if self._chain is None:
             self._chain = _lib.DeviceChain(_xyz_rows(vertices))
         return self._chain
+
+    def _columns(self, names):
+        """the named columns of the (materialised) table as contiguous arrays: one threaded pass (gsx_host_gather_columns_f32) for
+        float32 fields of a plain table, numpy's own copies otherwise.  Same values, so numpy's expressions on them give what they
+        give on the strided views the reference uses"""
+        d = self.data
+        fields = d.dtype.fields or {}
+        if isinstance(d, np.ndarray) and d.ndim == 1 and len(d) >= 4096 and all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names):
+            return list(_lib.host_gather_columns(d, list(names)))
+        return [d[nm] for nm in names]
+
+    def _column(self, name):
+        return self._columns((name,))[0]
+
+    def _xyz_is_f32(self):
+        names = self._data.dtype.names or ()
+        return all(f in names and self._data.dtype[f] == np.float32 for f in ("x", "y", "z"))
 
     def _flush_rgb(self):
         """a deferred add_rgb_from_sh changes the table's dtype: any further method sees the table the reference would have by then"""
@@ -277,10 +295,13 @@ class DataProcessor:
         if self.lazy and len(self) > 0 and self._data['opacity'].dtype == np.float32:
             ch = self._chain_for(self._data)
             original_len = ch.n
-            left = ch.ge_keep(self._data['opacity'], float(logit_thresh))   # np.float64 threshold: an f64 comparison
+            # (the column leaves the 248-byte rows through the threaded gather: numpy's strided copy takes ~45 ms at 10M splats)
+            left = ch.ge_keep(_lib.host_gather_columns(self._data, ["opacity"])[0], float(logit_thresh))   # np.float64 threshold: an f64 comparison
             status_print(f"Alpha Filter (min {limit}): Retained {left} out of {original_len} splats.")
             return None
-        mask = self.data['opacity'] >= logit_thresh
+        # eager (host table in, host table out at every call): the reference's expression on the column as ONE contiguous array
+        # (threaded gather; numpy's comparison on the 248-byte-stride view took 45 ms at 10M splats)
+        mask = self._column('opacity') >= logit_thresh
         original_len = len(self.data)
         self.data = _lib.host_compact_rows(self.data, mask)
         status_print(f"Alpha Filter (min {limit}): Retained {len(self.data)} out of {original_len} splats.")
@@ -289,15 +310,17 @@ class DataProcessor:
     def crop_by_bbox(self, min_x, min_y, min_z, max_x, max_y, max_z):
         """reference :215-231"""
         self._flush_rgb()
-        if self.lazy and isinstance(self._data, np.ndarray) and len(self) > 0 and all(
-                self._data.dtype[f] == np.float32 for f in ("x", "y", "z")):
+        if self.lazy and isinstance(self._data, np.ndarray) and len(self) > 0 and self._xyz_is_f32():
             left = self._chain_for(self._data).bbox_keep((min_x, min_y, min_z, max_x, max_y, max_z))
             debug_print(f"[DEBUG] Number of vertices after cropping: {left}")
             status_print(f"After cropping, retained {left} vertices.")
             return None
         d = self.data
-        mask = ((d['x'] >= min_x) & (d['x'] <= max_x) & (d['y'] >= min_y) & (d['y'] <= max_y) &
-                (d['z'] >= min_z) & (d['z'] <= max_z))
+        # eager: the reference's expression (:218-223) on contiguous copies of the three columns (one threaded gather) -- numpy's six
+        # comparisons on 248-byte-stride views took 283 ms at 10M splats
+        x, y, z = self._columns(("x", "y", "z"))
+        mask = ((x >= min_x) & (x <= max_x) & (y >= min_y) & (y <= max_y) &
+                (z >= min_z) & (z <= max_z))
         self.data = _lib.host_compact_rows(d, mask)
         debug_print(f"[DEBUG] Number of vertices after cropping: {len(self.data)}")
         status_print(f"After cropping, retained {len(self.data)} vertices.")
@@ -339,8 +362,8 @@ class DataProcessor:
             return (rgb * 255).astype(np.uint8)
         # (round 6: the three columns leave the table in ONE threaded pass and go through the device as one array -- three strided
         #  numpy copies of a 248-byte-stride column cost ~50 ms each at 10M splats)
-        mat = _lib.host_gather_columns(vertices, [prefix + "f_dc_%d" % c for c in range(3)])
-        return np.ascontiguousarray(_lib.rgb_from_sh(mat.reshape(-1)).reshape(3, len(vertices)).T)
+        mat = _lib.host_gather_xyz(vertices, [prefix + "f_dc_%d" % c for c in range(3)])       # (n, 3): the colours' own layout
+        return _lib.rgb_from_sh(mat.reshape(-1)).reshape(len(vertices), 3)
 
     def add_rgb_from_sh(self):
         """reference :233-274: append (red, green, blue) u1 fields computed from the SH DC term"""
@@ -387,9 +410,11 @@ class DataProcessor:
         if self._chain is not None:
             lo, hi = self._chain.bbox()
         else:
-            d = self._data
-            lo = [np.min(d[a]) for a in "xyz"]
-            hi = [np.max(d[a]) for a in "xyz"]
+            # the reference's reductions (:348-349) on contiguous copies of the columns (one threaded gather; six numpy reductions
+            # over 248-byte-stride views took 92 ms at 10M splats)
+            cols = self._columns(("x", "y", "z"))
+            lo = [np.min(c) for c in cols]
+            hi = [np.max(c) for c in cols]
         status_print(f"Auto-BBox Applied: [{lo[0]:.4f}, {lo[1]:.4f}, {lo[2]:.4f}] to [{hi[0]:.4f}, {hi[1]:.4f}, {hi[2]:.4f}]")
 
     # ------------------------------------------------------------------ names a newer reference might add
