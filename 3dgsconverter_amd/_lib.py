@@ -115,6 +115,8 @@ SIGNATURES = {
     "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_fields_nonzero_dev": (_I, [_P, _P, _I64, _I64, _I, C.POINTER(C.c_uint64)]),
+    "gsx_host_pinned_alloc": (_I, [_P, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gsx_host_pinned_free": (_I, [_P, _P]),
     "gsx_dev_upload_staged": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_download_staged": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_host_gather_f32": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I, _P]),
@@ -271,16 +273,24 @@ def _xyz_pointers(xyz_or_cols):
     return a, base, base + 4, base + 8, 3, a.shape[0]
 
 
-def host_gather_xyz(vertices: np.ndarray, names=("x", "y", "z")) -> np.ndarray:
+def host_gather_xyz(vertices: np.ndarray, names=("x", "y", "z"), out: "np.ndarray | None" = None) -> np.ndarray:
     """coords = np.column_stack((v['x'], v['y'], v['z'])) (data_processor.py:38,139) as float32 (N,3),
-    threaded (C ABI gsx_host_gather_f32).  Any layout the C routine cannot take goes through numpy."""
+    threaded (C ABI gsx_host_gather_f32).  Any layout the C routine cannot take goes through numpy.  out: a C-contiguous
+    (N, len(names)) float32 array to fill (a pinned staging buffer)"""
     fields = vertices.dtype.fields or {}
     ok = (vertices.ndim == 1 and vertices.flags.c_contiguous and
           all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names))
     if not ok:
-        return np.column_stack([np.asarray(vertices[nm], dtype=np.float32) for nm in names])
+        res = np.column_stack([np.asarray(vertices[nm], dtype=np.float32) for nm in names])
+        if out is not None:
+            out[...] = res
+            return out
+        return res
     n = len(vertices)
-    out = np.empty((n, len(names)), dtype=np.float32)
+    if out is None:
+        out = np.empty((n, len(names)), dtype=np.float32)
+    elif out.shape != (n, len(names)) or out.dtype != np.float32 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous (n, %d) float32 array" % len(names))
     if n == 0:
         return out
     offs = (_I64 * len(names))(*[int(fields[nm][1]) for nm in names])
@@ -1146,6 +1156,8 @@ class DeviceArena:
         self.ctx = Context(device)
         self._side = None
         self._bufs = {}
+        self._pinned = {}
+        self._leases = set()
 
     @property
     def side(self) -> "Context":
@@ -1164,13 +1176,44 @@ class DeviceArena:
             self._bufs[name] = cur
         return cur
 
+    def pinned(self, name: str, nbytes: int) -> np.ndarray:
+        """a named grow-only PAGE-LOCKED host buffer as a uint8 array (hipHostMalloc: the DMA engines read it at link rate)"""
+        nbytes = max(int(nbytes), 16)
+        cur = self._pinned.get(name)
+        if cur is None or cur[1] < nbytes:
+            if cur is not None:
+                self.ctx.lib.gsx_host_pinned_free(self.ctx.handle, C.c_void_p(cur[0]))
+                del self._pinned[name]
+            p = C.c_void_p()
+            check(self.ctx.lib.gsx_host_pinned_alloc(self.ctx.handle, nbytes, C.byref(p)), "gsx_host_pinned_alloc")
+            cur = self._pinned[name] = (p.value, nbytes)
+        return np.ctypeslib.as_array((C.c_uint8 * cur[1]).from_address(cur[0]))
+
+    def lease(self, who: str) -> bool:
+        """one user of the buffers named after `who` at a time (a second DeviceChain alive at the same moment gets a context and
+        buffers of its own)"""
+        if who in self._leases:
+            return False
+        self._leases.add(who)
+        return True
+
+    def unlease(self, who: str):
+        self._leases.discard(who)
+
     def held_bytes(self) -> int:
         return sum(b.nbytes for b in self._bufs.values())
+
+    def held_pinned_bytes(self) -> int:
+        return sum(nb for _, nb in self._pinned.values())
 
     def release(self):
         for b in self._bufs.values():
             b.free()
         self._bufs.clear()
+        for ptr, _ in self._pinned.values():
+            if self.ctx is not None and self.ctx.handle:
+                self.ctx.lib.gsx_host_pinned_free(self.ctx.handle, C.c_void_p(ptr))
+        self._pinned.clear()
         for c in (self._side, self.ctx):
             if c is not None:
                 c.close()
@@ -1203,28 +1246,67 @@ class DeviceChain:
     filter leaves its mask in HBM, ``gsx_compact_rows_dev`` compacts the rows there, and the composed survivor list comes
     back once -- the 248-byte host rows are compacted once, after the last filter."""
 
-    def __init__(self, xyz_rows: np.ndarray, device: int = 0, keep_pristine: bool = False):
-        a = np.ascontiguousarray(xyz_rows, dtype=np.float32)
+    def __init__(self, xyz_rows: "np.ndarray | None" = None, device: int = 0, keep_pristine: bool = False, table: "np.ndarray | None" = None):
+        """xyz_rows: (n, 3) coordinates, or table: the structured splat table itself -- its x, y, z are then gathered (threaded, C ABI
+        gsx_host_gather_f32) straight into a page-locked staging buffer of the arena: no 12n-byte temporary whose pages are faulted
+        in, copied from at pageable rate and unmapped again (9 + 5 + 9 ms of configs.dropin_e2e_10m's 37)"""
+        if table is not None:
+            require_hip()
+            ar0 = arena(device)
+            n_t = len(table)
+            if n_t >= 4096 and "chain" not in ar0._leases:
+                a = host_gather_xyz(table, out=ar0.pinned("chain_xyz", 12 * n_t)[:12 * n_t].view(np.float32).reshape(n_t, 3))
+            else:
+                a = host_gather_xyz(table)
+        else:
+            a = np.ascontiguousarray(xyz_rows, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] != 3:
             raise ValueError("Requires 3D data")
-        self.ctx = Context(device)
+        # round 6: the process-wide arena's context and named buffers when no other chain holds them -- a chain per filter run used
+        # to create a context, hipMalloc its ~37 bytes per row and, inside the context, the whole KNN workspace, and free it all
+        # again at close(): 10-12 of the 37 ms of configs.dropin_e2e_10m.  release_arenas() gives the memory back.
+        require_hip()
+        ar = arena(device)
+        self._ar = ar if ar.lease("chain") else None
+        self.ctx = ar.ctx if self._ar is not None else Context(device)
+        self._names = iter(range(1 << 30))
         self.ctx.set_param("adaptive", 1)   # every step below synchronises anyway
         self.n0 = self.n = int(a.shape[0])
-        self.rows = self.ctx.alloc(max(a.nbytes, 16)).upload(a)
-        self.spare = self.ctx.alloc(max(a.nbytes, 16))
+        self.rows = self._alloc(max(a.nbytes, 16), "rows")
+        if a.nbytes >= (32 << 20) and table is None:          # through the pinned staging lanes: a caller's array is pageable memory
+            check(self.ctx.lib.gsx_dev_upload_staged(self.ctx.handle, self.rows.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload_staged")
+        else:
+            self.rows.upload(a)
+        self.spare = self._alloc(max(a.nbytes, 16), "spare")
         # bench.py only: a second device copy of the uploaded rows, so that restart() can run the chain again without PCIe
-        self.pristine = self.ctx.alloc(max(a.nbytes, 16)) if keep_pristine else None
+        self.pristine = self._alloc(max(a.nbytes, 16), "pristine") if keep_pristine else None
         if self.pristine is not None:
             check(self.ctx.lib.gsx_dev_copy(self.ctx.handle, self.pristine.ptr, self.rows.ptr, a.nbytes), "gsx_dev_copy")
         self.orig = None                    # None = identity
         self._pool = []                     # survivor-list buffers not in use (4 n0 bytes each; at most two ever exist)
         self.empty = False                  # keep_none(): no survivor, whatever self.orig says
-        self.mask = self.ctx.alloc(self.n0 + 16)
+        self.mask = self._alloc(self.n0 + 16, "mask")
         self._md = self._st = None          # SOR work buffers (mean distances, statistics), allocated on first use
         self._pristine_box = None           # box of the uploaded rows, when it was measured before any filter ran (restart() keeps it)
         self._box = None                    # box of the rows at the first density_filter() (a superset of every LATER state of the
                                             # chain; restart() drops it).  gsx_density_filter_dev re-derives the frame itself when
                                             # a row falls outside the box it was given (status word `oob` of the device result)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _alloc(self, nbytes: int, name: str):
+        """a named grow-only buffer of the arena while this chain holds its lease, an allocation of its own otherwise"""
+        if self._ar is not None:
+            return self._ar.buf("chain_" + name, nbytes)
+        return self.ctx.alloc(nbytes)
+
+    def _free(self, b):
+        if b is not None and self._ar is None:
+            b.free()
 
     def restart(self):
         """back to the state right after the upload (needs keep_pristine): device-to-device copy, identity survivor list"""
@@ -1246,13 +1328,13 @@ class DeviceChain:
 
     def bbox(self):
         """per-axis (min, max) of the surviving rows (gsx_slab_bbox_dev: the multi-GPU path's box kernel) -> ([3], [3]) float32"""
-        out = self.ctx.alloc(32)
+        out = self._alloc(32, "bbox")
         try:
             x, y, z, st = self._xyz()
             check(self.ctx.lib.gsx_slab_bbox_dev(self.ctx.handle, x, y, z, st, self.n, out.ptr), "gsx_slab_bbox_dev")
             b = out.download(np.float32, 7)
         finally:
-            out.free()
+            self._free(out)
         self.bbox_nonfinite = bool(b[6] != 0)      # a NaN or an infinity among the coordinates (numpy's min / max would propagate a NaN)
         return [-b[0], -b[1], -b[2]], [b[3], b[4], b[5]]
 
@@ -1288,7 +1370,7 @@ class DeviceChain:
         return out
 
     def _compact(self) -> int:
-        out = self._pool.pop() if self._pool else self.ctx.alloc(4 * self.n0 + 16)
+        out = self._pool.pop() if self._pool else self._alloc(4 * self.n0 + 16, "list%d" % next(self._names))
         n_out = C.c_int64()
         check(self.ctx.lib.gsx_compact_rows_dev(self.ctx.handle, self.rows.ptr, self.orig.ptr if self.orig is not None else None,
                                                 self.mask.ptr, self.n, self.spare.ptr, out.ptr, C.byref(n_out)),
@@ -1325,19 +1407,19 @@ class DeviceChain:
         col = np.ascontiguousarray(column, dtype=np.float32)
         if col.shape != (self.n0,):
             raise ValueError("column must have one value per original row")
-        dev = self.ctx.alloc(max(col.nbytes, 16)).upload(col)
+        dev = self._alloc(max(col.nbytes, 16), "column").upload(col)
         try:
             check(self.ctx.lib.gsx_mask_ge_dev(self.ctx.handle, dev.ptr, self.orig.ptr if self.orig is not None else None, self.n,
                                                float(threshold), self.mask.ptr), "gsx_mask_ge_dev")
             return self._compact()
         finally:
-            dev.free()
+            self._free(dev)
 
     def sor_keep(self, k: int, threshold_factor: float):
         numpy_reduction_selfcheck(self.ctx)
         n = self.n
         if self._md is None:                # sized for the whole table once: no allocation in later calls
-            self._md, self._st = self.ctx.alloc(4 * self.n0 + 16), self.ctx.alloc(16)
+            self._md, self._st = self._alloc(4 * self.n0 + 16, "md"), self._alloc(16, "st")
         md, st = self._md, self._st
         x, y, z, stride = self._xyz()
         self.ctx.sor_knn(x, y, z, stride, n, 0, n, int(k), md.ptr)
@@ -1357,7 +1439,25 @@ class DeviceChain:
         return self.orig.download(np.uint32, self.n) if self.n else np.zeros(0, np.uint32)
 
     def close(self):
+        if self._ar is not None:             # the arena keeps the buffers and the context (and its KNN workspace) for the next chain
+            ar, self._ar = self._ar, None
+            healthy = False
+            if self.ctx is not None and self.ctx.handle:
+                try:
+                    self.ctx.set_param("adaptive", 0)
+                    self.ctx.synchronize()
+                    healthy = True
+                except GsxError:
+                    pass
+            ar.unlease("chain")
+            self.ctx = None
+            if not healthy:                  # a failed HIP call somewhere in this chain: do not hand the context on
+                release_arenas()
+            return
+        if self.ctx is None:
+            return
         for b in (self.rows, self.spare, self.orig, self.mask, self.pristine, self._md, self._st, *self._pool):
             if b is not None:
                 b.free()
         self.ctx.close()
+        self.ctx = None

@@ -308,6 +308,23 @@ int gsx_dev_malloc(gsx_ctx *c, size_t bytes, void **dptr)
     return 0;
 }
 
+// page-locked host memory the DMA engines read at link rate (a staging buffer a host routine fills, e.g. gsx_host_gather_f32 writing
+// the (n, 3) coordinates of a table straight into it: no page faults of a fresh allocation, no munmap afterwards)
+int gsx_host_pinned_alloc(gsx_ctx *c, size_t bytes, void **hptr)
+{
+    if (!c || !hptr) GSX_FAIL("gsx_host_pinned_alloc: bad arguments");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+int gsx_host_pinned_free(gsx_ctx *c, void *hptr)
+{
+    if (!c) GSX_FAIL("null ctx");
+    if (hptr) GSX_HIP(hipHostFree(hptr));
+    return 0;
+}
+
 int gsx_dev_free(gsx_ctx *c, void *dptr)
 {
     if (!c) GSX_FAIL("null ctx");

@@ -133,7 +133,7 @@ class DataProcessor:
 
     def _chain_for(self, vertices):
         if self._chain is None:
-            self._chain = _lib.DeviceChain(_xyz_rows(vertices))
+            self._chain = _lib.DeviceChain(table=vertices)      # (coords gathered straight into a page-locked staging buffer)
         return self._chain
 
     def _columns(self, names):

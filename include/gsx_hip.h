@@ -121,6 +121,10 @@ int  gsx_ctx_set_param(gsx_ctx *ctx, const char *name, double value);
 /* raw device memory for hosts that have no other allocator (bench without torch) */
 int gsx_dev_malloc(gsx_ctx *ctx, size_t bytes, void **dptr);
 int gsx_dev_free(gsx_ctx *ctx, void *dptr);
+/* page-locked host memory (hipHostMalloc) for staging buffers that host routines fill and the device reads at link rate: the lazy
+ * DataProcessor gathers `coords` (data_processor.py:38,139) straight into one, once per process */
+int gsx_host_pinned_alloc(gsx_ctx *ctx, size_t bytes, void **hptr);
+int gsx_host_pinned_free(gsx_ctx *ctx, void *hptr);
 int gsx_dev_upload(gsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gsx_dev_download(gsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int gsx_dev_copy(gsx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* device to device, asynchronous */

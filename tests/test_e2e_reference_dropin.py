@@ -71,7 +71,9 @@ def dropin(gsx, monkeypatch):
     class FakeChain:
         """_lib.DeviceChain (coordinates resident in HBM across filters) with the oracle as the device"""
 
-        def __init__(self, xyz_rows, device=0):
+        def __init__(self, xyz_rows=None, device=0, table=None):
+            if table is not None:      # round 6: the class gathers the coordinates itself (into a page-locked staging buffer)
+                xyz_rows = lib.host_gather_xyz(table)
             self.xyz = np.ascontiguousarray(xyz_rows, dtype=np.float32)
             self.n0 = self.n = len(self.xyz)
             self.idx = np.arange(self.n0)
