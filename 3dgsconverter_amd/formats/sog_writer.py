@@ -71,11 +71,28 @@ def _webp_all(zf, jobs):
         zf.writestr(j[0], blob)
 
 
+def _cols(ds, names):
+    """the named columns as contiguous arrays: ONE threaded pass over the rows for float32 fields (numpy's strided copies of a
+    248-byte-stride view cost ~5 ms per column and million rows), the views themselves for any other dtype"""
+    fields = ds.dtype.fields or {}
+    if len(ds) >= 4096 and all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names):
+        return list(_lib.host_gather_columns(ds, list(names)))
+    return [ds[nm] for nm in names]
+
+
+def _rows(ds, names):
+    """np.column_stack of the named columns -> (n, len(names)): row-major straight out of the threaded gather for float32 fields"""
+    fields = ds.dtype.fields or {}
+    if len(ds) >= 4096 and all(nm in fields and fields[nm][0] == np.dtype("<f4") for nm in names):
+        return _lib.host_gather_xyz(ds, list(names))
+    return np.column_stack([ds[nm] for nm in names])
+
+
 def _positions(ds):
     """:279-309 -- GPU transcendental + certificate, numpy for the texels next to a rounding boundary (_lib.sog_positions)"""
     u16, mins, maxs = [], [], []
-    for a in "xyz":
-        u, mn, mx = _lib.sog_positions(ds[a])
+    for col in _cols(ds, "xyz"):
+        u, mn, mx = _lib.sog_positions(col)
         u16.append(u)
         mins.append(mn)
         maxs.append(mx)
@@ -84,7 +101,8 @@ def _positions(ds):
 
 def _scalar_codebook(columns, ds, label):
     """:392-423 / :435-449: 256-entry codebook of the 3N scalars (fit on a 50 000-sample), then nearest-entry indices"""
-    flat = np.concatenate([ds[c] for c in columns])
+    cols = _cols(ds, columns)
+    flat = np.concatenate(cols)
     status_print(label)
     fit = flat
     if len(flat) > 50000:
@@ -93,8 +111,8 @@ def _scalar_codebook(columns, ds, label):
     # sklearn without.  The scalar solver gives the better of the two qualities deterministically.
     cent, _ = gpu_ops.kmeans(fit.reshape(-1, 1), 256, max_iter=20, init="k-means++")
     codebook = np.array(sorted(cent.flatten()))
-    idx = [gpu_ops.quantize_to_codebook(np.ascontiguousarray(ds[c]), codebook) if len(codebook) > 1
-           else np.zeros(len(ds), np.uint8) for c in columns]
+    idx = [gpu_ops.quantize_to_codebook(np.ascontiguousarray(c), codebook) if len(codebook) > 1
+           else np.zeros(len(ds), np.uint8) for c in cols]
     return codebook, idx
 
 
@@ -141,7 +159,7 @@ def _encode_host(data: np.ndarray, level: int, comm=None, be=None) -> dict:
 
     # rotations (:315-386)
     quats = np.full((texels, 4), 255, np.uint8)
-    quats[:n] = _lib.sog_quats(np.column_stack((ds["rot_0"], ds["rot_1"], ds["rot_2"], ds["rot_3"])))
+    quats[:n] = _lib.sog_quats(_rows(ds, ("rot_0", "rot_1", "rot_2", "rot_3")))
     out["textures"]["quats"] = quats
 
     # scales (:388-431) and colours + opacity (:433-459)
@@ -152,14 +170,14 @@ def _encode_host(data: np.ndarray, level: int, comm=None, be=None) -> dict:
     color_cb, (d0, d1, d2) = _scalar_codebook(("f_dc_0", "f_dc_1", "f_dc_2"), ds, "Clustering Colors...")
     sh0 = np.zeros((texels, 4), np.uint8)
     sh0[:n, 0], sh0[:n, 1], sh0[:n, 2] = d0, d1, d2
-    sh0[:n, 3] = _lib.sog_alpha(ds["opacity"])                                                 # :457-459
+    sh0[:n, 3] = _lib.sog_alpha(_cols(ds, ("opacity",))[0])                                    # :457-459
     out["textures"]["sh0"], out["color_codebook"] = sh0, color_cb
 
     # SH-N palette (:496-600)
     bands = out["bands"] = _sh_bands(data, ds)
     if bands > 0:
         coeffs = [0, 9, 24, 45][bands]
-        sh = np.column_stack([ds["f_rest_%d" % i] for i in range(coeffs)]).astype(np.float32)
+        sh = _rows(ds, ["f_rest_%d" % i for i in range(coeffs)]).astype(np.float32, copy=False)
         status_print(f"SOG Write Quality Level: {level} (0=Max, 9=Min)")
         status_print(f"SH Clustering: K={dist_palette.palette_plan(n, level)['target_k']}, Points={n}. Strategy: GPU (HIP gfx950)")
         centroids, labels = dist_palette.palette_kmeans(sh, level, 10, comm=comm, be=be)

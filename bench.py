@@ -807,7 +807,7 @@ def main_single(args):
             sogw = importlib.import_module("3dgsconverter_amd.formats.sog_writer")
             sogw.encode(tab, 2, device_resident=True)
             resident = sogw.encode(tab, 2, device_resident=True, profile=True)["stage_ms"]
-            t_pos, _ = best_of(lambda: [L.sog_positions(tab[a]) for a in "xyz"])
+            t_pos, _ = best_of(lambda: [L.sog_positions(c) for c in L.host_gather_columns(tab, ["x", "y", "z"])])   # as _encode_host calls it
             t_quat, _ = best_of(lambda: L.sog_quats(rot))
             t_alpha, _ = best_of(lambda: L.sog_alpha(opa))
             t_cply, enc = best_of(lambda: cply.encode(tab), reps=2)
