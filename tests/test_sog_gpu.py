@@ -428,7 +428,8 @@ def test_device_resident_core_on_a_scene_far_from_the_origin(gsx):
         _check_core_against_numpy(core, data, 4)
 
 
-@pytest.mark.parametrize("front,back,deg", [(0, 3, 3), (1, 0, 3), (2, 1, 2), (3, 2, 1), (0, 1, 0), (5, 6, 3), (1, 251, 3)])
+@pytest.mark.parametrize("front,back,deg", [(0, 3, 3), (1, 0, 3), (2, 1, 2), (3, 2, 1), (0, 1, 0), (5, 6, 3), (1, 251, 3), (3, 248, 3),
+                                            (0, 264, 3)])      # ... 500- and 499-byte rows (the largest off the grid), 512 on it
 def test_device_resident_core_reads_rows_off_the_four_byte_grid(gsx, front, back, deg):
     """round 6: rows whose size is not a multiple of 4 (the reference's converter appends three u1 colour fields before it calls the
     SOG writer, converter.py:243-252 -> 251 bytes) and float fields at odd offsets (u1 fields in front) are read on the device as
