@@ -1232,10 +1232,12 @@ def arena(device: int = 0) -> DeviceArena:
 
 def release_arenas():
     """free every cached work buffer and context of the writers' arenas (they are re-created on the next call)"""
-    for a in list(_arenas.values()):
+    for dev, a in list(_arenas.items()):
+        if a._leases:            # a device chain is alive on this arena's context (a lazy DataProcessor with pending filters): it keeps it
+            continue
         if a.ctx is not None:
             a.release()
-    _arenas.clear()
+        del _arenas[dev]
 
 
 class DeviceChain:
@@ -1268,12 +1270,23 @@ class DeviceChain:
         require_hip()
         ar = arena(device)
         self._ar = ar if ar.lease("chain") else None
+        self.ctx = None
+        self.rows = self.spare = self.orig = self.mask = self.pristine = self._md = self._st = None
+        self._pool = []
+        try:
+            self._setup(a, device, keep_pristine, table is not None)
+        except BaseException:
+            self.close()                    # (gives the lease back; a private context and its buffers are freed)
+            raise
+
+    def _setup(self, a, device, keep_pristine, pinned_source):
+        ar = self._ar
         self.ctx = ar.ctx if self._ar is not None else Context(device)
         self._names = iter(range(1 << 30))
         self.ctx.set_param("adaptive", 1)   # every step below synchronises anyway
         self.n0 = self.n = int(a.shape[0])
         self.rows = self._alloc(max(a.nbytes, 16), "rows")
-        if a.nbytes >= (32 << 20) and table is None:          # through the pinned staging lanes: a caller's array is pageable memory
+        if a.nbytes >= (32 << 20) and not pinned_source:      # through the pinned staging lanes: a caller's array is pageable memory
             check(self.ctx.lib.gsx_dev_upload_staged(self.ctx.handle, self.rows.ptr, a.ctypes.data, a.nbytes), "gsx_dev_upload_staged")
         else:
             self.rows.upload(a)
