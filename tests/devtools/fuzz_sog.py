@@ -15,7 +15,7 @@ def make(rng):
     n = int(np.exp(rng.uniform(np.log(1100), np.log(400000))))
     deg = int(rng.choice([0, 1, 2, 3], p=[0.1, 0.15, 0.15, 0.6]))
     t = datasets.sog_scene(n, int(rng.integers(1 << 30)), sh_degree=deg)
-    kind = str(rng.choice(["scene", "wide", "tiny", "grid", "dups", "onesided"]))
+    kind = str(rng.choice(["scene", "wide", "tiny", "grid", "dups", "onesided", "offset"]))
     for a in "xyz":
         if kind == "wide":
             t[a] = (rng.standard_normal(n) * np.exp(rng.uniform(-10, 10, n))).astype(np.float32)
@@ -27,6 +27,8 @@ def make(rng):
             t[a] = c
         elif kind == "onesided":
             t[a] = (np.abs(rng.standard_normal(n)) + rng.uniform(0, 5)).astype(np.float32)
+        elif kind == "offset":      # a capture far from the origin: most position texels sit next to a rounding boundary of numpy's log
+            t[a] = (rng.standard_normal(n) * rng.uniform(0.2, 3) + rng.choice([-1, 1]) * np.exp(rng.uniform(np.log(5), np.log(3000)))).astype(np.float32)
     if kind == "dups":
         src = rng.integers(0, n, n // 3)
         dst = rng.integers(0, n, n // 3)
@@ -36,12 +38,15 @@ def make(rng):
     if ncoef and rng.random() < 0.4:      # zero a tail of the coefficients: band downgrade
         for i in range(int(rng.integers(0, ncoef)), ncoef):
             t["f_rest_%d" % i] = np.float32(-0.0) if rng.random() < 0.3 else 0.0
-    if rng.random() < 0.2:                # odd row size
-        wide = np.zeros(n, dtype=np.dtype(t.dtype.descr + [("red", "u1"), ("green", "u1")]))
-        for nm in t.dtype.names:
-            wide[nm] = t[nm]
+    if rng.random() < 0.4:                # rows off the 4-byte grid: u1 fields behind (the converter's colours) and / or in front of the floats
+        front, back = int(rng.integers(0, 4)), int(rng.integers(0, 6))
+        if front + back == 0:
+            back = 3
+        wide = np.zeros(n, dtype=np.dtype([("pre%d" % i, "u1") for i in range(front)] + t.dtype.descr + [("post%d" % i, "u1") for i in range(back)]))
+        for nm in wide.dtype.names:
+            wide[nm] = t[nm] if nm in t.dtype.names else rng.integers(0, 256, n, dtype=np.uint8)
         t = wide
-        kind += "+u1"
+        kind += "+u1(%d,%d)" % (front, back)
     return kind, t, int(rng.integers(0, 10))
 
 
@@ -57,7 +62,7 @@ def main(cases=40, seed=0):
                 core = w.encode(tab, level, device_resident=True)
                 ref = osog.write_core_without_kmeans(tab, core["scale_codebook"], core["color_codebook"])
         except sd.NotEligible as e:
-            print("%3d %-12s n=%7d level %d declined (%s)" % (c, kind, n, level, e), flush=True)
+            print("%3d %-18s n=%7d level %d declined (%s)" % (c, kind, n, level, e), flush=True)
             continue
         for name in ("means_l", "means_u", "quats", "scales", "sh0"):
             if not np.array_equal(core["textures"][name], ref[name]):
@@ -75,7 +80,7 @@ def main(cases=40, seed=0):
             if not np.all(lab // plan["k_per_chunk"] == np.arange(n) // plan["chunk_size"]):
                 what.append("labels outside their chunk's slice")
         bad += bool(what)
-        print("%3d %-12s n=%7d level %d bands %d uncertain %d+%d %s" % (c, kind, n, level, core["bands"], core["stats"]["uncertain_positions"],
+        print("%3d %-18s n=%7d level %d bands %d uncertain %d+%d %s" % (c, kind, n, level, core["bands"], core["stats"]["uncertain_positions"],
                                                                      core["stats"]["uncertain_alpha"], "MISMATCH " + "; ".join(what) if what else "ok"), flush=True)
     print("fuzz_sog: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
     return bad
