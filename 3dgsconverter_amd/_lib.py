@@ -115,6 +115,7 @@ SIGNATURES = {
     "gsx_dev_upload_async": (_I, [_P, _P, _P, C.c_size_t]),
     "gsx_dev_memset": (_I, [_P, _P, _I, C.c_size_t]),
     "gsx_fields_nonzero_dev": (_I, [_P, _P, _I64, _I64, _I, C.POINTER(C.c_uint64)]),
+    "gsx_rows_repack_dev": (_I, [_P, _P, _I64, _I64, _P, _I64]),
     "gsx_host_pinned_alloc": (_I, [_P, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gsx_host_pinned_free": (_I, [_P, _P]),
     "gsx_dev_upload_staged": (_I, [_P, _P, _P, C.c_size_t]),
@@ -905,7 +906,9 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
     m = len(sh_names)
     base_names = ["opacity" if c == "alpha" else c for c in CPLY_COLUMNS]
     names = base_names + sh_names
-    resident = (ctx is None and n >= 1024 and data.ndim == 1 and data.flags.c_contiguous and data.dtype.itemsize % 4 == 0
+    # (rows that are not a multiple of 4 bytes -- three u1 colour fields behind the floats: 251 -- are copied to 252-byte rows ON the
+    #  device after the upload: gsx_rows_repack_dev, ~2 ms per 10M rows)
+    resident = (ctx is None and n >= 1024 and data.ndim == 1 and data.flags.c_contiguous
                 and all(nm in fields and fields[nm][0] == np.dtype("<f4") and fields[nm][1] % 4 == 0 for nm in names)
                 and all(fields[sh_names[i]][1] == fields[sh_names[0]][1] + 4 * i for i in range(m)))
     if resolve and not resident:
@@ -939,10 +942,15 @@ def cply_pack_table(data: np.ndarray, sh_names, order: "np.ndarray | None" = Non
         toucher = prefault(*(a for a in (verts, sh) if a is not None)) if resident and n >= (1 << 18) else None
         toucher2 = None
         if resident:
-            rd = data.dtype.itemsize // 4
-            d_rows = alloc(data.nbytes, "rows")
+            pitch = (data.dtype.itemsize + 3) & ~3
+            rd = pitch // 4
+            d_rows = alloc(data.nbytes + 16, "rows")
             upload_table(lib, ctx, d_rows.ptr, data)
             mark("upload")
+            if pitch != data.dtype.itemsize:
+                d_raw, d_rows = d_rows, alloc(n * pitch, "rows_aligned")
+                check(lib.gsx_rows_repack_dev(ctx.handle, d_raw.ptr, data.dtype.itemsize, n, d_rows.ptr, pitch), "gsx_rows_repack_dev")
+                mark("repack")
             if resolve:
                 word = C.c_uint64(0)
                 if m:

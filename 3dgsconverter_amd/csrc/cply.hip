@@ -441,6 +441,30 @@ __global__ __launch_bounds__(256) void cply_sh_kernel(const float *__restrict__ 
 
 using namespace gsx;
 
+// Rows whose size is not a multiple of 4 (the table widened by three u1 colour fields, data_processor.py:262-274: 251 bytes) copied
+// to rows of `dst_pitch` bytes (a multiple of 4): fields at 4-byte offsets inside a row then sit on the 4-byte grid of the device
+// buffer and the strided packers below read them with plain float loads.  One thread per destination dword; the two source
+// dwords it straddles are shared with its neighbours through the L1 / L2.
+__global__ __launch_bounds__(256) void rows_repack_kernel(const unsigned *__restrict__ src, int64_t row_bytes, int64_t n, unsigned *__restrict__ dst,
+                                                          int dst_dwords)
+{
+    const int64_t total = n * dst_dwords;
+    const int row_dwords = (int)((row_bytes + 3) >> 2);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / dst_dwords;
+        const int j = (int)(e - r * dst_dwords);
+        unsigned v = 0u;
+        if (j < row_dwords) {
+            const int64_t b = r * row_bytes + 4 * (int64_t)j;          // first source byte of this dword
+            const unsigned lo = src[b >> 2], hi = src[(b >> 2) + 1];   // (one dword past the table at most: see the header)
+            v = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(b & 3));
+            const int valid = (int)min((int64_t)4, row_bytes - 4 * (int64_t)j);   // the row's last dword: the bytes behind it are the NEXT row's
+            if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+        }
+        dst[e] = v;
+    }
+}
+
 // compressed_ply.py:139-150 (and sog.py:476-486): which of m consecutive float fields of the rows hold a value != 0 (NaN counts, -0.0
 // does not: numpy's `data[f] != 0`).  Lane = field, a wave walks rows with 8 loads in flight; one OR per wave at the end.
 __global__ __launch_bounds__(256) void fields_nonzero_kernel(const float *__restrict__ base, int64_t row_stride, int64_t n, int m,
@@ -530,6 +554,22 @@ int gsx_cply_sh_strided_dev(gsx_ctx *c, const float *cols_dev, int m, int64_t co
     if (n == 0 || m == 0) return 0;
     hipLaunchKernelGGL(cply_sh_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, c->stream, cols_dev, m, col_stride, elem_stride, order_dev, n,
                        out_dev);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+int gsx_rows_repack_dev(gsx_ctx *c, const void *rows_dev, int64_t row_bytes, int64_t n, void *out_dev, int64_t out_pitch)
+{
+    if (!c || (n > 0 && (!rows_dev || !out_dev))) GSX_FAIL("gsx_rows_repack_dev: null argument");
+    if (n < 0 || row_bytes < 1 || out_pitch < row_bytes || (out_pitch & 3) || out_pitch > (1 << 20)) GSX_FAIL("gsx_rows_repack_dev: bad size");
+    if ((reinterpret_cast<uintptr_t>(rows_dev) & 3) || (reinterpret_cast<uintptr_t>(out_dev) & 3)) GSX_FAIL("gsx_rows_repack_dev: buffers must be 4-byte aligned");
+    GSX_HIP(hipSetDevice(c->device));
+    if (n == 0) return 0;
+    const int dd = (int)(out_pitch / 4);
+    const int64_t total = n * dd;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(div_up(total, (int64_t)1024), (int64_t)c->num_cu * 16));
+    hipLaunchKernelGGL(rows_repack_kernel, dim3(blocks), dim3(256), 0, c->stream, static_cast<const unsigned *>(rows_dev), row_bytes, n,
+                       static_cast<unsigned *>(out_dev), dd);
     GSX_HIP(hipGetLastError());
     return 0;
 }

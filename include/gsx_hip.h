@@ -590,6 +590,11 @@ int gsx_cply_sh_strided_dev(gsx_ctx *ctx, const float *cols_dev, int m, int64_t 
  * + c], s < n -- holds a value != 0 (NaN counts, -0.0 does not, as in numpy).  One pass over the rows (10M x 45 fields: < 1 ms) where
  * the reference's loop costs ~0.1 s per strided column.  Synchronises the context's stream. */
 int gsx_fields_nonzero_dev(gsx_ctx *ctx, const float *first_field_dev, int64_t row_stride, int64_t n, int m, uint64_t *mask_out);
+/* rows of any size -> rows of out_pitch bytes (a multiple of 4 >= row_bytes; the padding bytes are zero), both resident in HBM: the
+ * table the reference's converter widens by three u1 colour fields (data_processor.py:262-274, 251-byte rows) becomes one whose
+ * float32 fields at 4-byte offsets can be read by the strided packers above.  rows_dev must be readable up to 8 bytes past the
+ * last row (a device allocation's slack). */
+int gsx_rows_repack_dev(gsx_ctx *ctx, const void *rows_dev, int64_t row_bytes, int64_t n, void *out_dev, int64_t out_pitch);
 /* ... with column 9 = the OPACITY itself (compressed_ply.py:200-203 `1.0 / (1.0 + np.exp(-x))`, then :312 floor(a * 255 + 0.5)): the
  * alpha byte comes from a float64 exp + the rounding certificate of gsx_sog_alpha; list_dev receives `cap` entries of two uint32
  * (position in the NEW order, bits of the opacity) for the ~1e-4 splats whose byte the caller patches with numpy's own expression

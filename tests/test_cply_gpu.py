@@ -213,3 +213,39 @@ def test_degree_detection_on_resident_rows_is_the_host_scan(gsx, writer, last):
     np.testing.assert_array_equal(vertex.view(np.uint32).reshape(-1, 4), wv)
     if want_names:
         np.testing.assert_array_equal(sh.view(np.uint8).reshape(len(d), -1), wsh)
+
+
+def test_rows_repack_and_the_writer_on_a_table_widened_by_colour_fields(gsx, writer):
+    """round 6: gsx_rows_repack_dev (rows of any size -> rows padded to a multiple of 4, on the device) against numpy, and through it the
+    compressed-PLY writer on the 251-byte rows add_rgb_from_sh leaves (data_processor.py:262-274; `--rgb` with this target):
+    device-resident like the plain table, same elements"""
+    lib = gsx._lib
+    ctx = lib.Context(0)
+    rng = np.random.default_rng(4)
+    try:
+        for rb, n in [(251, 1), (251, 1000), (249, 4097), (7, 333), (1, 17), (250, 100_003), (248, 50)]:
+            raw = rng.integers(0, 256, (n, rb), dtype=np.uint8)
+            pitch = (rb + 3) & ~3
+            src = ctx.alloc(raw.nbytes + 16).upload(raw)
+            dst = ctx.alloc(n * pitch)
+            lib.check(lib.require_hip().gsx_rows_repack_dev(ctx.handle, src.ptr, rb, n, dst.ptr, pitch), "gsx_rows_repack_dev")
+            got = dst.download(np.uint8, n * pitch).reshape(n, pitch)
+            np.testing.assert_array_equal(got[:, :rb], raw)
+            assert not got[:, rb:].any()
+            src.free(), dst.free()
+    finally:
+        ctx.close()
+    for last in (44, 8):
+        d = ocply.cply_scene(30_011, 23, "clustered")
+        for i in range(last + 1, 45):
+            d["f_rest_%d" % i] = 0
+        wide = lib.host_append_u8_columns(d, ("red", "green", "blue"), rng.integers(0, 256, (len(d), 3), dtype=np.uint8))
+        assert wide.dtype.itemsize == 251
+        stages = {}
+        names = writer.active_sh_names(wide)
+        lib.cply_pack_table(wide, names, None, None, stages)
+        assert "repack" in stages and "upload" in stages          # the resident path, not the host gather
+        a, b = writer.encode(wide), writer.encode(d)
+        for x, y in zip(a[:3], b[:3]):
+            assert (x is None and y is None) or x.tobytes() == y.tobytes()
+        np.testing.assert_array_equal(a[3], b[3])
