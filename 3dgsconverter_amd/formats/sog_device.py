@@ -156,15 +156,12 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
     def alloc(nbytes, name=None):
         return ar.buf("sog_%s" % (name if name is not None else next(names)), nbytes)
 
-    def release(*bs):
-        pass                       # (grow-only arena: nothing is handed back between calls)
-
     out = {"n": n, "width": width, "height": height, "textures": {}, "stats": {}}
     try:
         n_img = 5 + (1 if coeffs_present else 0)
         host_tex_all = np.empty((n_img, texels, 4), np.uint8)
-        toucher = None      # (touching the result pages during the upload -- _lib.prefault, what the compressed-PLY writer does -- slowed the
-                            #  upload's own page pinning by as much as it saved here, where the download hides behind the palette anyway)
+        # (touching the result pages during the upload -- _lib.prefault, what the compressed-PLY writer does -- slowed the upload's own
+        #  page pinning by as much as it saved here, where the download hides behind the palette anyway: not done)
         # ---- the write's random draws (the 50 000-scalar samples of the two codebook fits, :392-397 / :436-440, and the palette's
         # initial centroids) need only n: a helper thread makes them while this one sits in the upload (6-7 ms at 10M splats)
         rng = _draws()
@@ -229,7 +226,6 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         _lib.check(lib.gsx_sog_gather_dev(ctx.handle, d_rows.ptr, C.byref(lay), d_perm.ptr, n, coeffs, d_pos.ptr, d_rot.ptr, d_scale.ptr,
                                           d_dc.ptr, d_op.ptr, d_sh.ptr if d_sh else None), "gsx_sog_gather_dev")
         ctx.synchronize()
-        release(d_rows, d_keys, d_perm)
         st.mark("gather")
 
         # ---- positions, rotations
@@ -299,13 +295,10 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
         al_list = d_list.download(np.uint32, 2 * m_al).reshape(m_al, 2) if m_al else np.zeros((0, 2), np.uint32)
         st.mark("codebooks_codes")
 
-        # ---- SH palette (:496-552) as ONE batched Lloyd call, then the centroid codebook (:561) and its indices
         # ---- SH palette (:496-552) as ONE batched Lloyd call on a worker thread (the C call releases the GIL): while its ~40 ms of
         # kernels run, this thread brings the five finished images back through a second context (its own stream, the staging
         # lanes' DMA engines) and evaluates numpy's log / exp for the listed texels
         host_tex = host_tex_all[:len(tex_names)]      # (one image fewer when the band detection found no SH)
-        if toucher is not None:
-            toucher.join()
         for i, nm in enumerate(tex_names):
             out["textures"][nm] = host_tex[i]
         worker, werr = None, []
