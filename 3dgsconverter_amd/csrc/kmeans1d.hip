@@ -168,6 +168,34 @@ struct K1View {
         }
         return lo;
     }
+    // the same index, searched outwards from where the boundary was one Lloyd step ago (round 6: a boundary moves by a few values per
+    // step once the centroids settle; the 22 dependent loads of the plain bisection were most of an iteration).  g < 0: no guess.
+    __device__ __forceinline__ int64_t upper_from(double t, int64_t g) const
+    {
+        if (g < 0) return upper(t);
+        int64_t lo = 0, hi = n;
+        if (g >= n || (double)xs[g] > t) {          // the answer is at or below g
+            hi = g < n ? g : n;
+            for (int64_t step = 1;; step <<= 1) {
+                const int64_t p = hi - step;
+                if (p < 0) break;
+                if ((double)xs[p] > t) hi = p; else { lo = p + 1; break; }
+            }
+        } else {                                    // xs[g] <= t: the answer is above g
+            lo = g + 1;
+            for (int64_t step = 1;; step <<= 1) {
+                const int64_t p = lo + step - 1;
+                if (p >= n) break;
+                if ((double)xs[p] > t) { hi = p; break; }
+                lo = p + 1;
+            }
+        }
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((double)xs[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    }
 };
 
 __device__ __forceinline__ double k1_block_sum(double v, double *s_red /* [16] */)
@@ -247,8 +275,8 @@ __global__ __launch_bounds__(K1_MAXK) void k1_lloyd_kernel(K1View v, int k, int 
             __syncthreads();
             int64_t b_lo = 0, b_hi = n;
             if (j < k) {
-                if (j > 0) b_lo = v.upper(((double)s_c[j - 1] + (double)c) * 0.5);
-                if (j + 1 < k) b_hi = v.upper(((double)c + (double)s_c[j + 1]) * 0.5);
+                if (j > 0) b_lo = v.upper_from(((double)s_c[j - 1] + (double)c) * 0.5, p_lo);
+                if (j + 1 < k) b_hi = v.upper_from(((double)c + (double)s_c[j + 1]) * 0.5, p_hi);
             }
             const int64_t cnt = j < k ? b_hi - b_lo : 0;
             // round 6: a step that moves no run boundary reproduces its centroids, and so would every later one: the remaining
