@@ -350,14 +350,29 @@ def encode(data: np.ndarray, compression_level: int = 0, device: int = 0, profil
             flat_n = palette * coeffs
             _lib.check(lib.gsx_sog_labels_texels_dev(ctx.handle, d_lab.ptr, n, texels, plan["chunk_size"], k, tex["shN_labels"].ptr),
                        "gsx_sog_labels_texels_dev")
-            status_print("Clustering SH Centroids into Codebook...")
-            d_cb2, d_cidx = alloc(4 * 256), alloc(flat_n)
-            _lib.check(lib.gsx_kmeans1d_dev(ctx.handle, d_cent.ptr, flat_n, 256, 100, 0, d_cb2.ptr, None, None), "gsx_kmeans1d_dev")
-            _lib.check(lib.gsx_quantize_sorted_codebook_dev(ctx.handle, d_cent.ptr, flat_n, d_cb2.ptr, 256, d_cidx.ptr), "gsx_quantize_sorted_codebook_dev")
-            out["palette"] = palette
-            out["shn_codebook"] = d_cb2.download(np.float32, 256).astype(np.float64)
-            out["shn_centroid_index"] = d_cidx.download(np.uint8, flat_n)
-            _lib.check(lib.gsx_dev_download_staged(ctx.handle, host_tex[5].ctypes.data, tex["shN_labels"].ptr, 4 * texels), "gsx_dev_download_staged")
+            ctx.synchronize()              # the labels image is complete: it travels (second context, staging lanes) while the codebook is fitted
+            lerr = []
+
+            def fetch_labels():
+                try:
+                    _lib.check(lib.gsx_dev_download_staged(ar.side.handle, host_tex[5].ctypes.data, tex["shN_labels"].ptr, 4 * texels),
+                               "gsx_dev_download_staged")
+                except BaseException as e:
+                    lerr.append(e)
+            fetcher = threading.Thread(target=fetch_labels, name="gsx-sog-labels")
+            fetcher.start()
+            try:
+                status_print("Clustering SH Centroids into Codebook...")
+                d_cb2, d_cidx = alloc(4 * 256), alloc(flat_n)
+                _lib.check(lib.gsx_kmeans1d_dev(ctx.handle, d_cent.ptr, flat_n, 256, 100, 0, d_cb2.ptr, None, None), "gsx_kmeans1d_dev")
+                _lib.check(lib.gsx_quantize_sorted_codebook_dev(ctx.handle, d_cent.ptr, flat_n, d_cb2.ptr, 256, d_cidx.ptr), "gsx_quantize_sorted_codebook_dev")
+                out["palette"] = palette
+                out["shn_codebook"] = d_cb2.download(np.float32, 256).astype(np.float64)
+                out["shn_centroid_index"] = d_cidx.download(np.uint8, flat_n)
+            finally:
+                fetcher.join()
+            if lerr:
+                raise lerr[0]
             st.mark("centroid_codebook+labels")
         if profile:
             out["_lists"] = (pos_list, al_list)
