@@ -127,6 +127,7 @@ SIGNATURES = {
     "gsx_host_zero_columns": (_I, [_P, _I64, _I64, C.POINTER(_I64), _I]),
     "gsx_host_append_columns": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64]),
     "gsx_host_take_rows_append": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64]),
+    "gsx_host_take_rows_shape": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64, C.POINTER(_I64), _I, _P, _I64]),
     "gsx_rgb_from_sh": (_I, [_P, _I64, _P, _P]),
     "gsx_rgb_from_sh_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
@@ -382,6 +383,32 @@ def host_append_u8_columns(rows: np.ndarray, names, columns: np.ndarray) -> np.n
         return out
     check(load().gsx_host_append_columns(rows.ctypes.data, rows.dtype.itemsize, len(rows), cols.ctypes.data, len(names),
                                          out.ctypes.data, new_dtype.itemsize), "gsx_host_append_columns")
+    return out
+
+
+def host_take_rows_shape(rows: np.ndarray, idx: np.ndarray, names=(), columns: "np.ndarray | None" = None, zero_names=()) -> np.ndarray:
+    """rows[idx] with the float32 fields `zero_names` set to 0.0 and, when `names` / `columns` are given, the u1 fields `names`
+    appended from columns[idx] -- compaction, cap_sh_degree and add_rgb_from_sh (data_processor.py:114,149 / :310-313 / :262-274) in
+    ONE threaded pass (C ABI gsx_host_take_rows_shape)"""
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    names = tuple(names)
+    fields = rows.dtype.fields or {}
+    zero_names = [nm for nm in zero_names if nm in fields]
+    new_dtype = np.dtype(rows.dtype.descr + [(nm, "u1") for nm in names]) if names else rows.dtype
+    tail_ok = all(new_dtype.fields[nm][1] == rows.dtype.itemsize + i for i, nm in enumerate(names))
+    plain = (rows.ndim == 1 and rows.flags.c_contiguous and not rows.dtype.hasobject and tail_ok
+             and all(fields[nm][0].itemsize == 4 for nm in zero_names))
+    if not plain:
+        out = host_take_rows_append_u8(rows, idx, names, columns) if names else host_take_rows(rows, idx)
+        host_zero_columns(out, zero_names)
+        return out
+    cols = np.ascontiguousarray(columns, dtype=np.uint8).reshape(len(rows), len(names)) if names else None
+    out = np.empty(len(idx), dtype=new_dtype)
+    if len(idx):
+        offs = (_I64 * max(len(zero_names), 1))(*[int(fields[nm][1]) for nm in zero_names])
+        check(load().gsx_host_take_rows_shape(rows.ctypes.data, rows.dtype.itemsize, len(rows), idx.ctypes.data, len(idx),
+                                              cols.ctypes.data if names else None, len(names), offs, len(zero_names), out.ctypes.data,
+                                              new_dtype.itemsize), "gsx_host_take_rows_shape")
     return out
 
 

@@ -249,12 +249,40 @@ extern "C" int gsx_host_append_columns(const void *rows, int64_t row_bytes, int6
 // widened copy (:262-274) -- what the reference's converter does for every target that needs colours (converter.py:243-252) -- as
 // ONE pass: output row j = source row idx[j] followed by the extra bytes of THAT source row (extra: n x extra_bytes, indexed like
 // the source table).  idx: strictly ascending row numbers (the device chain's survivor list).
+extern "C" int gsx_host_take_rows_shape(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
+                                        const uint8_t *extra, int64_t extra_bytes, const int64_t *zero_offsets, int nzero, void *out,
+                                        int64_t out_row_bytes);
+
 extern "C" int gsx_host_take_rows_append(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
                                          const uint8_t *extra, int64_t extra_bytes, void *out, int64_t out_row_bytes)
 {
-    if (!rows || !extra || (!idx && n_idx > 0) || (!out && n_idx > 0)) GSX_FAIL("gsx_host_take_rows_append: null argument");
-    if (n < 0 || row_bytes <= 0 || n_idx < 0 || extra_bytes <= 0 || out_row_bytes < row_bytes + extra_bytes) GSX_FAIL("gsx_host_take_rows_append: bad shape");
+    if (!extra || extra_bytes <= 0) GSX_FAIL("gsx_host_take_rows_append: null argument");
+    return gsx_host_take_rows_shape(rows, row_bytes, n, idx, n_idx, extra, extra_bytes, nullptr, 0, out, out_row_bytes);
+}
+
+// ... and cap_sh_degree's column fill (data_processor.py:310-313) in the same pass: zero_offsets = byte offsets of the 4-byte fields
+// to zero in every OUTPUT row (nzero may be 0; extra may be null with extra_bytes 0).  The lazy class's whole table shaping --
+// compaction, SH cap, colours -- is then one read of the survivors and one write of the new table.
+extern "C" int gsx_host_take_rows_shape(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
+                                        const uint8_t *extra, int64_t extra_bytes, const int64_t *zero_offsets, int nzero, void *out,
+                                        int64_t out_row_bytes)
+{
+    if (!rows || (!extra && extra_bytes > 0) || (!idx && n_idx > 0) || (!out && n_idx > 0) || (!zero_offsets && nzero > 0))
+        GSX_FAIL("gsx_host_take_rows_shape: null argument");
+    if (n < 0 || row_bytes <= 0 || n_idx < 0 || extra_bytes < 0 || out_row_bytes < row_bytes + extra_bytes || nzero < 0 || nzero > 4096)
+        GSX_FAIL("gsx_host_take_rows_shape: bad shape");
+    for (int c = 0; c < nzero; ++c)
+        if (zero_offsets[c] < 0 || zero_offsets[c] + 4 > row_bytes) GSX_FAIL("gsx_host_take_rows_shape: column %d outside the row", c);
     if (n_idx == 0) return 0;
+    std::vector<std::pair<int64_t, int64_t>> runs;   // (offset, bytes): contiguous columns become one memset per row
+    {
+        std::vector<int64_t> off(zero_offsets, zero_offsets + nzero);
+        std::sort(off.begin(), off.end());
+        for (int64_t o : off) {
+            if (!runs.empty() && runs.back().first + runs.back().second == o) runs.back().second += 4;
+            else if (runs.empty() || runs.back().first + runs.back().second < o) runs.emplace_back(o, 4);
+        }
+    }
     const int nt = worker_count(2 * n_idx * out_row_bytes);
     const char *src = static_cast<const char *>(rows);
     char *dst = static_cast<char *>(out);
@@ -275,12 +303,13 @@ extern "C" int gsx_host_take_rows_append(const void *rows, int64_t row_bytes, in
             }
             char *d = dst + i * out_row_bytes;
             memcpy(d, src + r * row_bytes, (size_t)row_bytes);
-            memcpy(d + row_bytes, extra + r * extra_bytes, (size_t)extra_bytes);
+            for (const auto &ru : runs) memset(d + ru.first, 0, (size_t)ru.second);
+            if (extra_bytes) memcpy(d + row_bytes, extra + r * extra_bytes, (size_t)extra_bytes);
             if (pad) memset(d + row_bytes + extra_bytes, 0, (size_t)pad);
         }
     });
     for (int t = 0; t < nt; ++t)
-        if (bad[t]) GSX_FAIL("gsx_host_take_rows_append: the index list is not strictly ascending inside [0, n)");
+        if (bad[t]) GSX_FAIL("gsx_host_take_rows_shape: the index list is not strictly ascending inside [0, n)");
     return 0;
 }
 

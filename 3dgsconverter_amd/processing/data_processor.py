@@ -114,10 +114,13 @@ class DataProcessor:
                 if ch.n != ch.n0 or copy_always:
                     # the chain's survivor list (ascending row indices) applied to the host table directly -- round 5: the
                     # boolean mask numpy would index with (`mask[survivors] = True` on 8M indices) cost more than the compaction
-                    if rgb is not None:
-                        # round 6: ... and add_rgb_from_sh's widened copy (:262-274) in the same pass (the reference's converter calls
-                        # it after the filters for every target that needs colours, converter.py:243-252): one new table, not two
-                        self._data = _lib.host_take_rows_append_u8(self._data, ch.survivors(), ("red", "green", "blue"), rgb)
+                    if rgb is not None or self._pending_zero:
+                        # round 6: ... and add_rgb_from_sh's widened copy (:262-274; the reference's converter calls it after the filters
+                        # for every target that needs colours, converter.py:243-252) and cap_sh_degree's deferred column fill (:310-313)
+                        # in the same pass: one read of the survivors, one write of the new table
+                        zero, self._pending_zero = self._pending_zero, []
+                        self._data = _lib.host_take_rows_shape(self._data, ch.survivors(), ("red", "green", "blue") if rgb is not None else (),
+                                                               rgb, zero)
                         rgb = None
                     else:
                         self._data = _lib.host_take_rows(self._data, ch.survivors())

@@ -197,6 +197,12 @@ int gsx_host_append_columns(const void *rows, int64_t row_bytes, int64_t n, cons
  * ascending).  One pass over the survivors instead of two copies of the table. */
 int gsx_host_take_rows_append(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
                               const uint8_t *extra, int64_t extra_bytes, void *out, int64_t out_row_bytes);
+/* ... and cap_sh_degree's column fill (data_processor.py:310-313 `self.data[f_rest_i] = 0.0`) in the same pass: zero_offsets = byte
+ * offsets of nzero 4-byte fields to zero in every OUTPUT row; extra may be NULL with extra_bytes 0 (no columns appended).  The lazy
+ * class's whole table shaping -- compaction, SH cap, colours -- is one read of the survivors and one write of the new table. */
+int gsx_host_take_rows_shape(const void *rows, int64_t row_bytes, int64_t n, const uint32_t *idx, int64_t n_idx,
+                             const uint8_t *extra, int64_t extra_bytes, const int64_t *zero_offsets, int nzero, void *out,
+                             int64_t out_row_bytes);
 
 /*
  * The O(N) row filters that run before density / SOR (converter.py:196-203), as device masks over the chain's rows --

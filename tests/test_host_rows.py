@@ -227,3 +227,38 @@ def test_take_rows_and_append_columns_in_one_pass():
         L.host_take_rows_append_u8(t, np.array([5, 5], dtype=np.uint32), ("red", "green", "blue"), cols)
     with pytest.raises(L.GsxError):
         L.host_take_rows_append_u8(t, np.array([0, n], dtype=np.uint32), ("red", "green", "blue"), cols)
+
+
+def test_take_rows_shape_is_compaction_then_sh_cap_then_colours():
+    """round 6: gsx_host_take_rows_shape == `vertices[mask]` (data_processor.py:114,149), `data[f_rest_i] = 0.0` for the capped columns
+    (:310-313) and the widened copy with the survivors' colours (:262-274), in one pass -- with and without colours, with and
+    without zeroed columns; a table the C routine does not take (strided view) goes through the separate steps"""
+    rng = np.random.default_rng(21)
+    n = 60_001
+    t = _table(n, False, seed=5)
+    cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    zero_sets = ([], ["f_rest_%d" % i for i in range(9, 45)], ["f_rest_3", "f_rest_4", "f_rest_40", "opacity"])
+    for frac in (0.0, 0.5, 1.0):
+        mask = rng.random(n) < frac
+        idx = np.flatnonzero(mask).astype(np.uint32)
+        for zero in zero_sets:
+            for with_rgb in (False, True):
+                got = L.host_take_rows_shape(t, idx, ("red", "green", "blue") if with_rgb else (), cols if with_rgb else None, zero)
+                kept = t[mask]
+                for nm in zero:
+                    kept[nm] = 0.0
+                if with_rgb:
+                    want = np.empty(len(kept), dtype=np.dtype(t.dtype.descr + [("red", "u1"), ("green", "u1"), ("blue", "u1")]))
+                    for nm in t.dtype.names:
+                        want[nm] = kept[nm]
+                    for i, nm in enumerate(("red", "green", "blue")):
+                        want[nm] = cols[mask, i]
+                else:
+                    want = kept
+                assert got.dtype == want.dtype and got.tobytes() == want.tobytes(), (frac, len(zero), with_rgb)
+    view = t[::2]
+    idx = np.arange(0, len(view), 3, dtype=np.uint32)
+    got = L.host_take_rows_shape(view, idx, (), None, ["f_rest_7"])
+    want = view[idx]
+    want["f_rest_7"] = 0.0
+    assert got.tobytes() == want.tobytes()
