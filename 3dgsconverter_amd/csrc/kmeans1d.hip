@@ -210,9 +210,13 @@ __device__ __forceinline__ double k1_block_sum(double v, double *s_red /* [16] *
     return t;
 }
 
-// One workgroup, K threads (rounded up to a wave).  mode_mask: bit 0 = uniform-bin start, bit 1 = equal-count-bin start.
+// One workgroup PER START, K threads each (rounded up to a wave).  mode_mask: bit 0 = uniform-bin start, bit 1 = equal-count-bin start.
+// Round 6: the two starts used to run one after the other in ONE workgroup (a launch is a chain of dependent loads: latency, not
+// throughput); now each has a workgroup of its own, parks its centroids in cent_tmp and the last one to arrive picks the winner by
+// the old rule (start A unless B's inertia is strictly smaller).
 __global__ __launch_bounds__(K1_MAXK) void k1_lloyd_kernel(K1View v, int k, int iters, int mode_mask, float *__restrict__ cent_out,
-                                                           double *__restrict__ inertia_out /* [3]: chosen, start A, start B */)
+                                                           double *__restrict__ inertia_out /* [3]: chosen, start A, start B */,
+                                                           float *__restrict__ cent_tmp /* [2][K1_MAXK] */, unsigned *__restrict__ ticket)
 {
     __shared__ double s_w[K1_BINS + 1];
     __shared__ float s_c[K1_MAXK + 1];
@@ -220,10 +224,9 @@ __global__ __launch_bounds__(K1_MAXK) void k1_lloyd_kernel(K1View v, int k, int 
     const int j = threadIdx.x;
     const int64_t n = v.n;
     const double lo = (double)v.xs[0], hi = (double)v.xs[n - 1];
-    float best_c = (float)lo;
-    double best_inertia = 1.0e300;
-    for (int mode = 0; mode < 2; ++mode) {
-        if (!((mode_mask >> mode) & 1)) continue;
+    __shared__ unsigned s_last;
+    {
+        const int mode = mode_mask == 3 ? (int)blockIdx.x : (mode_mask >> 1);   // (one workgroup per set bit; mask 1 -> start A, 2 -> start B)
         // ---- companded start: weight of bin b, exclusive scan, centroid j at the (j + 1/2)/K quantile of the weights
         for (int b = j; b < K1_BINS; b += blockDim.x) {
             double w;
@@ -294,15 +297,30 @@ __global__ __launch_bounds__(K1_MAXK) void k1_lloyd_kernel(K1View v, int k, int 
             if (cnt > 0) c = (float)((v.s1(b_hi) - v.s1(b_lo)) / (double)cnt);
         }
         const double inertia = k1_block_sum(my_inertia, s_red);
-        if (j == 0) inertia_out[1 + mode] = inertia;
-        if (inertia < best_inertia) {
-            best_inertia = inertia;
-            best_c = c;
-        }
-        __syncthreads();
+        if (j < k) __hip_atomic_store(&cent_tmp[mode * K1_MAXK + j], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j == 0) __hip_atomic_store(&inertia_out[1 + mode], inertia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (j < k) cent_out[j] = best_c;
-    if (j == 0) inertia_out[0] = best_inertia;
+    __threadfence();
+    __syncthreads();
+    if (j == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // the last workgroup to arrive: start A unless start B ran and its inertia is strictly smaller (the sequential rule)
+    int win = (mode_mask & 1) ? 0 : 1;
+    double best_inertia = __hip_atomic_load(&inertia_out[1 + win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mode_mask == 3) {
+        const double ib = __hip_atomic_load(&inertia_out[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ib < best_inertia) {
+            best_inertia = ib;
+            win = 1;
+        }
+    }
+    if (j < k) cent_out[j] = __hip_atomic_load(&cent_tmp[win * K1_MAXK + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == 0) {
+        inertia_out[0] = best_inertia;
+        *ticket = 0u;
+    }
 }
 
 // label = nearest centroid, ties to the lower index (gpu_ops.py:66-70: strict `<` keeps the first minimum); centroids ascending
@@ -339,7 +357,7 @@ static int kmeans1d_dev(gsx_ctx *c, const float *vals, int64_t n, int k, int ite
         GSX_FAIL("kmeans1d: rocprim size query failed");
     // layout: keys A | keys B | xs | p1 | p2 | tiles (2 x (ntiles + 1)) | flags + inertia | temp
     const size_t un = sizeof(unsigned) * (size_t)n, dn = sizeof(double) * (size_t)n;
-    const size_t bytes = 3 * un + 2 * dn + sizeof(double) * 2 * (size_t)(ntiles + 2) + 256 + temp_bytes + 1024;
+    const size_t bytes = 3 * un + 2 * dn + sizeof(double) * 2 * (size_t)(ntiles + 2) + 256 + temp_bytes + 1024 + sizeof(float) * 2 * K1_MAXK + 256;
     GSX_CHECK(c->scratch5.reserve(bytes));
     char *p = c->scratch5.as<char>();
     auto take = [&](size_t b) {
@@ -351,8 +369,9 @@ static int kmeans1d_dev(gsx_ctx *c, const float *vals, int64_t n, int k, int ite
     float *xs = reinterpret_cast<float *>(take(un));
     double *p1 = reinterpret_cast<double *>(take(dn)), *p2 = reinterpret_cast<double *>(take(dn));
     double *tiles = reinterpret_cast<double *>(take(sizeof(double) * 2 * (size_t)(ntiles + 2)));
-    unsigned *flags = reinterpret_cast<unsigned *>(take(64));
+    unsigned *flags = reinterpret_cast<unsigned *>(take(64));     // [0]: non-finite input, [8]: k1_lloyd's arrival ticket
     double *inertia = reinterpret_cast<double *>(take(64));
+    float *cent_tmp = reinterpret_cast<float *>(take(sizeof(float) * 2 * K1_MAXK));
     void *temp = take(temp_bytes);
     GSX_HIP(hipMemsetAsync(flags, 0, 64, c->stream));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
@@ -362,7 +381,8 @@ static int kmeans1d_dev(gsx_ctx *c, const float *vals, int64_t n, int k, int ite
     hipLaunchKernelGGL(k1_tile_scan_kernel, dim3(1), dim3(256), 0, c->stream, tiles, ntiles);
     K1View v{xs, p1, p2, tiles, n};
     const int threads = std::min(K1_MAXK, ((k + 63) / 64) * 64);
-    hipLaunchKernelGGL(k1_lloyd_kernel, dim3(1), dim3(threads), 0, c->stream, v, k, iters, mode_mask, cent_dev, inertia);
+    hipLaunchKernelGGL(k1_lloyd_kernel, dim3(mode_mask == 3 ? 2 : 1), dim3(threads), 0, c->stream, v, k, iters, mode_mask, cent_dev, inertia,
+                       cent_tmp, flags + 8);
     if (labels_dev) hipLaunchKernelGGL(k1_labels_kernel, dim3(blocks), dim3(256), 0, c->stream, vals, n, cent_dev, k, labels_dev);
     GSX_HIP(hipGetLastError());
     unsigned hflag = 0;
