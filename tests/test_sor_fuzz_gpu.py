@@ -31,3 +31,11 @@ def test_fuzz_sog_slice(gsx):
     compression level -- against the restated reference statements (oracle/sog.py), five images byte for byte"""
     import fuzz_sog
     assert fuzz_sog.main(cases=16, seed=20260930) == 0
+
+
+def test_fuzz_chain_slice(gsx):
+    """round 6: 25 random sequences of the drop-in DataProcessor's methods (bbox / alpha / density / SOR / SH cap / colours / auto-bbox in
+    any order), lazy class -- device chain, deferred column fills and colours, ONE fused compaction (gsx_host_take_rows_shape) --
+    against the eager class: the final tables are the same bytes"""
+    import fuzz_chain
+    assert fuzz_chain.main(cases=25, seed=20261001) == 0
