@@ -262,3 +262,52 @@ def test_take_rows_shape_is_compaction_then_sh_cap_then_colours():
     want = view[idx]
     want["f_rest_7"] = 0.0
     assert got.tobytes() == want.tobytes()
+
+
+def test_row_filters_and_sh_cap_against_the_reference_class_on_random_sequences():
+    """build container only: random sequences of crop_by_bbox / apply_alpha_filter / cap_sh_degree / apply_auto_bbox (the methods of the
+    eager drop-in class that need no device) against the REFERENCE's own class on the same table -- bounds as Python floats, ints,
+    numpy float32 / float64 scalars, coordinates with NaN and +-inf, thresholds at both ends.  Round 6 moved these methods onto
+    contiguous copies of the columns (one threaded gather): the expressions must keep numpy's promotion rules.  Same bytes, same
+    printed box."""
+    from oracle import refload
+    if not refload.available():
+        pytest.skip("reference not mounted (build container only)")
+    import contextlib, io
+    RefDP, _, _ = refload.load()
+    dp = importlib.import_module("3dgsconverter_amd.processing.data_processor")
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        n = int(rng.integers(4096, 60000))
+        t = _table(n, bool(case % 3 == 0), seed=case)
+        for a in "xyz":
+            t[a] = (rng.standard_normal(n) * 3).astype(np.float32)
+        t["opacity"] = (rng.standard_normal(n) * 3).astype(np.float32)
+        if case % 4 == 0:
+            t["x"][rng.integers(0, n, 5)] = np.nan
+            t["y"][rng.integers(0, n, 5)] = np.inf
+            t["opacity"][rng.integers(0, n, 5)] = np.nan
+        steps = []
+        for _ in range(int(rng.integers(1, 5))):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                lo, hi = sorted(rng.uniform(-6, 6, 2))
+                cast = [float, lambda v: int(round(v)), np.float32, np.float64][int(rng.integers(0, 4))]
+                steps.append(("crop_by_bbox", tuple(cast(v) for v in (lo, lo - 1, lo, hi, hi + 1, hi))))
+            elif kind == 1:
+                steps.append(("apply_alpha_filter", (int(rng.choice([0, 1, 17, 128, 200, 254, 255])),)))
+            elif kind == 2:
+                steps.append(("cap_sh_degree", (int(rng.integers(0, 4)),)))
+            else:
+                steps.append(("apply_auto_bbox", ()))
+        outs, logs = [], []
+        for cls in (RefDP, dp.DataProcessor):
+            p = cls(t.copy())
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
+                for name, args in steps:
+                    getattr(p, name)(*args)
+            outs.append(p.data)
+            logs.append([l for l in buf.getvalue().splitlines() if l.startswith("Auto-BBox") or l.startswith("Alpha Filter") or l.startswith("After cropping")])
+        assert outs[0].dtype == outs[1].dtype and outs[0].tobytes() == outs[1].tobytes(), (case, steps)
+        assert logs[0] == logs[1], (case, steps, logs)
