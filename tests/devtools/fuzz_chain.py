@@ -26,7 +26,10 @@ def make(rng):
         kind = str(rng.choice(["bbox", "alpha", "density", "sor", "cap", "rgb", "auto"]))
         if kind == "bbox":
             lo, hi = sorted(rng.uniform(-0.1 * edge, 1.1 * edge, 2))
-            steps.append(("crop_by_bbox", (lo, lo, lo, hi, hi, hi)))
+            # bounds as the caller may hand them: Python floats (weak scalars: the comparison stays float32), numpy scalars of either
+            # width (float64 promotes the comparison), ints
+            cast = [float, np.float32, np.float64, lambda v: int(round(v))][int(rng.integers(0, 4))]
+            steps.append(("crop_by_bbox", tuple(cast(v) for v in (lo, lo, lo, hi, hi, hi))))
         elif kind == "alpha":
             steps.append(("apply_alpha_filter", (int(rng.integers(0, 256)),)))
         elif kind == "density":
