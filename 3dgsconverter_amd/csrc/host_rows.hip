@@ -336,7 +336,7 @@ struct StagePool {
 } g_stage;
 std::atomic_flag g_stage_busy = ATOMIC_FLAG_INIT;
 
-int stage_prepare(int device, int lanes)
+int stage_prepare(int device, int lanes, bool with_buffers = true)
 {
     if (g_stage.device != device && g_stage.ready) {   // another GPU: rebuild (one process normally drives one)
         for (int l = 0; l < g_stage.ready; ++l) {
@@ -353,13 +353,16 @@ int stage_prepare(int device, int lanes)
     g_stage.device = device;
     for (int l = g_stage.ready; l < lanes; ++l) {
         StageLane &s = g_stage.lanes[l];
-        for (int b = 0; b < 2; ++b) {
-            GSX_HIP(hipHostMalloc(&s.pin[b], STAGE_CHUNK, hipHostMallocDefault));
-            GSX_HIP(hipEventCreateWithFlags(&s.ev[b], hipEventDisableTiming));
-        }
+        for (int b = 0; b < 2; ++b) GSX_HIP(hipEventCreateWithFlags(&s.ev[b], hipEventDisableTiming));
         GSX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         g_stage.ready = l + 1;
     }
+    // the lanes' page-locked 8 MiB buffers only for the paths that copy through them: pinning 2 x 8 MiB per lane costs tens of
+    // milliseconds, which the first upload of a process (pinned IN PLACE: register_copy) used to pay for nothing
+    if (with_buffers)
+        for (int l = 0; l < lanes; ++l)
+            for (int b = 0; b < 2; ++b)
+                if (!g_stage.lanes[l].pin[b]) GSX_HIP(hipHostMalloc(&g_stage.lanes[l].pin[b], STAGE_CHUNK, hipHostMallocDefault));
     return 0;
 }
 
@@ -375,7 +378,7 @@ constexpr int REG_LANES = 6;
 int register_copy(gsx_ctx *c, char *dev, char *host, size_t bytes, bool upload)
 {
     if (g_stage_busy.test_and_set()) return 1;
-    int rc = stage_prepare(c->device, REG_LANES);   // (the lanes' streams and events; their pinned buffers stay unused here)
+    int rc = stage_prepare(c->device, REG_LANES, false);   // (the lanes' streams and events only)
     std::atomic<int> failed{0};
     if (rc == 0) {
         // chunk borders on 2 MiB multiples of the ADDRESS: no page is shared by two chunks (a page registered twice fails)
