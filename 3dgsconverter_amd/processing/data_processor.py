@@ -57,7 +57,16 @@ def _reference_class():
 
 
 def _xyz_rows(vertices):
-    """reference :38/:139 `coords` -- (N,3) float32, gathered from the AoS table by the threaded C routine"""
+    """reference :38/:139 `coords` -- (N,3) float32, gathered from the AoS table by the threaded C routine.  Large tables: into a
+    page-locked staging buffer the arena keeps (round 6: a fresh 12n-byte array costs as much to fault in, copy from at pageable rate and
+    unmap again as the filter itself) -- the result is only valid until the next call and is used at once by the eager methods"""
+    n = len(vertices)
+    if n >= 65536 and isinstance(vertices, np.ndarray):
+        try:
+            buf = _lib.arena(0).pinned("eager_xyz", 12 * n)[:12 * n].view(np.float32).reshape(n, 3)
+            return _lib.host_gather_xyz(vertices, out=buf)
+        except _lib.GsxError:
+            pass                        # no device: the callers' device entry points say so themselves
     return _lib.host_gather_xyz(vertices)
 
 
