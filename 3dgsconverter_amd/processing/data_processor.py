@@ -374,8 +374,17 @@ class DataProcessor:
             return (rgb * 255).astype(np.uint8)
         # (round 6: the three columns leave the table in ONE threaded pass and go through the device as one array -- three strided
         #  numpy copies of a 248-byte-stride column cost ~50 ms each at 10M splats)
-        mat = _lib.host_gather_xyz(vertices, [prefix + "f_dc_%d" % c for c in range(3)])       # (n, 3): the colours' own layout
-        return _lib.rgb_from_sh(mat.reshape(-1)).reshape(len(vertices), 3)
+        names3 = [prefix + "f_dc_%d" % c for c in range(3)]
+        n = len(vertices)
+        mat = None
+        if n >= 65536:      # (n, 3), the colours' own layout, into a page-locked staging buffer of the arena (as _xyz_rows does)
+            try:
+                mat = _lib.host_gather_xyz(vertices, names3, out=_lib.arena(0).pinned("rgb_in", 12 * n)[:12 * n].view(np.float32).reshape(n, 3))
+            except _lib.GsxError:
+                mat = None
+        if mat is None:
+            mat = _lib.host_gather_xyz(vertices, names3)
+        return _lib.rgb_from_sh(mat.reshape(-1)).reshape(n, 3)
 
     def add_rgb_from_sh(self):
         """reference :233-274: append (red, green, blue) u1 fields computed from the SH DC term"""
