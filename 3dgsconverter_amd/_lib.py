@@ -130,6 +130,8 @@ SIGNATURES = {
     "gsx_host_take_rows_shape": (_I, [_P, _I64, _I64, _P, _I64, _P, _I64, C.POINTER(_I64), _I, _P, _I64]),
     "gsx_rgb_from_sh": (_I, [_P, _I64, _P, _P]),
     "gsx_rgb_from_sh_dev": (_I, [_P, _P, _I64, _P, _P]),
+    "gsx_rgb_from_sh_list": (_I, [_P, _I64, _P, _P, _I64, C.POINTER(_I64)]),
+    "gsx_rgb_from_sh_list_dev": (_I, [_P, _P, _I64, _P, _P, _I64, _P]),
     "gsx_compact_rows_dev": (_I, [_P, _P, _P, _P, _I64, _P, _P, C.POINTER(_I64)]),
     "gsx_mask_bbox_dev": (_I, [_P, _P, _I64, _P, _P]),
     "gsx_mask_ge_dev": (_I, [_P, _P, _P, _I64, _D, _P]),
@@ -456,9 +458,18 @@ def rgb_from_sh(f_dc: np.ndarray, stats: dict | None = None) -> np.ndarray:
     out = np.empty(n, dtype=np.uint8)
     if n == 0:
         return out
-    unc = np.empty(n, dtype=np.uint8)
-    check(lib.gsx_rgb_from_sh(v.ctypes.data, n, out.ctypes.data, unc.ctypes.data), "gsx_rgb_from_sh")
-    idx = nonzero_bytes(unc)
+    # the uncertain elements as a compact index list (about 1e-4 of the values); a table with more of them than the list holds (NaNs by
+    # the million) takes the flag-per-element form
+    cap = n // 64 + 4096
+    lst = np.empty(cap, dtype=np.uint32)
+    cnt = _I64(0)
+    check(lib.gsx_rgb_from_sh_list(v.ctypes.data, n, out.ctypes.data, lst.ctypes.data, cap, C.byref(cnt)), "gsx_rgb_from_sh_list")
+    if cnt.value <= cap:
+        idx = np.sort(lst[:cnt.value]).astype(np.int64)
+    else:
+        unc = np.empty(n, dtype=np.uint8)
+        check(lib.gsx_rgb_from_sh(v.ctypes.data, n, out.ctypes.data, unc.ctypes.data), "gsx_rgb_from_sh")
+        idx = nonzero_bytes(unc)
     if len(idx):
         with np.errstate(all="ignore"):
             lin = np.clip(0.5 + v[idx] * 0.28209479177387814, 0.0, 1.0)

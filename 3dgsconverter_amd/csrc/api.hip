@@ -743,6 +743,34 @@ int gsx_rgb_from_sh(const float *f_dc, int64_t n, uint8_t *out, uint8_t *uncerta
     return 0;
 }
 
+int gsx_rgb_from_sh_list(const float *f_dc, int64_t n, uint8_t *out, uint32_t *list_out, int64_t cap, int64_t *count_out)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    if (!f_dc || !out || !count_out || (cap > 0 && !list_out)) GSX_FAIL("gsx_rgb_from_sh_list: null argument");
+    *count_out = 0;
+    if (n <= 0) return 0;
+    gsx_ctx *c;
+    GSX_CHECK(host_ctx(&c));
+    GSX_CHECK(c->scratch.reserve(sizeof(float) * (size_t)n));
+    GSX_CHECK(c->scratch4.reserve((size_t)n + 16 + 16 + 4 * (size_t)cap));
+    uint8_t *d_out = c->scratch4.as<uint8_t>();
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->scratch4.as<char>() + (((size_t)n + 15) & ~(size_t)15));
+    uint32_t *d_list = d_cnt + 4;
+    GSX_HIP(hipMemcpyAsync(c->scratch.p, f_dc, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GSX_CHECK(gsx_rgb_from_sh_list_dev(c, c->scratch.as<float>(), n, d_out, d_list, cap, d_cnt));
+    uint32_t hc = 0;
+    GSX_HIP(hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipMemcpyAsync(&hc, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(hipStreamSynchronize(c->stream));
+    *count_out = hc;
+    const size_t m = std::min<size_t>(hc, (size_t)cap);
+    if (m) {
+        GSX_HIP(hipMemcpyAsync(list_out, d_list, 4 * m, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 int gsx_sog_positions(const float *v, int64_t n, float log_min, float log_max, uint16_t *out, uint8_t *uncertain_out)
 {
     std::lock_guard<std::mutex> lk(g_host_mu);

@@ -122,12 +122,21 @@ __device__ __forceinline__ float chain_ulp_step(float a, int steps)
     return __uint_as_float((unsigned)b);
 }
 
+// LIST: the uncertain elements as a compact list of their indices (wave-aggregated append; *count keeps counting past cap) instead of a
+// flag byte per element -- round 6: the 30 MB of flags of a 10M-splat table cost 2 ms to bring back and 6.5 ms to scan on the host
+template <bool LIST>
 __global__ __launch_bounds__(256) void rgb_from_sh_kernel(const float *__restrict__ f_dc, int64_t n, uint8_t *__restrict__ out,
-                                                          uint8_t *__restrict__ uncertain)
+                                                          uint8_t *__restrict__ uncertain, unsigned *__restrict__ list, unsigned cap,
+                                                          unsigned *__restrict__ count)
 {
     const float c0 = 0.28209479177387814f;            // np.float32(SH_C0)
     const double e = (double)(float)(1.0 / 2.2);       // the exponent numpy uses: float32(1.0 / 2.2)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t span = LIST ? ((n + 255) / 256) * 256 : n;   // (LIST: whole waves stay together for the ballot)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < span; i += (int64_t)gridDim.x * 256) {
+        if (LIST && i >= n) {
+            (void)__ballot(false);
+            continue;
+        }
         const float v = f_dc[i];
         float lin = __fadd_rn(0.5f, __fmul_rn(v, c0));
         lin = fminf(fmaxf(lin, 0.0f), 1.0f);           // np.clip (NaN propagates: flagged below)
@@ -145,7 +154,21 @@ __global__ __launch_bounds__(256) void rgb_from_sh_kernel(const float *__restric
         }
         ok = ok && q[0] == q[1];
         out[i] = (uint8_t)q[0];
-        uncertain[i] = ok ? 0 : 1;
+        if constexpr (LIST) {
+            const unsigned long long m = __ballot(!ok);
+            if (m != 0ull) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+                base = (unsigned)__shfl((int)base, leader);
+                if (!ok) {
+                    const unsigned pslot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pslot < cap) list[pslot] = (unsigned)i;
+                }
+            }
+        } else {
+            uncertain[i] = ok ? 0 : 1;
+        }
     }
 }
 
@@ -159,7 +182,21 @@ extern "C" int gsx_rgb_from_sh_dev(gsx_ctx *c, const float *f_dc_dev, int64_t n,
     GSX_HIP(hipSetDevice(c->device));
     if (n <= 0) return 0;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
-    hipLaunchKernelGGL(rgb_from_sh_kernel, dim3(blocks), dim3(256), 0, c->stream, f_dc_dev, n, out_dev, uncertain_dev);
+    hipLaunchKernelGGL(rgb_from_sh_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, f_dc_dev, n, out_dev, uncertain_dev, nullptr, 0u, nullptr);
+    GSX_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gsx_rgb_from_sh_list_dev(gsx_ctx *c, const float *f_dc_dev, int64_t n, uint8_t *out_dev, uint32_t *list_dev, int64_t cap,
+                                        uint32_t *count_dev)
+{
+    if (!c || !count_dev || (n > 0 && (!f_dc_dev || !out_dev)) || (cap > 0 && !list_dev)) GSX_FAIL("gsx_rgb_from_sh_list_dev: null argument");
+    if (n < 0 || n >= (1LL << 32) || cap < 0 || cap > 0xffffffffLL) GSX_FAIL("gsx_rgb_from_sh_list_dev: bad size");
+    GSX_HIP(hipSetDevice(c->device));
+    GSX_HIP(hipMemsetAsync(count_dev, 0, 4, c->stream));
+    if (n == 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(div_up(n, 1024), (int64_t)c->num_cu * 8));
+    hipLaunchKernelGGL(rgb_from_sh_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, f_dc_dev, n, out_dev, nullptr, list_dev, (unsigned)cap, count_dev);
     GSX_HIP(hipGetLastError());
     return 0;
 }

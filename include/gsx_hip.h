@@ -181,6 +181,12 @@ int gsx_compact_rows_dev(gsx_ctx *ctx, const float *rows_dev, const uint32_t *or
  */
 int gsx_rgb_from_sh(const float *f_dc, int64_t n, uint8_t *out, uint8_t *uncertain_out);
 int gsx_rgb_from_sh_dev(gsx_ctx *ctx, const float *f_dc_dev, int64_t n, uint8_t *out_dev, uint8_t *uncertain_dev);
+/* the same colours with the uncertain elements as a LIST of their indices (unordered; `cap` entries, *count keeps counting past
+ * cap: the caller then falls back to the flag form) instead of one flag byte per value: for a 10M-splat table the 30 MB of flags
+ * cost more to bring back and scan on the host (8 ms) than the colours themselves */
+int gsx_rgb_from_sh_list(const float *f_dc, int64_t n, uint8_t *out, uint32_t *list_out, int64_t cap, int64_t *count_out);
+int gsx_rgb_from_sh_list_dev(gsx_ctx *ctx, const float *f_dc_dev, int64_t n, uint8_t *out_dev, uint32_t *list_dev, int64_t cap,
+                             uint32_t *count_dev);
 /*
  * Host row helpers of the two table-shaping methods (threaded, no device code):
  *   gsx_host_zero_columns   -- data_processor.py:276-314 cap_sh_degree: `self.data[f_rest_i] = 0.0` for the columns above the
